@@ -1,0 +1,183 @@
+"""CPU oracle for the per-cluster multi-view depth renderer.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product path (vilgod_amd/) never imports it.
+
+Pinned against the reference itself: tests/golden/make_golden.py runs the
+reference's own `mv_utils.RealisticProjection.get_img`,
+`pointcloud_utils.transform_cluster_points_to_origin` and the resize/quantise
+lines of `ZeroShotDetector.classification` (stub-imported from /root/reference
+in the build container) and tests/test_oracle_render.py checks this restatement
+against those frozen outputs bit for bit.
+
+Reference lines restated (paths relative to /root/reference):
+  D1 src/utils/pointcloud_utils.py:390-412  transform_cluster_points_to_origin
+  D2 src/utils/mv_utils.py:40-88,134-141,166,189-201  euler2mat, views, point_transform
+  D3 src/utils/mv_utils.py:91-127            points2grid
+  D4 src/utils/mv_utils.py:11-37,204-220     GridToImage + Gaussian kernel
+  D5 src/vilgod/zero_shot_detector.py:405-409 bilinear resize, H<->W permute, uint8 truncation
+  D6 third_party/CLIP/clip/clip.py:79-86     ToTensor + Normalize (Resize/CenterCrop are
+     identities at 224x224)
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.spatial.transform import Rotation as R
+
+RESOLUTION = 112
+DEPTH = 8
+OBJ_RATIO = 0.8
+DEPTH_BIAS = 0.2
+IMAGE_SIZE = 224
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+# mv_utils.py:134-141 -- the four hard-coded views (euler x, y, z); translation is unused.
+VIEW_ANGLES = np.asarray([
+    [0.0, 0.0, 0.0],
+    [-np.pi / 10, 0.0, 0.0],
+    [0.0, np.pi / 30, 0.0],
+    [0.0, -np.pi / 30, 0.0],
+])
+# the two commented-out views of mv_utils.py:139-140; BASELINE config 3 ("6-view render")
+VIEW_ANGLES_6 = np.concatenate([VIEW_ANGLES, np.asarray([
+    [-np.pi / 10, np.pi / 30, 0.0],
+    [-np.pi / 10, -np.pi / 30, 0.0],
+])])
+
+
+def apply_transform(pts, T):
+    """pointcloud_utils.py:21-46 (numpy branch, mode='left', box=False): result is written
+    back into a copy of `pts`, i.e. rounded to pts.dtype."""
+    if len(pts) == 0:
+        return pts
+    out = pts.copy()
+    h = np.hstack((out[:, :3], np.ones((len(out), 1))))
+    out[..., :3] = np.einsum('ij,kj->ki', T, h)[..., :3]
+    return out
+
+
+def cluster_to_origin(points):
+    """D1. `points`: (P,3) in the ego frame, any float dtype (the reference passes float32).
+    Returns float64 (P,3) exactly as pointcloud_utils.py:390-412 does."""
+    rot1 = R.from_euler('z', np.pi / 2.)
+    rot2 = R.from_euler('x', np.pi)
+    pts = points.copy()
+    c = np.median(pts[..., :3], axis=0)
+    angle = np.arctan2(c[1], c[0])
+    rot3 = R.from_euler('z', -angle)
+    pts[..., :2] -= c[:2]
+    pts = rot3.apply(pts)
+    pts[..., 0] -= 1
+    pts = np.stack([pts[:, 2], pts[:, 1], pts[:, 0]], axis=1)
+    T = np.eye(4)
+    T[:3, :3] = rot2.as_matrix() @ rot1.as_matrix()
+    return apply_transform(pts, T)
+
+
+def euler_to_mat(angle):
+    """mv_utils.py:40-88 for a [V,3] float32 tensor -> [V,3,3] (xmat @ ymat @ zmat)."""
+    x, y, z = angle[:, 0], angle[:, 1], angle[:, 2]
+    zero = z * 0
+    one = zero + 1
+    cz, sz = torch.cos(z), torch.sin(z)
+    zmat = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).reshape(-1, 3, 3)
+    cy, sy = torch.cos(y), torch.sin(y)
+    ymat = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).reshape(-1, 3, 3)
+    cx, sx = torch.cos(x), torch.sin(x)
+    xmat = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).reshape(-1, 3, 3)
+    return xmat @ ymat @ zmat
+
+
+def view_matrices(view_angles=VIEW_ANGLES):
+    """mv_utils.py:165-166: rot_mat = euler2mat(angle).transpose(1,2); points @ rot_mat."""
+    ang = torch.tensor(view_angles).float()
+    return euler_to_mat(ang).transpose(1, 2).contiguous()
+
+
+def points_to_grid(points):
+    """D3, mv_utils.py:91-127.  points: [B,P,3] float32 tensor -> [B,DEPTH,R,R] (already
+    permuted (0,1,3,2))."""
+    points = points.clone()
+    batch = points.shape[0]
+    pmax, pmin = points.max(dim=1)[0], points.min(dim=1)[0]
+    pcent = ((pmax + pmin) / 2)[:, None, :]
+    prange = (pmax - pmin).max(dim=-1)[0][:, None, None]
+    points = (points - pcent) / prange * 2.
+    points[:, :, :2] = points[:, :, :2] * OBJ_RATIO
+    _x = (points[:, :, 0] + 1) / 2 * RESOLUTION
+    _y = (points[:, :, 1] + 1) / 2 * RESOLUTION
+    _z = ((points[:, :, 2] + 1) / 2 + DEPTH_BIAS) / (1 + DEPTH_BIAS) * (DEPTH - 2)
+    _x.ceil_()
+    _y.ceil_()
+    z_int = _z.ceil()
+    _x = torch.clip(_x, 1, RESOLUTION - 2)
+    _y = torch.clip(_y, 1, RESOLUTION - 2)
+    _z = torch.clip(_z, 1, DEPTH - 2)
+    coords = (z_int * RESOLUTION * RESOLUTION + _y * RESOLUTION + _x).long()
+    grid = torch.zeros([batch, DEPTH * RESOLUTION * RESOLUTION])
+    grid.scatter_reduce_(1, coords, _z, 'amax', include_self=True)
+    return grid.reshape(batch, DEPTH, RESOLUTION, RESOLUTION).permute(0, 1, 3, 2)
+
+
+def gaussian_kernel_3x3(sigma=3.0):
+    """mv_utils.py:204-220 with ksize=3, depth=1, sigma=3, zsigma=1 -> [3,3] float32."""
+    xs = np.arange(3, dtype=np.float32) - 1
+    k1 = np.exp(-(xs ** 2) / (2 * sigma ** 2))
+    k2 = torch.from_numpy(k1[..., None] @ k1[None, ...])
+    k2 = k2 / k2.sum()
+    zk = np.exp(-(np.zeros(1, dtype=np.float32) ** 2) / 2.0)
+    k3 = np.repeat(k2[None, :, :], 1, axis=0) * zk[:, None, None]
+    k3 = k3 / torch.sum(k3)
+    return torch.Tensor(k3).reshape(3, 3)
+
+
+def grid_to_image(grid):
+    """D4, mv_utils.py:30-37. grid [B,DEPTH,R,R] -> [B,3,R-2,R-2]."""
+    x = F.max_pool3d(grid.unsqueeze(1), kernel_size=(1, 5, 5), stride=1, padding=(0, 1, 1))
+    w = gaussian_kernel_3x3().reshape(1, 1, 1, 3, 3)
+    x = F.conv3d(x, w, bias=torch.zeros(1), stride=1, padding=(0, 1, 1))
+    img = torch.max(x, dim=2)[0]
+    img = img / torch.max(torch.max(img, dim=-1)[0], dim=-1)[0][:, :, None, None]
+    img = 1 - img
+    return img.repeat(1, 3, 1, 1)
+
+
+def render_views(points_origin_f32, rot=None):
+    """D2-D4 for ONE cluster: [P,3] float32 tensor -> [V,3,110,110]
+    (RealisticProjection.get_img with batch 1, mv_utils.py:173-187)."""
+    rot = view_matrices() if rot is None else rot
+    v = rot.shape[0]
+    pts = torch.repeat_interleave(points_origin_f32.unsqueeze(0), v, dim=0)
+    pts = torch.matmul(pts, rot)
+    return grid_to_image(points_to_grid(pts))
+
+
+def resize_quantise(depth_images, image_size=IMAGE_SIZE):
+    """D5, zero_shot_detector.py:405-409: [n,3,110,110] -> uint8 [n,224,224,3] (the arrays
+    handed to PIL.Image.fromarray)."""
+    x = F.interpolate(depth_images, size=(image_size, image_size), mode='bilinear', align_corners=True)
+    x = x.permute(0, 3, 2, 1).detach().cpu().numpy()
+    return np.stack([np.uint8(img * 255) for img in x]) if len(x) else np.zeros((0, image_size, image_size, 3), np.uint8)
+
+
+def clip_normalise(u8):
+    """D6, clip.py:79-86 at 224x224: ToTensor (/255, HWC->CHW) then Normalize."""
+    x = torch.from_numpy(u8).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    mean = torch.tensor(CLIP_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(CLIP_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    return x.sub(mean).div(std)
+
+
+def render_clusters(cluster_points_ego, rot=None, image_size=IMAGE_SIZE):
+    """Whole D1-D6 chain for a list of clusters (each (P,3) float32, ego frame).
+    Returns (uint8 [C*V,224,224,3], float32 [C*V,3,224,224])."""
+    rot = view_matrices() if rot is None else rot
+    imgs = []
+    for pts in cluster_points_ego:
+        o = torch.from_numpy(cluster_to_origin(pts)).float()
+        imgs.append(render_views(o, rot))
+    if not imgs:
+        return np.zeros((0, image_size, image_size, 3), np.uint8), torch.zeros(0, 3, image_size, image_size)
+    u8 = resize_quantise(torch.cat(imgs, dim=0), image_size)
+    return u8, clip_normalise(u8)

@@ -1,0 +1,99 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python (stub-imported from
+/root/reference, see oracle/refstubs.py) on seeded inputs.  Run only in the build container:
+
+    python tests/golden/make_golden.py [render] [vit] [detect] [box]
+
+The fixtures are data (inputs + the reference's outputs); no reference source is stored.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refstubs  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def render_cases():
+    """Seeded clusters: sizes x azimuths, roughly object shaped, float32 in the ego frame."""
+    rng = np.random.default_rng(20241220)
+    cases = []
+    for P in [10, 50, 500, 5000]:
+        for az, rg in [(0.3, 8.0), (2.0, 25.0), (-2.5, 55.0)]:
+            c = np.array([rg * np.cos(az), rg * np.sin(az), 0.8])
+            ext = rng.uniform([0.3, 0.3, 0.5], [2.5, 1.2, 1.0])
+            pts = (rng.normal(size=(P, 3)) * ext + c).astype(np.float32)
+            cases.append(pts)
+    return cases
+
+
+def make_render():
+    refstubs.install()
+    from src.utils import mv_utils, pointcloud_utils
+    proj = mv_utils.RealisticProjection(refstubs.projection_cfg())
+    cases = render_cases()
+    store = {}
+    hashes = []
+    for i, pts in enumerate(cases):
+        origin = pointcloud_utils.transform_cluster_points_to_origin(pts)          # pointcloud_utils.py:390
+        t = torch.from_numpy(origin).float().unsqueeze(0)                           # zero_shot_detector.py:394
+        img = proj.get_img(t).detach()                                              # mv_utils.py:173
+        assert torch.equal(img[:, 0], img[:, 1]) and torch.equal(img[:, 0], img[:, 2])
+        big = torch.nn.functional.interpolate(img, size=(224, 224), mode='bilinear', align_corners=True)
+        big = big.permute(0, 3, 2, 1).detach().cpu().numpy()                        # zero_shot_detector.py:405-408
+        u8 = np.stack([np.uint8(b * 255) for b in big])                             # :409
+        assert (u8[..., 0] == u8[..., 1]).all() and (u8[..., 0] == u8[..., 2]).all()
+        hashes.append([sha(origin), sha(img[:, 0].numpy()), sha(u8[..., 0])])
+        store[f'pts_{i}'] = pts
+        if i % 3 == 0:   # keep full images for 4 of the 12 cases, hashes for all
+            store[f'origin_{i}'] = origin
+            store[f'img_{i}'] = img[:, 0].numpy()
+            store[f'u8_{i}'] = u8[..., 0]
+    store['hashes'] = np.array(hashes)
+    store['rot_mat'] = proj.rot_mat.numpy()
+    np.savez_compressed(os.path.join(OUT, 'render_golden.npz'), **store)
+    print('render_golden.npz', len(cases), 'cases')
+
+
+def make_vit():
+    from vilgod_amd import clip_weights as cw
+    m = refstubs.load_clip_model_py()
+    cfg = dict(width=128, layers=2, heads=2, patch=16, resolution=64, output_dim=32)
+    wd = cw.synthetic_vit_weights(11, **cfg)
+    ref = m.VisionTransformer(cfg['resolution'], cfg['patch'], cfg['width'], cfg['layers'], cfg['heads'],
+                              cfg['output_dim'])
+    ref.load_state_dict(wd)
+    ref.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        y = ref(x)
+    store = dict(x=x.numpy(), y=y.numpy(), seed=np.array(11), cfg=np.array([cfg[k] for k in
+                 ('width', 'layers', 'heads', 'patch', 'resolution', 'output_dim')]))
+    # full ViT-B/16: weights are re-derived from the seed on both sides; store input seed + output
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    ref = m.VisionTransformer(224, 16, 768, 12, 12, 512)
+    ref.load_state_dict(wd)
+    ref.eval()
+    xb = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        yb = ref(xb)
+    store['xb_seed'] = np.array(6)
+    store['yb'] = yb.numpy()
+    np.savez_compressed(os.path.join(OUT, 'vit_golden.npz'), **store)
+    print('vit_golden.npz')
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['render', 'vit']
+    for w in which:
+        globals()['make_' + w]()

@@ -1,0 +1,93 @@
+"""Builds libvilgod_hip.so (HIP kernels + C ABI, gfx950 only) in-tree with hipcc.
+
+    python -m vilgod_amd.build            # incremental
+    python -m vilgod_amd.build --force
+
+The .so lands next to this file so it travels with the repository snapshot to the GPU box; it
+is git-ignored.  No torch involvement: plain `hipcc -shared`.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIB = os.path.join(HERE, 'libvilgod_hip.so')
+OBJ = os.path.join(HERE, 'csrc', '_obj')
+
+ARCH = 'gfx950'
+COMMON = ['-O3', '-fPIC', '-std=c++17', f'--offload-arch={ARCH}', f'-I{INCLUDE}', f'-I{CSRC}',
+          '-Wno-unused-result', '-DNDEBUG']
+# per-source extra flags.  Parity-critical float code is compiled without FMA contraction so that
+# only the FMAs written in the source exist (the CPU oracle is compiled the same way).
+SOURCES = {
+    'api.hip': [],
+    'render.hip': ['-ffp-contract=off'],
+    'ground.hip': ['-ffp-contract=off'],
+    'cluster.hip': ['-ffp-contract=off'],
+    'hdbscan_tree.cpp': ['-ffp-contract=off'],
+    'segment.hip': ['-ffp-contract=off'],
+    'vit.hip': [],
+}
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    headers.append(os.path.abspath(__file__))
+    jobs = []
+    objs = []
+    for src, extra in SOURCES.items():
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OBJ, src.rsplit('.', 1)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            lang = ['-x', 'hip'] if src.endswith('.cpp') else []
+            jobs.append((src, [hipcc] + COMMON + extra + lang + ['-c', path, '-o', obj]))
+
+    def run(job):
+        src, cmd = job
+        if verbose:
+            print('[vilgod_amd.build] hipcc', src, flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+        if verbose:
+            print('[vilgod_amd.build] link', os.path.basename(LIB), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)
