@@ -34,7 +34,9 @@ int vg_gather_ego(const float* d_points, int stride, const int32_t* d_index, int
 
 /* per-cluster np.median over xyz (float32) and the view-direction rotation derived from it
  * (pointcloud_utils.py:396-398).  d_seg_off: [n_clusters+1] offsets into the packed point array.
- * d_median: [n_clusters,3] f32.  d_rot: [n_clusters,5] f64 = {m00,m01,m10,m11,m22}. */
+ * d_median: [n_clusters,3] f32.  d_rot: [n_clusters,6] f64 = {m00,m01,m10,m11,m22, angle}: the matrix
+ * scipy's Rotation.from_euler('z', -angle) yields and the float32 angle = atan2(med_y, med_x) itself
+ * (correctly rounded; numpy's float32 arctan2 is a <=1 ulp SIMD routine). */
 int vg_cluster_median(const float* d_ego, const int32_t* d_seg_off, int n_clusters, float* d_median,
                       double* d_rot, void* stream);
 
@@ -52,6 +54,33 @@ int vg_to_origin(const float* d_ego, const int32_t* d_point_cluster, int n, cons
  *          3: f32 [n,110,110], one channel of get_img()'s output before the resize (parity tests). */
 int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clusters, const float* d_view_rot,
                     int n_views, const float* d_lut, void* d_out, int out_kind, void* stream);
+
+/* ---- CLIP ViT image tower + zero-shot scores (rows D7, D9) --------------------------------------
+ * Replaces ClipWrapper.predict_clip_labels' GPU part, src/utils/clip_utils.py:37-44:
+ *   model.encode_image (third_party/CLIP/clip/model.py:340-341 -> VisionTransformer.forward :223-240,
+ *   ResidualAttentionBlock :171-192, LayerNorm-in-fp32 :157-163, QuickGELU :166-168),
+ *   feature normalisation, 100 * f @ text.T, softmax.  */
+typedef struct vg_vit vg_vit;
+
+/* dtype 0: float32 everywhere (parity mode vs the fp32 CPU reference)
+ * dtype 1: fp16 GEMM operands/activations with fp32 accumulate, fp32 LayerNorm and fp32 residual stream
+ *          (what model.py:375-396 `convert_weights` gives the reference on a GPU, or better).
+ * Constraints: width % 128 == 0, width <= 1024, heads * 64 == width, tokens <= 224. */
+int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int resolution, int out_dim, int dtype);
+void vg_vit_destroy(vg_vit* v);
+/* one tensor by its reference state_dict name without the 'visual.' prefix (model.py:206-221,171-183);
+ * h_data: HOST float32.  Synchronous (hipMalloc + copy); not on the per-frame path. */
+int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t numel);
+/* bytes of device workspace for n_crops; the caller zero-fills it once. */
+int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops);
+/* d_crops: [n,3,res,res] CHW, input_kind 0 = float32, 1 = float16 (what vg_render_crops out_kind 1/2
+ * writes).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
+int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
+                  void* stream);
+/* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
+ * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */
+int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
+                   int32_t* d_top1, float* d_top1_score, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,14 +57,16 @@ def apply_transform(pts, T):
     return out
 
 
-def cluster_to_origin(points):
+def cluster_to_origin(points, angle=None):
     """D1. `points`: (P,3) in the ego frame, any float dtype (the reference passes float32).
-    Returns float64 (P,3) exactly as pointcloud_utils.py:390-412 does."""
+    Returns float64 (P,3) exactly as pointcloud_utils.py:390-412 does.
+    `angle`: optional override of the view angle (tests use it to separate the <=1 ulp freedom of
+    numpy's float32 arctan2 from the rest of the chain)."""
     rot1 = R.from_euler('z', np.pi / 2.)
     rot2 = R.from_euler('x', np.pi)
     pts = points.copy()
     c = np.median(pts[..., :3], axis=0)
-    angle = np.arctan2(c[1], c[0])
+    angle = np.arctan2(c[1], c[0]) if angle is None else angle
     rot3 = R.from_euler('z', -angle)
     pts[..., :2] -= c[:2]
     pts = rot3.apply(pts)

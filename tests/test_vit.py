@@ -1,0 +1,147 @@
+"""CLIP ViT image tower + scoring parity.
+
+CPU:  oracle/vit_oracle.py == the reference's VisionTransformer outputs frozen in tests/golden/vit_golden.npz
+      (reduced config with stored weights-by-seed, and the full ViT-B/16 regenerated from seed 0).
+GPU:  csrc/vit.hip through the C ABI.
+      fp32 mode: probabilities within 1e-3 of the oracle, identical top-1 (north_star tolerance).
+      fp16 mode: throughput mode (what the reference itself runs on a GPU); tolerance is necessarily looser:
+                 features within 2e-2 relative L2, probabilities within 5e-2, top-1 equal wherever the oracle's
+                 top-2 margin exceeds 0.1.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+from vilgod_amd import clip_weights as cw
+
+TOL_PROB_F32 = 1e-3
+
+
+@pytest.fixture(scope='module')
+def golden(golden_dir):
+    return np.load(f'{golden_dir}/vit_golden.npz')
+
+
+def small_cfg(g):
+    keys = ('width', 'layers', 'heads', 'patch', 'resolution', 'output_dim')
+    return dict(zip(keys, [int(v) for v in g['cfg']]))
+
+
+# ------------------------------------------------------------------------------------------- CPU
+def test_oracle_matches_reference_small(golden):
+    cfg = small_cfg(golden)
+    wd = cw.synthetic_vit_weights(int(golden['seed']), **cfg)
+    y = vo.vit_forward(wd, torch.from_numpy(golden['x']), cfg['heads'])
+    assert np.abs(y.numpy() - golden['y']).max() < 2e-5
+
+
+def test_oracle_matches_reference_vit_b16(golden):
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    xb = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(int(golden['xb_seed'])))
+    with torch.no_grad():
+        y = vo.vit_forward(wd, xb, 12)
+    assert np.abs(y.numpy() - golden['yb']).max() < 5e-5
+
+
+def test_weight_names_match_reference_state_dict():
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    assert sum(v.numel() for v in wd.values()) == 86192640          # SURVEY §8c [probe]
+    assert cw.infer_config(wd) == cw.VIT_B16
+    assert wd['transformer.resblocks.11.attn.in_proj_weight'].shape == (2304, 768)
+
+
+def test_vote_ties_and_majority():
+    names = np.array(['Vehicle', 'Vehicle', 'Pedestrian', 'Background'])
+    assert vo.vote(names, np.array([0.5, 0.7, 0.9, 0.2]))[0] == 'Vehicle'
+    names = np.array(['Vehicle', 'Vehicle', 'Pedestrian', 'Pedestrian'])
+    n, s = vo.vote(names, np.array([0.5, 0.7, 0.9, 0.2]))
+    assert n == 'Vehicle' and abs(s - 0.6) < 1e-12      # tie -> best mean score (0.6 vs 0.55)
+    n, s = vo.vote(names, np.array([0.5, 0.5, 0.6, 0.4]))
+    assert n == 'Pedestrian' or n == 'Vehicle'
+
+
+# ------------------------------------------------------------------------------------------- GPU
+def _oracle_probs(wd, heads, x, text):
+    with torch.no_grad():
+        f = vo.encode_in_chunks(wd, x, heads, 50)
+        return f, vo.clip_probabilities(f, text)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 6, 9])
+def test_hip_vit_small_f32(cuda, golden, n):
+    from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
+    cfg = small_cfg(golden)
+    wd = cw.synthetic_vit_weights(int(golden['seed']), **cfg)
+    x = torch.from_numpy(golden['x'])
+    x = torch.cat([x, x.flip(0)])[:n].contiguous() if n > 6 else x[:n].contiguous()
+    enc = VitEncoder(wd, dtype='f32', device=cuda)
+    f = enc.encode(x.to(cuda)).cpu()
+    want = vo.vit_forward(wd, x, cfg['heads'])
+    if n <= 6:
+        assert np.abs(f.numpy()[:n] - golden['y'][:n]).max() < 5e-5     # vs the reference's own output
+    assert (f - want).abs().max() < 5e-5
+
+
+@pytest.mark.gpu
+def test_hip_vit_small_f16(cuda, golden):
+    from vilgod_amd.clip_wrapper import VitEncoder
+    cfg = small_cfg(golden)
+    wd = cw.synthetic_vit_weights(int(golden['seed']), **cfg)
+    x = torch.from_numpy(golden['x'])
+    enc = VitEncoder(wd, dtype='f16', device=cuda)
+    f = enc.encode(x.to(cuda)).cpu()
+    f_h = enc.encode(x.half().to(cuda)).cpu()
+    want = torch.from_numpy(golden['y'])
+    rel = ((f - want).norm() / want.norm()).item()
+    print('small f16 rel L2 err', rel)
+    assert rel < 1e-2
+    assert ((f_h - want).norm() / want.norm()).item() < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'f16'])
+def test_hip_vit_b16_scores(cuda, dtype):
+    """Full ViT-B/16, seeded synthetic weights, 10 crops (one more than a multiple of anything) ->
+    probabilities over 24 prompts."""
+    from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    text = cw.synthetic_text_features(0, 24, 512)
+    x = torch.randn(10, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    f_want, p_want = _oracle_probs(wd, 12, x, text)
+    enc = VitEncoder(wd, dtype=dtype, device=cuda)
+    f = enc.encode(x.to(cuda))
+    probs, top1, score = clip_scores(f, text.to(cuda))
+    f, probs, top1, score = f.cpu(), probs.cpu(), top1.cpu().numpy(), score.cpu().numpy()
+    idx_want, s_want = vo.top1(p_want)
+    rel = ((f - f_want).norm() / f_want.norm()).item()
+    perr = (probs - p_want).abs().max().item()
+    print(f'ViT-B/16 {dtype}: feature rel L2 err {rel:.2e}, max prob err {perr:.2e}')
+    assert torch.allclose(probs.sum(-1), torch.ones(10), atol=1e-5)
+    if dtype == 'f32':
+        assert perr < TOL_PROB_F32
+        assert np.array_equal(top1, idx_want)
+        assert np.abs(score - s_want).max() < TOL_PROB_F32
+    else:
+        assert rel < 2e-2 and perr < 5e-2
+        srt = np.sort(p_want.numpy(), axis=1)
+        confident = (srt[:, -1] - srt[:, -2]) > 0.1
+        assert np.array_equal(top1[confident], idx_want[confident])
+    assert np.array_equal(top1, probs.argmax(-1).numpy())
+    assert np.allclose(score, probs.max(-1).values.numpy())
+
+
+@pytest.mark.gpu
+def test_hip_clip_scores_exact_small(cuda):
+    """D9 alone on hand-made features, incl. n = 0."""
+    from vilgod_amd.clip_wrapper import clip_scores
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(33, 512, generator=g)
+    text = cw.synthetic_text_features(3, 24, 512)
+    want = vo.clip_probabilities(feat, text)
+    probs, top1, score = clip_scores(feat.to(cuda), text.to(cuda))
+    assert (probs.cpu() - want).abs().max() < 1e-5
+    assert np.array_equal(top1.cpu().numpy(), vo.top1(want)[0])
+    p0, t0, s0 = clip_scores(torch.zeros(0, 512, device=cuda), text.to(cuda))
+    assert p0.shape == (0, 24) and t0.numel() == 0

@@ -1,0 +1,124 @@
+"""Host side of CLIP zero-shot classification (mirror of the reference's
+`src/utils/clip_utils.py::ClipWrapper`: same constructor arguments, same `predict_clip_labels`
+return values) on top of the HIP ViT of csrc/vit.hip.
+
+Differences from the reference, all on purpose:
+  * crops arrive as a CUDA tensor straight from the renderer (no PIL round trip; the uint8
+    quantisation and CLIP normalisation already happened in the render kernel);
+  * all crops of a frame are encoded in one call (`split_size` only bounds the workspace);
+  * without a checkpoint on disk (`<model_path>/<model_name>`) seeded synthetic weights and text
+    features are used (bench / tests) -- stated loudly in `self.weights_source`.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import clip_weights
+from ._lib import lib, ptr, stream_ptr, check
+
+DTYPES = {'f32': 0, 'f16': 1}
+
+
+class VitEncoder:
+    """Owns a vg_vit handle + workspace."""
+
+    def __init__(self, weights, dtype='f16', device='cuda'):
+        cfg = clip_weights.infer_config(weights)
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = torch.device(device)
+        h = ctypes.c_void_p()
+        check(lib.vg_vit_create(ctypes.byref(h), cfg['width'], cfg['layers'], cfg['heads'], cfg['patch'],
+                                cfg['resolution'], cfg['output_dim'], DTYPES[dtype]), 'vg_vit_create')
+        self._h = h
+        with torch.cuda.device(self.device):
+            for name, t in weights.items():
+                t = t.detach().to(torch.float32).contiguous().cpu()
+                check(lib.vg_vit_set_weight(self._h, name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel()),
+                      f'vg_vit_set_weight({name})')
+        self._ws = None
+        self._ws_crops = 0
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and lib is not None:
+            lib.vg_vit_destroy(h)
+            self._h = None
+
+    def _workspace(self, n):
+        if self._ws is None or n > self._ws_crops:
+            nbytes = lib.vg_vit_workspace_bytes(self._h, n)
+            self._ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_crops = n
+        return self._ws
+
+    def encode(self, crops, stream=None):
+        """crops: [n,3,res,res] float32 or float16 CUDA tensor -> [n,output_dim] float32 features."""
+        assert crops.is_cuda and crops.is_contiguous()
+        n = crops.shape[0]
+        feat = torch.empty((n, self.cfg['output_dim']), dtype=torch.float32, device=crops.device)
+        if n == 0:
+            return feat
+        kind = {torch.float32: 0, torch.float16: 1}[crops.dtype]
+        ws = self._workspace(n)
+        check(lib.vg_vit_encode(self._h, ptr(crops), kind, n, ptr(ws), ptr(feat), stream_ptr(stream)), 'vg_vit_encode')
+        return feat
+
+
+def clip_scores(feat, text_features, stream=None):
+    """-> (probs [n,K] f32, top1 [n] int32, top1_score [n] f32), clip_utils.py:42-61."""
+    n, dim = feat.shape
+    K = text_features.shape[0]
+    probs = torch.empty((n, K), dtype=torch.float32, device=feat.device)
+    top1 = torch.empty((n,), dtype=torch.int32, device=feat.device)
+    score = torch.empty((n,), dtype=torch.float32, device=feat.device)
+    if n:
+        check(lib.vg_clip_scores(ptr(feat), n, dim, ptr(text_features), K, ptr(probs), ptr(top1), ptr(score),
+                                 stream_ptr(stream)), 'vg_clip_scores')
+    return probs, top1, score
+
+
+class ClipWrapper:
+    def __init__(self, clip_cfg, model_path, device=None, dtype='f16', synthetic_seed=0):
+        assert model_path is not None, 'model_path is None'
+        if device is None:
+            device = 'cuda'
+        self.device = torch.device(device)
+        g = clip_cfg.get if hasattr(clip_cfg, 'get') else (lambda k, d=None: getattr(clip_cfg, k, d))
+        self.top_k = g('top_k', 1)
+        if self.top_k != 1:
+            raise NotImplementedError('only top_k = 1 (tools/configs/preprocessor/*.yaml) is implemented on the GPU')
+        self.split_size = g('split_size', 50)
+        self.template = g('prompt_template')
+        class_list = list(g('class_list'))
+        self.id_to_class_dict = {idx: name for idx, name in enumerate(class_list)}
+        ckpt = os.path.join(str(model_path), str(g('model_name', 'ViT-B-16.pt')))
+        if os.path.exists(ckpt):
+            weights = clip_weights.load_state_dict(ckpt)
+            tf_path = ckpt + '.text_features.npy'
+            if not os.path.exists(tf_path):
+                raise FileNotFoundError(
+                    f'{tf_path}: normalised text features [n_classes,{weights["proj"].shape[1]}] for the prompts '
+                    f'"{self.template}" x class_list are computed once off-line (text tower is not on the hot path)')
+            text = torch.from_numpy(np.load(tf_path)).float()
+            self.weights_source = ckpt
+        else:
+            weights = clip_weights.synthetic_vit_weights(synthetic_seed, **clip_weights.VIT_B16)
+            text = clip_weights.synthetic_text_features(synthetic_seed, len(class_list), weights['proj'].shape[1])
+            self.weights_source = f'synthetic(seed={synthetic_seed})'
+        self.text_features = text.to(self.device).contiguous()
+        self.encoder = VitEncoder(weights, dtype=dtype, device=self.device)
+
+    def predict_probs(self, crops, stream=None):
+        feat = self.encoder.encode(crops, stream)
+        return clip_scores(feat, self.text_features, stream)
+
+    def predict_clip_labels(self, crops):
+        """crops: [n,3,224,224] CUDA tensor.  Returns (class names, scores) lists of length n, as
+        clip_utils.py:49-63 with top_k = 1."""
+        probs, top1, score = self.predict_probs(crops)
+        top1 = top1.cpu().numpy()
+        score = score.cpu().numpy()
+        return [self.id_to_class_dict[int(i)] for i in top1], list(score)

@@ -74,7 +74,7 @@ __device__ float radix_select(const float* __restrict__ v, int n, int axis, int 
     return vg_fkey_inv(prefix);
 }
 
-// out_med[c] = median xyz (float32, np.median semantics); out_rot[c] = {m00,m01,m10,m11,m22} of
+// out_med[c] = median xyz (float32, np.median semantics); out_rot[c] = {m00,m01,m10,m11,m22,angle} of
 // scipy Rotation.from_euler('z', -atan2(med_y, med_x)).as_matrix() in float64.
 __global__ __launch_bounds__(256) void k_cluster_median(const float* __restrict__ ego,
                                                         const int* __restrict__ seg_off,
@@ -110,11 +110,12 @@ __global__ __launch_bounds__(256) void k_cluster_median(const float* __restrict_
         double a = -(double)ang;
         double s = sin(a * 0.5), w = cos(a * 0.5);
         double z2 = s * s, w2 = w * w, zw = s * w;
-        out_rot[c * 5 + 0] = -z2 + w2;        // m00 = x2 - y2 - z2 + w2
-        out_rot[c * 5 + 1] = 2.0 * (-zw);     // m01 = 2 (xy - zw)
-        out_rot[c * 5 + 2] = 2.0 * zw;        // m10 = 2 (xy + zw)
-        out_rot[c * 5 + 3] = -z2 + w2;        // m11 = -x2 + y2 - z2 + w2
-        out_rot[c * 5 + 4] = z2 + w2;         // m22 = -x2 - y2 + z2 + w2
+        out_rot[c * 6 + 0] = -z2 + w2;        // m00 = x2 - y2 - z2 + w2
+        out_rot[c * 6 + 1] = 2.0 * (-zw);     // m01 = 2 (xy - zw)
+        out_rot[c * 6 + 2] = 2.0 * zw;        // m10 = 2 (xy + zw)
+        out_rot[c * 6 + 3] = -z2 + w2;        // m11 = -x2 + y2 - z2 + w2
+        out_rot[c * 6 + 4] = z2 + w2;         // m22 = -x2 - y2 + z2 + w2
+        out_rot[c * 6 + 5] = (double)ang;     // the float32 view angle itself (diagnostics / parity tests)
     }
 }
 
@@ -130,7 +131,7 @@ __global__ void k_to_origin(const float* __restrict__ ego, const int* __restrict
     float xs = ego[(size_t)i * 3 + 0] - med[c * 3 + 0];   // float32 subtraction (pts_ is float32)
     float ys = ego[(size_t)i * 3 + 1] - med[c * 3 + 1];
     double x = xs, y = ys, z = ego[(size_t)i * 3 + 2];
-    const double* m = rot + (size_t)c * 5;
+    const double* m = rot + (size_t)c * 6;
     double q0 = m[0] * x + m[1] * y;
     double q1 = m[2] * x + m[3] * y;
     double q2 = m[4] * z;

@@ -1,0 +1,738 @@
+// CLIP ViT image tower + zero-shot scoring for gfx950.
+//
+// Replaces third_party/CLIP/clip/model.py:206-240 (VisionTransformer.forward), :171-192
+// (ResidualAttentionBlock), :157-168 (LayerNorm in fp32, QuickGELU) as called from
+// src/utils/clip_utils.py:39-44 (encode_image -> normalise -> 100*cos -> softmax).
+//
+// Two precisions, one code path:
+//   dtype 1 (f16): GEMM operands and activations fp16, fp32 accumulate, fp32 LayerNorm -- what the
+//                  reference runs on a GPU (model.py:375-396 convert_weights) -- except that the
+//                  residual stream is kept in fp32 (strictly more accurate than the reference's fp16
+//                  stream).  GEMMs: v_mfma_f32_32x32x16_f16, 128x128x64 LDS tiles, 4 waves.
+//                  Attention: one workgroup per (crop, head), K and V^T resident in LDS, S^T = K Q^T
+//                  and O^T = V^T P^T both on MFMA with the softmax row living on one lane.
+//   dtype 0 (f32): parity mode against the fp32 CPU reference (tolerance 1e-3 on probabilities):
+//                  plain fp32 VALU kernels, no MFMA, same epilogues.
+//
+// Layout (all row-major, K contiguous):
+//   tokens M = n_crops * T (T = 1 + (res/patch)^2), rows padded to a multiple of 128 (workspace is
+//   zero-initialised by the host once, padding rows stay finite).
+//   x    [Mp, W]   f32   residual stream
+//   h    [Mp, W]   f16|f32   LayerNorm output / attention output
+//   qkv  [Mp, 3W]  f16|f32
+//   mlp  [Mp, 4W]  f16|f32
+#include "common.h"
+#include <hip/hip_fp16.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_NONE_F32 = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware tile order: consecutive hardware block ids are dealt round-robin to the 8 XCDs; give each
+// XCD a contiguous run of tiles so the column tiles that share one activation row-tile hit one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, s = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp16 MFMA GEMM:  C[m][n] = sum_k X[m][k] * Wt[n][k]  (+ epilogue).  M%128==0, N%128==0, K%64==0.
+// The MFMA computes the TRANSPOSED tile (A operand = weight rows, B operand = activation rows) so a
+// lane owns one output row m and 4-wide runs of consecutive n: vector loads/stores in the epilogue.
+#define GT 128
+#define GK 64
+#define GLD (GK + 8)   // LDS row stride in halves: 144 B -> ds_read_b128 conflict free
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f16(const f16* __restrict__ X, const f16* __restrict__ Wt,
+                                                  const float* __restrict__ bias, void* __restrict__ Cout,
+                                                  float* __restrict__ resid, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) f16 Xs[GT * GLD];
+    __shared__ __attribute__((aligned(16))) f16 Ws[GT * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = N / GT;
+    const int nwg = gridDim.x;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int tm = t / ntn, tn = t - tm * ntn;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const int wm = wave >> 1, wn = wave & 1;          // 2x2 waves, 64x64 each
+
+    // staging: 128 rows x 8 chunks (16 B) per operand; thread owns chunks tid + 256*i
+    const f16* xg[4];
+    const f16* wg[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + 256 * i, row = c >> 3, part = c & 7;
+        xg[i] = X + (size_t)(m0 + row) * K + part * 8;
+        wg[i] = Wt + (size_t)(n0 + row) * K + part * 8;
+        soff[i] = row * GLD + part * 8;
+    }
+    uint4 rx[4], rw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rx[i] = *(const uint4*)(xg[i]);
+        rw[i] = *(const uint4*)(wg[i]);
+    }
+    f32x16 acc[2][2];   // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int nk = K / GK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(uint4*)(Xs + soff[i]) = rx[i];
+            *(uint4*)(Ws + soff[i]) = rw[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rx[i] = *(const uint4*)(xg[i] + (size_t)(kt + 1) * GK);
+                rw[i] = *(const uint4*)(wg[i] + (size_t)(kt + 1) * GK);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < GK / 16; ++s) {
+            f16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *(const f16x8*)(Ws + (wn * 64 + i * 32 + r31) * GLD + s * 16 + hh * 8);
+                fb[i] = *(const f16x8*)(Xs + (wm * 64 + i * 32 + r31) * GLD + s * 16 + hh * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    // epilogue: lane owns row m; register r -> n = (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + r31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hh;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e];
+                if (EPI != EPI_NONE_F32) {
+                    float4 b4 = *(const float4*)(bias + n);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+                }
+                if (EPI == EPI_BIAS_RESID) {
+                    float* p = resid + (size_t)m * N + n;
+                    float4 x4 = *(float4*)p;
+                    x4.x += v[0]; x4.y += v[1]; x4.z += v[2]; x4.w += v[3];
+                    *(float4*)p = x4;
+                } else if (EPI == EPI_NONE_F32) {
+                    *(float4*)((float*)Cout + (size_t)m * N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    f16x4 h4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    *(f16x4*)((f16*)Cout + (size_t)m * N + n) = h4;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 parity-mode GEMM (VALU): 64x64 tile, 256 threads, 4x4 micro-tile, same epilogues.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                  const float* __restrict__ bias, float* __restrict__ Cout,
+                                                  float* __restrict__ resid, int M, int N, int K) {
+    __shared__ float Xs[16][64 + 4];
+    __shared__ float Ws[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int ntn = N / 64;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // 64 rows x 16 k per operand = 1024 values, 4 per thread
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int c = tid + 256 * i, row = c >> 4, kk = c & 15;
+            Xs[kk][row] = X[(size_t)(m0 + row) * K + k0 + kk];
+            Ws[kk][row] = Wt[(size_t)(n0 + row) * K + k0 + kk];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = Xs[kk][ty * 4 + i];
+                b[i] = Ws[kk][tx * 4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            float v = acc[i][j];
+            if (EPI != EPI_NONE_F32) v += bias[n];
+            if (EPI == EPI_BIAS_GELU) v = v / (1.0f + expf(-1.702f * v));
+            if (EPI == EPI_BIAS_RESID)
+                resid[(size_t)m * N + n] += v;
+            else
+                Cout[(size_t)m * N + n] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col of CHW crops into patch rows: P[(crop*G*G + py*G + px)][c*ps*ps + i*ps + j]
+template <typename TI, typename TO>
+__global__ void k_im2col(const TI* __restrict__ crops, TO* __restrict__ P, int n, int res, int ps) {
+    const int G = res / ps, Kp = 3 * ps * ps;
+    size_t total = (size_t)n * G * G * Kp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int col = idx % Kp;
+        size_t row = idx / Kp;
+        int px = row % G, py = (row / G) % G;
+        size_t crop = row / ((size_t)G * G);
+        int j = col % ps, i = (col / ps) % ps, c = col / (ps * ps);
+        P[idx] = (TO)(float)crops[((crop * 3 + c) * res + (py * ps + i)) * res + px * ps + j];
+    }
+}
+
+// x[crop][t] = (t == 0 ? class_embedding : patch_out[crop][t-1]) + positional_embedding[t]; x = ln_pre(x)
+// one wave per token row.  (model.py:227-229)
+__global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                     const float* __restrict__ pos, const float* __restrict__ lw,
+                                                     const float* __restrict__ lb, float* __restrict__ x, int n_rows,
+                                                     int T, int W) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int crop = row / T, t = row - crop * T;
+    const float* src = (t == 0) ? cls : patch_out + ((size_t)crop * (T - 1) + (t - 1)) * W;
+    float v[16];
+    const int per = W / 64;   // W multiple of 64, <= 1024
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+        int c = lane + 64 * i;
+        v[i] = src[c] + pos[(size_t)t * W + c];
+        s += v[i];
+    }
+    float mean = vg_wave_sum(s) / (float)W;
+    float q = 0.f;
+    for (int i = 0; i < per; ++i) {
+        float d = v[i] - mean;
+        q += d * d;
+    }
+    float rstd = rsqrtf(vg_wave_sum(q) / (float)W + 1e-5f);
+    for (int i = 0; i < per; ++i) {
+        int c = lane + 64 * i;
+        x[(size_t)row * W + c] = (v[i] - mean) * rstd * lw[c] + lb[c];
+    }
+}
+
+// LayerNorm (fp32 statistics, model.py:157-163): x f32 [rows,W] -> h (f16 or f32). one wave per row.
+template <typename TO>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ lw,
+                                                   const float* __restrict__ lb, TO* __restrict__ h, int n_rows, int W,
+                                                   int row_stride_in /*in rows of W*/) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const float* src = x + (size_t)row * row_stride_in * W;
+    float v[16];
+    const int per = W / 64;
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+        v[i] = src[lane + 64 * i];
+        s += v[i];
+    }
+    float mean = vg_wave_sum(s) / (float)W;
+    float q = 0.f;
+    for (int i = 0; i < per; ++i) {
+        float d = v[i] - mean;
+        q += d * d;
+    }
+    float rstd = rsqrtf(vg_wave_sum(q) / (float)W + 1e-5f);
+    for (int i = 0; i < per; ++i) {
+        int c = lane + 64 * i;
+        h[(size_t)row * W + c] = (TO)((v[i] - mean) * rstd * lw[c] + lb[c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp16 attention, head dim 64, T <= 224.  One workgroup (7 waves) per (crop, head); wave w owns query rows
+// [32w, 32w+32).  S^T[key][q] = K Q^T (A = K rows from LDS, B = Q rows from HBM), softmax along keys is a
+// per-lane reduction (+ one cross-half shuffle), O^T[d][q] = V^T P^T with the S^T accumulators re-used
+// as the B operand (guide §3 "An accumulator tile as the next MFMA's operand").
+#define AT_MAXT 224
+#define AT_KLD 72      // K rows: 64 + 8 halves
+#define AT_VLD 232     // V^T rows: 224 + 8 halves
+__global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T,
+                                                       int W, int heads) {
+    __shared__ __attribute__((aligned(16))) f16 Ks[AT_MAXT * AT_KLD];
+    __shared__ __attribute__((aligned(16))) f16 Vt[64 * AT_VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crop = blockIdx.x / heads, head = blockIdx.x - crop * heads;
+    const size_t row0 = (size_t)crop * T;
+    const int ld = 3 * W;
+    const f16* qbase = qkv + row0 * ld + head * 64;
+    const f16* kbase = qbase + W;
+    const f16* vbase = qbase + 2 * W;
+
+    // K -> LDS rows (zero beyond T)
+    for (int c = tid; c < AT_MAXT * 8; c += 448) {
+        int key = c >> 3, part = c & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < T) v = *(const uint4*)(kbase + (size_t)key * ld + part * 8);
+        *(uint4*)(Ks + key * AT_KLD + part * 8) = v;
+    }
+    // V -> LDS transposed (zero beyond T); consecutive lanes take consecutive keys
+    for (int c = tid; c < AT_MAXT * 8; c += 448) {
+        int part = c / AT_MAXT, key = c - part * AT_MAXT;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) v = *(const f16x8*)(vbase + (size_t)key * ld + part * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
+    }
+    __syncthreads();
+    const int q0 = wave * 32;
+    if (q0 >= T) return;
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int q = q0 + r31;
+    const int nkb = (T + 31) / 32;
+
+    f16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[s] = (q < T) ? *(const f16x8*)(qbase + (size_t)q * ld + s * 16 + hh * 8) : z;
+    }
+    f32x16 sacc[7];
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+        if (kb < nkb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r31) * AT_KLD + s * 16 + hh * 8);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+    }
+    // softmax over keys (scores scaled by 1/8 = dh^-0.5, model.py via nn.MultiheadAttention)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v = (key < T) ? sacc[kb][r] : -INFINITY;
+            sacc[kb][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float c2 = 0.125f * 1.4426950408889634f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = exp2f((sacc[kb][r] - mx) * c2);
+            sacc[kb][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb) {
+        if (kb < nkb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kb][8 * s + j];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    // A[d][k]: element j <-> key kb*32 + 16s + 8(j>>2) + 4hh + (j&3)
+                    const f16* vp = Vt + (dt * 32 + r31) * AT_VLD + kb * 32 + 16 * s + 4 * hh;
+                    f16x4 lo = *(const f16x4*)vp, hi = *(const f16x4*)(vp + 8);
+                    f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (q < T) {
+        f16* o = out + (row0 + q) * (size_t)W + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
+                *(f16x4*)(o + dt * 32 + 8 * g + 4 * hh) = h4;
+            }
+    }
+}
+
+// fp32 parity-mode attention: one workgroup per (crop, head); K,V in LDS; one wave per query row at a time.
+__global__ __launch_bounds__(256) void k_attention_f32(const float* __restrict__ qkv, float* __restrict__ out, int T,
+                                                       int W, int heads) {
+    extern __shared__ float sm[];
+    float* Ks = sm;                 // [T][65]
+    float* Vs = sm + (size_t)T * 65;  // [T][64]
+    float* Ps = Vs + (size_t)T * 64;  // [4 waves][T]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crop = blockIdx.x / heads, head = blockIdx.x - crop * heads;
+    const size_t row0 = (size_t)crop * T;
+    const int ld = 3 * W;
+    const float* qbase = qkv + row0 * ld + head * 64;
+    for (int c = tid; c < T * 64; c += 256) {
+        int key = c >> 6, d = c & 63;
+        Ks[key * 65 + d] = qbase[(size_t)key * ld + W + d];
+        Vs[key * 64 + d] = qbase[(size_t)key * ld + 2 * W + d];
+    }
+    __syncthreads();
+    float* P = Ps + wave * T;
+    for (int q = wave; q < T; q += 4) {
+        float qd = qbase[(size_t)q * ld + lane] * 0.125f;   // q scaled before QK^T like nn.MultiheadAttention
+        float mx = -INFINITY;
+        for (int k0 = 0; k0 < T; k0 += 64) {
+            int key = k0 + lane;
+            float s = 0.f;
+            for (int d = 0; d < 64; ++d) {
+                float qv = __shfl(qd, d);
+                if (key < T) s = fmaf(qv, Ks[key * 65 + d], s);
+            }
+            if (key < T) {
+                P[key] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = vg_wave_max(mx);
+        float sum = 0.f;
+        for (int key = lane; key < T; key += 64) {
+            float p = expf(P[key] - mx);
+            P[key] = p;
+            sum += p;
+        }
+        sum = vg_wave_sum(sum);
+        __builtin_amdgcn_s_waitcnt(0);
+        float o = 0.f;
+        for (int key = 0; key < T; ++key) o = fmaf(P[key], Vs[key * 64 + lane], o);
+        out[(row0 + q) * (size_t)W + head * 64 + lane] = o / sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: ln_post(x[crop, 0, :]) @ proj  (model.py:235-238).  one workgroup per crop.
+__global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, const float* __restrict__ lw,
+                                              const float* __restrict__ lb, const float* __restrict__ proj,
+                                              float* __restrict__ feat, int T, int W, int D) {
+    extern __shared__ float sm[];   // [W]
+    __shared__ float red[8];
+    const int crop = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = x + (size_t)crop * T * W;
+    float s = 0.f;
+    for (int c = tid; c < W; c += 256) s += src[c];
+    s = vg_wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    float mean = (red[0] + red[1] + red[2] + red[3]) / (float)W;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < W; c += 256) {
+        float d = src[c] - mean;
+        q += d * d;
+    }
+    q = vg_wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)W + 1e-5f);
+    for (int c = tid; c < W; c += 256) sm[c] = (src[c] - mean) * rstd * lw[c] + lb[c];
+    __syncthreads();
+    for (int j = tid; j < D; j += 256) {
+        float a = 0.f;
+        for (int i = 0; i < W; ++i) a = fmaf(sm[i], proj[(size_t)i * D + j], a);
+        feat[(size_t)crop * D + j] = a;
+    }
+}
+
+// clip_utils.py:42-61: f /= |f|; probs = softmax(100 f T^T); top-1.  one wave per crop, K <= 64 classes.
+__global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ feat, const float* __restrict__ text,
+                                                    float* __restrict__ probs, int* __restrict__ top1,
+                                                    float* __restrict__ top1_score, int n, int D, int Kc) {
+    const int crop = blockIdx.x, lane = threadIdx.x;
+    const float* f = feat + (size_t)crop * D;
+    float ss = 0.f;
+    for (int i = lane; i < D; i += 64) ss += f[i] * f[i];
+    float nrm = sqrtf(vg_wave_sum(ss));
+    float logit = -INFINITY;
+    if (lane < Kc) {
+        float a = 0.f;
+        for (int i = 0; i < D; ++i) a = fmaf(100.0f * (f[i] / nrm), text[(size_t)lane * D + i], a);
+        logit = a;
+    }
+    float mx = vg_wave_max(logit);
+    float e = (lane < Kc) ? expf(logit - mx) : 0.f;
+    float p = e / vg_wave_sum(e);
+    if (lane < Kc) probs[(size_t)crop * Kc + lane] = p;
+    // argmax, lowest index on ties
+    float best = (lane < Kc) ? p : -1.f;
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o);
+        int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        top1[crop] = bi;
+        top1_score[crop] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct vg_vit {
+    int width, layers, heads, patch, res, out_dim, dtype, T;
+    std::map<std::string, void*> w;        // device pointers (f32 or f16 depending on role)
+    std::map<std::string, size_t> numel;
+};
+
+static bool is_gemm_weight(const std::string& n) {
+    return n == "conv1.weight" || n.find("in_proj_weight") != std::string::npos ||
+           n.find("out_proj.weight") != std::string::npos || n.find("c_fc.weight") != std::string::npos ||
+           n.find("c_proj.weight") != std::string::npos;
+}
+
+template <int EPI>
+static int launch_gemm(const vg_vit* v, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
+                       int N, int K, hipStream_t st) {
+    if (v->dtype == 1) {
+        if (M % GT || N % GT || K % GK) return VG_ERR_ARG;
+        int nwg = (M / GT) * (N / GT);
+        hipLaunchKernelGGL((k_gemm_f16<EPI>), dim3(nwg), dim3(256), 0, st, (const f16*)X, (const f16*)Wt, bias, C, resid,
+                           M, N, K);
+    } else {
+        if (M % 64 || N % 64 || K % 16) return VG_ERR_ARG;
+        int nwg = (M / 64) * (N / 64);
+        hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nwg), dim3(256), 0, st, (const float*)X, (const float*)Wt, bias,
+                           (float*)C, resid, M, N, K);
+    }
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+extern "C" {
+
+int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int resolution, int out_dim, int dtype) {
+    if (!out || width % 128 || width > 1024 || heads * 64 != width || resolution % patch || dtype < 0 || dtype > 1)
+        return VG_ERR_ARG;
+    int T = (resolution / patch) * (resolution / patch) + 1;
+    if (T > AT_MAXT || (3 * patch * patch) % 64) return VG_ERR_ARG;
+    vg_vit* v = new vg_vit();
+    v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
+    v->out_dim = out_dim; v->dtype = dtype; v->T = T;
+    *out = v;
+    return VG_OK;
+}
+
+void vg_vit_destroy(vg_vit* v) {
+    if (!v) return;
+    for (auto& kv : v->w) (void)hipFree(kv.second);
+    delete v;
+}
+
+/* upload one tensor by its reference state_dict name (prefix 'visual.' dropped); h_data is host float32.
+ * GEMM weights are stored in the compute dtype, everything else stays float32. */
+int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t numel) {
+    if (!v || !name || !h_data || numel <= 0) return VG_ERR_ARG;
+    std::string n(name);
+    auto it = v->w.find(n);
+    if (it != v->w.end()) {
+        (void)hipFree(it->second);
+        v->w.erase(it);
+    }
+    void* d = nullptr;
+    if (v->dtype == 1 && is_gemm_weight(n)) {
+        std::vector<f16> tmp((size_t)numel);
+        for (int64_t i = 0; i < numel; ++i) tmp[i] = (f16)h_data[i];
+        VG_CHECK(hipMalloc(&d, (size_t)numel * 2));
+        VG_CHECK(hipMemcpy(d, tmp.data(), (size_t)numel * 2, hipMemcpyHostToDevice));
+    } else {
+        VG_CHECK(hipMalloc(&d, (size_t)numel * 4));
+        VG_CHECK(hipMemcpy(d, h_data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    }
+    v->w[n] = d;
+    v->numel[n] = (size_t)numel;
+    return VG_OK;
+}
+
+static int64_t pad128(int64_t m) { return (m + 127) / 128 * 128; }
+
+/* bytes of zero-initialised device workspace vg_vit_encode needs for n_crops */
+int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops) {
+    if (!v || n_crops <= 0) return 0;
+    int64_t Mp = pad128((int64_t)n_crops * v->T), W = v->width, es = v->dtype == 1 ? 2 : 4;
+    int64_t Pp = pad128((int64_t)n_crops * (v->T - 1)), Kp = 3 * v->patch * v->patch;
+    int64_t b = Mp * W * 4            // x (f32)
+                + Mp * W * es         // h
+                + Mp * 3 * W * es     // qkv
+                + Mp * 4 * W * es     // mlp
+                + Pp * Kp * es        // patches
+                + Pp * W * 4;         // patch-embed output (f32)
+    return b + 1024;
+}
+
+/* input_kind 0: f32 CHW crops [n,3,res,res]; 1: f16 CHW crops; d_feat: [n,out_dim] f32 */
+int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
+                  void* stream) {
+    if (!v || !d_crops || !d_workspace || !d_feat || n_crops <= 0 || input_kind < 0 || input_kind > 1) return VG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int W = v->width, T = v->T, L = v->layers, H = v->heads;
+    const int64_t M = (int64_t)n_crops * T, Mp = pad128(M), es = v->dtype == 1 ? 2 : 4;
+    const int64_t P = (int64_t)n_crops * (T - 1), Pp = pad128(P), Kp = 3 * v->patch * v->patch;
+    char* ws = (char*)d_workspace;
+    float* x = (float*)ws;            ws += Mp * W * 4;
+    void* h = ws;                     ws += Mp * W * es;
+    void* qkv = ws;                   ws += Mp * 3 * W * es;
+    void* mlp = ws;                   ws += Mp * 4 * W * es;
+    void* patches = ws;               ws += Pp * Kp * es;
+    float* pe = (float*)ws;
+
+    auto need = [&](const std::string& n) -> void* {
+        auto it = v->w.find(n);
+        return it == v->w.end() ? nullptr : it->second;
+    };
+    const char* top[] = {"conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "ln_pre.bias",
+                         "ln_post.weight", "ln_post.bias", "proj"};
+    for (const char* n : top)
+        if (!need(n)) {
+            fprintf(stderr, "[vilgod_hip] vg_vit_encode: weight %s not set\n", n);
+            return VG_ERR_ARG;
+        }
+    // im2col
+    {
+        int blocks = (int)((P * Kp + 255) / 256);
+        if (blocks > 65535 * 8) blocks = 65535 * 8;
+        if (v->dtype == 1) {
+            if (input_kind == 0)
+                hipLaunchKernelGGL((k_im2col<float, f16>), dim3(blocks), dim3(256), 0, st, (const float*)d_crops, (f16*)patches, n_crops, v->res, v->patch);
+            else
+                hipLaunchKernelGGL((k_im2col<f16, f16>), dim3(blocks), dim3(256), 0, st, (const f16*)d_crops, (f16*)patches, n_crops, v->res, v->patch);
+        } else {
+            if (input_kind == 0)
+                hipLaunchKernelGGL((k_im2col<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)d_crops, (float*)patches, n_crops, v->res, v->patch);
+            else
+                hipLaunchKernelGGL((k_im2col<f16, float>), dim3(blocks), dim3(256), 0, st, (const f16*)d_crops, (float*)patches, n_crops, v->res, v->patch);
+        }
+        VG_LAUNCH_CHECK();
+    }
+    int rc = launch_gemm<EPI_NONE_F32>(v, patches, need("conv1.weight"), nullptr, pe, nullptr, (int)Pp, W, (int)Kp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_embed_lnpre, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
+                       (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
+                       (const float*)need("ln_pre.bias"), x, (int)M, T, W);
+    VG_LAUNCH_CHECK();
+    for (int l = 0; l < L; ++l) {
+        std::string p = "transformer.resblocks." + std::to_string(l) + ".";
+        const char* names[] = {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                               "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                               "mlp.c_proj.weight", "mlp.c_proj.bias"};
+        void* wp[12];
+        for (int i = 0; i < 12; ++i) {
+            wp[i] = need(p + names[i]);
+            if (!wp[i]) {
+                fprintf(stderr, "[vilgod_hip] vg_vit_encode: weight %s%s not set\n", p.c_str(), names[i]);
+                return VG_ERR_ARG;
+            }
+        }
+        if (v->dtype == 1)
+            hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[0], (const float*)wp[1], (f16*)h, (int)M, W, 1);
+        else
+            hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[0], (const float*)wp[1], (float*)h, (int)M, W, 1);
+        VG_LAUNCH_CHECK();
+        rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st);
+        if (rc) return rc;
+        if (v->dtype == 1) {
+            hipLaunchKernelGGL(k_attention_f16, dim3(n_crops * H), dim3(448), 0, st, (const f16*)qkv, (f16*)h, T, W, H);
+        } else {
+            size_t lds = ((size_t)T * 65 + (size_t)T * 64 + 4 * (size_t)T) * sizeof(float);
+            static bool attr = false;
+            if (!attr) {
+                VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL(k_attention_f32, dim3(n_crops * H), dim3(256), lds, st, (const float*)qkv, (float*)h, T, W, H);
+        }
+        VG_LAUNCH_CHECK();
+        rc = launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
+        if (rc) return rc;
+        if (v->dtype == 1)
+            hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
+        else
+            hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (float*)h, (int)M, W, 1);
+        VG_LAUNCH_CHECK();
+        rc = launch_gemm<EPI_BIAS_GELU>(v, h, wp[8], (const float*)wp[9], mlp, nullptr, (int)Mp, 4 * W, W, st);
+        if (rc) return rc;
+        rc = launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_head, dim3(n_crops), dim3(256), W * sizeof(float), st, x, (const float*)need("ln_post.weight"),
+                       (const float*)need("ln_post.bias"), (const float*)need("proj"), d_feat, T, W, v->out_dim);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
+                   int32_t* d_top1, float* d_top1_score, void* stream) {
+    if (n <= 0) return VG_OK;
+    if (!d_feat || !d_text || !d_probs || !d_top1 || !d_top1_score || n_classes <= 0 || n_classes > 64) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_clip_scores, dim3(n), dim3(64), 0, (hipStream_t)stream, d_feat, d_text, d_probs, d_top1,
+                       d_top1_score, n, dim, n_classes);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+}  // extern "C"

@@ -101,7 +101,7 @@ class RealisticProjection:
         ego = torch.empty((ptot, 3), dtype=torch.float32, device=dev)
         check(lib.vg_gather_ego(ptr(points), points.stride(0), ptr(index), ptot, ptr(T), ptr(ego), sp), 'vg_gather_ego')
         med = torch.empty((n_clusters, 3), dtype=torch.float32, device=dev)
-        rot = torch.empty((n_clusters, 5), dtype=torch.float64, device=dev)
+        rot = torch.empty((n_clusters, 6), dtype=torch.float64, device=dev)
         check(lib.vg_cluster_median(ptr(ego), ptr(seg_off), n_clusters, ptr(med), ptr(rot), sp), 'vg_cluster_median')
         # per-point cluster id from the offsets
         ar = torch.arange(ptot, device=dev, dtype=torch.int32)
@@ -111,7 +111,7 @@ class RealisticProjection:
               'vg_to_origin')
         check(lib.vg_render_crops(ptr(origin), ptr(seg_off), n_clusters, ptr(self._d_rot), V, ptr(self._d_lut),
                                   ptr(result), kind, sp), 'vg_render_crops')
-        self._last = dict(ego=ego, median=med, origin=origin)
+        self._last = dict(ego=ego, median=med, origin=origin, rot=rot)
         return result
 
     def render_origin(self, origin, seg_off, out='f16', stream=None):
