@@ -54,6 +54,7 @@ def make_render():
         assert (u8[..., 0] == u8[..., 1]).all() and (u8[..., 0] == u8[..., 2]).all()
         hashes.append([sha(origin), sha(img[:, 0].numpy()), sha(u8[..., 0])])
         store[f'pts_{i}'] = pts
+        store[f'originf32_{i}'] = origin.astype(np.float32)
         if i % 3 == 0:   # keep full images for 4 of the 12 cases, hashes for all
             store[f'origin_{i}'] = origin
             store[f'img_{i}'] = img[:, 0].numpy()
