@@ -77,6 +77,14 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops);
  * writes).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
 int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                   void* stream);
+/* One projection GEMM of the tower, C = X @ Wt^T with the fused epilogue the block uses
+ * (model.py:175-191: in_proj, out_proj + residual, c_fc + QuickGELU, c_proj + residual), exposed so the
+ * GEMM can be unit-tested and timed alone.  dtype 1: f16 operands (M%128, N%128, K%64 == 0); 0: f32
+ * (M%64, N%64, K%16).  epi 0: +bias -> C   1: +bias, QuickGELU -> C   2: d_resid(f32) += X@Wt^T + bias
+ * 3: C float32, no bias (patch embedding, model.py:224). */
+int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
+            int M, int N, int K, void* stream);
+
 /* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
  * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,

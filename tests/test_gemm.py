@@ -1,0 +1,50 @@
+"""The projection GEMM of the ViT (csrc/vit.hip k_gemm_f16 / k_gemm_f32) alone, all fused epilogues,
+against a plain torch fp32 reference of the same op (floating-point kernel -> torch fp32 reference).
+Tolerance: fp16 operands, fp32 accumulate -> |err| <= 2e-3 * sqrt(K) * |x||w| scale; fp32 mode 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+
+def _ref(X, W, bias, resid, epi):
+    acc = X.float() @ W.float().t()
+    if epi != 3:
+        acc = acc + bias
+    if epi == 1:
+        acc = acc * torch.sigmoid(1.702 * acc)
+    if epi == 2:
+        return resid + acc
+    return acc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [1, 0])
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+@pytest.mark.parametrize('shape', [(256, 128, 64), (384, 768, 768), (128, 2304, 768), (256, 768, 3072)])
+def test_gemm_epilogues(cuda, dtype, epi, shape):
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    # asymmetric, non-identity operands (a transposed tile write must not pass)
+    X = torch.randn(M, K, generator=g) * 0.5
+    W = torch.randn(N, K, generator=g) * 0.05
+    W[:, 0] += torch.arange(N) * 1e-3
+    bias = torch.randn(N, generator=g) * 0.1
+    resid = torch.randn(M, N, generator=g)
+    td = torch.float16 if dtype == 1 else torch.float32
+    Xd, Wd = X.to(td).to(cuda), W.to(td).to(cuda)
+    C = torch.zeros(M, N, dtype=torch.float32 if epi == 3 else td, device=cuda)
+    R = resid.clone().to(cuda)
+    check(lib.vg_gemm(dtype, epi, ptr(Xd), ptr(Wd), ptr(bias.to(cuda)), ptr(C), ptr(R), M, N, K, stream_ptr()))
+    got = (R if epi == 2 else C).float().cpu()
+    want = _ref(Xd.cpu(), Wd.cpu(), bias, resid, epi)
+    tol = 3e-3 if dtype == 1 else 2e-4
+    err = (got - want).abs().max().item()
+    assert err < tol * max(1.0, want.abs().max().item()), err
+
+
+@pytest.mark.gpu
+def test_gemm_rejects_bad_shapes(cuda):
+    from vilgod_amd._lib import lib, ptr, stream_ptr
+    x = torch.zeros(100, 64, dtype=torch.float16, device=cuda)
+    assert lib.vg_gemm(1, 0, ptr(x), ptr(x), ptr(x), ptr(x), None, 100, 128, 64, stream_ptr()) == 1

@@ -66,63 +66,55 @@ __global__ __launch_bounds__(256) void k_gemm_f16(const f16* __restrict__ X, con
     const int m0 = tm * GT, n0 = tn * GT;
     const int wm = wave >> 1, wn = wave & 1;          // 2x2 waves, 64x64 each
 
-    // staging: 128 rows x 8 chunks (16 B) per operand; thread owns chunks tid + 256*i
-    const f16* xg[4];
-    const f16* wg[4];
-    int soff[4];
+    // staging: 128 rows x 8 chunks (16 B) per operand; thread owns chunks (row = (tid>>3) + 32*i, part = tid&7).
+    // Everything is a named scalar / fully unrolled so the staging registers never go to scratch.
+    const int srow = tid >> 3, spart = tid & 7;
+    const f16* xg = X + (size_t)(m0 + srow) * K + spart * 8;
+    const f16* wg = Wt + (size_t)(n0 + srow) * K + spart * 8;
+    const size_t gstep = (size_t)32 * K;          // 32 rows further down
+    const int soff = srow * GLD + spart * 8;
+    const int sstep = 32 * GLD;
+    uint4 rx0, rx1, rx2, rx3, rw0, rw1, rw2, rw3;
+#define VG_STAGE_LOAD(koff)                                                             \
+    rx0 = *(const uint4*)(xg + (koff));             rw0 = *(const uint4*)(wg + (koff));             \
+    rx1 = *(const uint4*)(xg + gstep + (koff));     rw1 = *(const uint4*)(wg + gstep + (koff));     \
+    rx2 = *(const uint4*)(xg + 2 * gstep + (koff)); rw2 = *(const uint4*)(wg + 2 * gstep + (koff)); \
+    rx3 = *(const uint4*)(xg + 3 * gstep + (koff)); rw3 = *(const uint4*)(wg + 3 * gstep + (koff));
+    VG_STAGE_LOAD(0)
+    f32x16 acc00, acc01, acc10, acc11;   // acc[ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = tid + 256 * i, row = c >> 3, part = c & 7;
-        xg[i] = X + (size_t)(m0 + row) * K + part * 8;
-        wg[i] = Wt + (size_t)(n0 + row) * K + part * 8;
-        soff[i] = row * GLD + part * 8;
-    }
-    uint4 rx[4], rw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        rx[i] = *(const uint4*)(xg[i]);
-        rw[i] = *(const uint4*)(wg[i]);
-    }
-    f32x16 acc[2][2];   // [ni][mi]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
     const int r31 = lane & 31, hh = lane >> 5;
     const int nk = K / GK;
+    const f16* wfrag = Ws + (wn * 64 + r31) * GLD + hh * 8;
+    const f16* xfrag = Xs + (wm * 64 + r31) * GLD + hh * 8;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(uint4*)(Xs + soff[i]) = rx[i];
-            *(uint4*)(Ws + soff[i]) = rw[i];
-        }
+        *(uint4*)(Xs + soff) = rx0;             *(uint4*)(Ws + soff) = rw0;
+        *(uint4*)(Xs + soff + sstep) = rx1;     *(uint4*)(Ws + soff + sstep) = rw1;
+        *(uint4*)(Xs + soff + 2 * sstep) = rx2; *(uint4*)(Ws + soff + 2 * sstep) = rw2;
+        *(uint4*)(Xs + soff + 3 * sstep) = rx3; *(uint4*)(Ws + soff + 3 * sstep) = rw3;
         __syncthreads();
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rx[i] = *(const uint4*)(xg[i] + (size_t)(kt + 1) * GK);
-                rw[i] = *(const uint4*)(wg[i] + (size_t)(kt + 1) * GK);
-            }
+        {   // prefetch the next K tile (the last iteration re-reads its own tile: branch-free)
+            const int kn = (kt + 1 < nk) ? kt + 1 : kt;
+            const size_t koff = (size_t)kn * GK;
+            VG_STAGE_LOAD(koff)
         }
 #pragma unroll
         for (int s = 0; s < GK / 16; ++s) {
-            f16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *(const f16x8*)(Ws + (wn * 64 + i * 32 + r31) * GLD + s * 16 + hh * 8);
-                fb[i] = *(const f16x8*)(Xs + (wm * 64 + i * 32 + r31) * GLD + s * 16 + hh * 8);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+            f16x8 fa0 = *(const f16x8*)(wfrag + s * 16);
+            f16x8 fa1 = *(const f16x8*)(wfrag + 32 * GLD + s * 16);
+            f16x8 fb0 = *(const f16x8*)(xfrag + s * 16);
+            f16x8 fb1 = *(const f16x8*)(xfrag + 32 * GLD + s * 16);
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb1, acc11, 0, 0, 0);
         }
     }
+#undef VG_STAGE_LOAD
+    f32x16 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
     // epilogue: lane owns row m; register r -> n = (r&3) + 8*(r>>2) + 4*hh
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -723,6 +715,23 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                        (const float*)need("ln_post.bias"), (const float*)need("proj"), d_feat, T, W, v->out_dim);
     VG_LAUNCH_CHECK();
     return VG_OK;
+}
+
+/* C = X @ Wt^T (+ epilogue), exposed for unit tests / micro-benchmarks of the GEMM itself.
+ * dtype 1: X,Wt f16, M%128==0, N%128==0, K%64==0; dtype 0: f32, M%64, N%64, K%16.
+ * epi 0: +bias -> C (compute dtype)   1: +bias, QuickGELU -> C   2: resid(f32) += acc + bias   3: C f32, no bias */
+int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
+            int M, int N, int K, void* stream) {
+    vg_vit v;
+    v.dtype = dtype;
+    hipStream_t st = (hipStream_t)stream;
+    switch (epi) {
+        case 0: return launch_gemm<EPI_BIAS>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
+        case 1: return launch_gemm<EPI_BIAS_GELU>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
+        case 2: return launch_gemm<EPI_BIAS_RESID>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
+        case 3: return launch_gemm<EPI_NONE_F32>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
+    }
+    return VG_ERR_ARG;
 }
 
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
