@@ -90,6 +90,49 @@ int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* 
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
                    int32_t* d_top1, float* d_top1_score, void* stream);
 
+/* ---- ground segmentation (rows A1-A5) -----------------------------------------------------------
+ * Replaces the pybind11 module `pypatchworkpp` (third_party/patchwork-plusplus/python_wrapper/pybinding.cpp:9-55)
+ * as used by ZeroShotDetector.mask_ground_points (src/vilgod/zero_shot_detector.py:129-151) through
+ * pointcloud_utils.mask_ground_points_patchwork_pp (src/utils/pointcloud_utils.py:49-56).
+ * One handle per sequence and stream: like the reference object it carries the adaptive state
+ * (elevation / flatness stores and thresholds, sensor height) from frame to frame
+ * (patchworkpp.cpp:315-316, 339-376) and is not thread-safe. */
+typedef struct vg_ground vg_ground;
+
+/* field-for-field patchwork::Params (patchworkpp/include/patchworkpp.h:38-108; `verbose`,
+ * `intensity_thr` dropped: unused by the algorithm) */
+typedef struct vg_ground_params {
+    int enable_RNR, enable_RVPF, enable_TGR;
+    int num_iter, num_lpr, num_min_pts, num_zones, num_rings_of_interest;
+    double RNR_ver_angle_thr, RNR_intensity_thr;
+    double sensor_height, th_seeds, th_dist, th_seeds_v, th_dist_v, max_range, min_range;
+    double uprightness_thr, adaptive_seed_selection_margin;
+    int num_sectors_each_zone[4];
+    int num_rings_each_zone[4];
+    int max_flatness_storage, max_elevation_storage;
+    double elevation_thr[4], flatness_thr[4];
+} vg_ground_params;
+
+void vg_ground_default_params(vg_ground_params* p);          /* patchworkpp.h:75-107 */
+int vg_ground_create(vg_ground** out, const vg_ground_params* p, int max_points);   /* patchworkpp.h:116-146 */
+void vg_ground_destroy(vg_ground* h);
+/* fresh adaptive state (the reference builds a new object per sequence, zero_shot_detector.py:137-140);
+ * p may be NULL to keep the parameters. */
+int vg_ground_reset(vg_ground* h, const vg_ground_params* p);
+/* estimateGround + getGround (patchworkpp.cpp:152-337; pybinding.cpp:49,53).  d_points: [n,stride] f32,
+ * columns x, y, z, intensity; z_offset is subtracted in float64 and rounded to float32 exactly as
+ * pointcloud_utils.py:50-51 + the Eigen::MatrixXf conversion do.  d_ground_mask: [n] uint8, 1 = ground
+ * (the index set the reference returns; lidar_frame.py:82-87 turns it into this mask anyway). */
+int vg_ground_estimate(vg_ground* h, const float* d_points, int n, int stride, double z_offset,
+                       uint8_t* d_ground_mask, void* stream);
+/* synchronous diagnostics: {sensor_height (getHeight, pybinding.cpp:47), elevation_thr[4], flatness_thr[4],
+ * stored elevation counts[4], stored flatness counts[4]} */
+int vg_ground_get_state(vg_ground* h, double* h_out17, void* stream);
+int vg_ground_num_patches(const vg_ground* h);
+/* synchronous: [n_patches,12] = n, n_ground, normal[3] (getNormals), mean[3] (getCenters), singular values[3],
+ * decision (0 non-ground, 1 ground) */
+int vg_ground_get_patch_info(vg_ground* h, float* h_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
