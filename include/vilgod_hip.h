@@ -133,6 +133,21 @@ int vg_ground_num_patches(const vg_ground* h);
  * decision (0 non-ground, 1 ground) */
 int vg_ground_get_patch_info(vg_ground* h, float* h_out, void* stream);
 
+/* ---- spatial clustering (row B2) -------------------------------------------------------------------
+ * Replaces `cluster_model.fit(X)` (src/vilgod/zero_shot_detector.py:248; model built by
+ * src/utils/cluster_utils.py:11-12 from tools/configs/preprocessor/waymo.yaml:10-15:
+ * hdbscan.HDBSCAN(min_cluster_size=15, cluster_selection_epsilon=0.15, metric='euclidean')) and reads
+ * back `labels_` / `probabilities_` (consumed at src/vilgod/lidar_frame.py:163-167).
+ * The library itself is an un-vendored, unpinned dependency of the reference (README.md:74-75). */
+
+/* Hierarchy stage on the HOST from the MST of the mutual-reachability graph, edges sorted ascending by
+ * (w2, lo, hi): single linkage -> condense(min_cluster_size) -> stability -> EOM ->
+ * cluster_selection_epsilon -> labels (-1 = noise) and probabilities.  h_w2: SQUARED weights.
+ * Host pointers only; no GPU involved (runs in the CPU test-suite too). */
+int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, const double* h_w2, int n,
+                         int min_cluster_size, double eps, int32_t* h_labels, double* h_probs,
+                         int32_t* h_n_clusters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,216 @@
+// HDBSCAN hierarchy stage (kernel list K2d): from the sorted minimum spanning tree of
+// the mutual-reachability graph to flat labels and membership probabilities.
+//
+// This is the sequential O(n alpha(n)) tail of the clustering path; it runs on the host (one thread per
+// rank, overlapped with GPU work of the neighbouring frames) exactly as SURVEY §7 step 4 plans
+// ("union-find dendrogram/condense/EOM+eps, C++ host").  The GPU produces and sorts the MST (cluster.hip).
+//
+// Semantics = the library the reference calls (hdbscan.HDBSCAN(min_cluster_size=15,
+// cluster_selection_epsilon=0.15), tools/configs/preprocessor/waymo.yaml:10-15; src/vilgod/
+// zero_shot_detector.py:248) as documented by its scikit-learn port:
+//   single linkage  sklearn/cluster/_hdbscan/_linkage.pyx:226-274
+//   condense        _tree.pyx:122-238      stability :240-278      EOM :729-741
+//   epsilon         :578-641, :743-761     labels    :433-512      probabilities :515-554
+// allow_single_cluster = False, cluster_selection_method = 'eom' (library defaults).
+#include <math.h>
+#include <stdint.h>
+#include <algorithm>
+#include <limits>
+#include <vector>
+
+#include "vilgod_hip.h"
+
+namespace {
+
+struct Tree {
+    int n;
+    std::vector<int> left, right, size;     // internal node i (id n+i)
+    std::vector<double> dist;
+};
+
+inline int uf_find(std::vector<int>& p, int x) {
+    int r = x;
+    while (p[r] != r) r = p[r];
+    while (p[x] != r) {
+        int nx = p[x];
+        p[x] = r;
+        x = nx;
+    }
+    return r;
+}
+
+}  // namespace
+
+extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, const double* h_w2, int n,
+                                    int min_cluster_size, double eps, int32_t* h_labels, double* h_probs,
+                                    int32_t* h_n_clusters) {
+    if (n < 0 || (n > 1 && (!h_lo || !h_hi || !h_w2)) || !h_labels || !h_probs || min_cluster_size < 2) return 1;
+    if (h_n_clusters) *h_n_clusters = 0;
+    for (int i = 0; i < n; ++i) {
+        h_labels[i] = -1;
+        h_probs[i] = 0.0;
+    }
+    if (n <= min_cluster_size) return 0;
+    const int m = n - 1;
+    // ---- single linkage ------------------------------------------------------------------------
+    Tree t;
+    t.n = n;
+    t.left.resize(m); t.right.resize(m); t.size.resize(m); t.dist.resize(m);
+    {
+        std::vector<int> parent(2 * n - 1), sz(2 * n - 1, 1);
+        for (int i = 0; i < 2 * n - 1; ++i) parent[i] = i;
+        for (int i = 0; i < m; ++i) {
+            int a = uf_find(parent, h_lo[i]), b = uf_find(parent, h_hi[i]);
+            if (a == b) return 1;   // not a tree
+            t.left[i] = a;
+            t.right[i] = b;
+            t.dist[i] = sqrt(h_w2[i]);
+            parent[a] = parent[b] = n + i;
+            sz[n + i] = sz[a] + sz[b];
+            t.size[i] = sz[n + i];
+        }
+    }
+    // ---- condense (BFS, ids in visiting order like the library) ----------------------------------
+    // rows: parent cluster (0-based, 0 = root), child (point id, or cluster index if csize > 1), lambda, csize
+    std::vector<int> r_parent, r_child, r_size;
+    std::vector<double> r_lambda;
+    r_parent.reserve(n + 64); r_child.reserve(n + 64); r_size.reserve(n + 64); r_lambda.reserve(n + 64);
+    std::vector<int> relabel(2 * n - 1, -1);
+    std::vector<char> ignore(2 * n - 1, 0);
+    int next_label = 1;
+    const int root = 2 * n - 2;
+    relabel[root] = 0;
+    std::vector<int> queue, next_q, stack;
+    queue.push_back(root);
+    auto emit_leaves = [&](int node, int p, double lam) {
+        stack.clear();
+        stack.push_back(node);
+        while (!stack.empty()) {
+            int x = stack.back();
+            stack.pop_back();
+            if (x < n) {
+                r_parent.push_back(p); r_child.push_back(x); r_lambda.push_back(lam); r_size.push_back(1);
+            } else {
+                ignore[x] = 1;
+                stack.push_back(t.right[x - n]);
+                stack.push_back(t.left[x - n]);
+            }
+        }
+    };
+    const double INF = std::numeric_limits<double>::infinity();
+    while (!queue.empty()) {
+        next_q.clear();
+        for (int node : queue) {
+            if (node < n || ignore[node]) continue;
+            const int l = t.left[node - n], r = t.right[node - n];
+            const double d = t.dist[node - n];
+            const double lam = d > 0.0 ? 1.0 / d : INF;
+            const int lc = l >= n ? t.size[l - n] : 1, rc = r >= n ? t.size[r - n] : 1;
+            const int p = relabel[node];
+            if (lc >= min_cluster_size && rc >= min_cluster_size) {
+                relabel[l] = next_label;
+                r_parent.push_back(p); r_child.push_back(next_label++); r_lambda.push_back(lam); r_size.push_back(lc);
+                relabel[r] = next_label;
+                r_parent.push_back(p); r_child.push_back(next_label++); r_lambda.push_back(lam); r_size.push_back(rc);
+            } else if (lc < min_cluster_size && rc < min_cluster_size) {
+                emit_leaves(l, p, lam);
+                emit_leaves(r, p, lam);
+            } else if (lc < min_cluster_size) {
+                relabel[r] = p;
+                emit_leaves(l, p, lam);
+            } else {
+                relabel[l] = p;
+                emit_leaves(r, p, lam);
+            }
+            next_q.push_back(l);
+            next_q.push_back(r);
+        }
+        queue.swap(next_q);
+    }
+    const int nc = next_label;          // clusters 0..nc-1, 0 = root
+    const size_t nrows = r_parent.size();
+    // ---- stability, cluster tree ------------------------------------------------------------------
+    std::vector<double> birth(nc, 0.0), stab(nc, 0.0), death(nc, 0.0);
+    std::vector<int> cpar(nc, -1);
+    for (size_t i = 0; i < nrows; ++i)
+        if (r_size[i] > 1) {
+            birth[r_child[i]] = r_lambda[i];
+            cpar[r_child[i]] = r_parent[i];
+        }
+    for (size_t i = 0; i < nrows; ++i) {
+        stab[r_parent[i]] += (r_lambda[i] - birth[r_parent[i]]) * (double)r_size[i];
+        if (r_lambda[i] > death[r_parent[i]]) death[r_parent[i]] = r_lambda[i];
+    }
+    // children lists (CSR)
+    std::vector<int> kid_off(nc + 1, 0), kids(nc > 1 ? nc - 1 : 0);
+    for (int c = 1; c < nc; ++c) kid_off[cpar[c] + 1]++;
+    for (int c = 0; c < nc; ++c) kid_off[c + 1] += kid_off[c];
+    {
+        std::vector<int> cur(kid_off.begin(), kid_off.end() - 1);
+        for (int c = 1; c < nc; ++c) kids[cur[cpar[c]]++] = c;
+    }
+    // ---- excess of mass ----------------------------------------------------------------------------
+    std::vector<char> selected(nc, 1);
+    selected[0] = 0;
+    for (int c = nc - 1; c >= 1; --c) {
+        double sub = 0.0;
+        for (int k = kid_off[c]; k < kid_off[c + 1]; ++k) sub += stab[kids[k]];
+        if (sub > stab[c]) {
+            selected[c] = 0;
+            stab[c] = sub;
+        } else {
+            stack.clear();
+            for (int k = kid_off[c]; k < kid_off[c + 1]; ++k) stack.push_back(kids[k]);
+            while (!stack.empty()) {
+                int k = stack.back();
+                stack.pop_back();
+                selected[k] = 0;
+                for (int j = kid_off[k]; j < kid_off[k + 1]; ++j) stack.push_back(kids[j]);
+            }
+        }
+    }
+    // ---- cluster_selection_epsilon -------------------------------------------------------------------
+    if (eps != 0.0 && nc > 1) {
+        std::vector<char> cand(nc, 0);
+        for (int c = 1; c < nc; ++c) {
+            if (!selected[c]) continue;
+            if (1.0 / birth[c] < eps) {
+                int node = c;
+                while (true) {
+                    int p = cpar[node];
+                    if (p == 0) break;
+                    if (1.0 / birth[p] > eps) { node = p; break; }
+                    node = p;
+                }
+                cand[node] = 1;
+            } else
+                cand[c] = 1;
+        }
+        // top-most candidate wins (descendants of a chosen ancestor are dropped, _tree.pyx:634-636)
+        for (int c = 1; c < nc; ++c) {
+            selected[c] = 0;
+            if (!cand[c]) continue;
+            bool nested = false;
+            for (int a = cpar[c]; a > 0; a = cpar[a])
+                if (cand[a]) { nested = true; break; }
+            selected[c] = !nested;
+        }
+    }
+    // ---- labels + probabilities -------------------------------------------------------------------------
+    std::vector<int> label_of(nc, -1), owner(nc, -1);
+    int nl = 0;
+    for (int c = 1; c < nc; ++c)
+        if (selected[c]) label_of[c] = nl++;
+    for (int c = 1; c < nc; ++c) owner[c] = selected[c] ? c : owner[cpar[c]];
+    for (size_t i = 0; i < nrows; ++i) {
+        if (r_size[i] != 1) continue;
+        const int o = owner[r_parent[i]];
+        if (o < 0) continue;
+        const int pt = r_child[i];
+        h_labels[pt] = label_of[o];
+        const double mx = death[o], lam = r_lambda[i];
+        h_probs[pt] = (mx == 0.0 || std::isinf(lam)) ? 1.0 : std::min(lam, mx) / mx;
+    }
+    if (h_n_clusters) *h_n_clusters = nl;
+    return 0;
+}
