@@ -142,11 +142,25 @@ int vg_ground_get_patch_info(vg_ground* h, float* h_out, void* stream);
 
 /* Hierarchy stage on the HOST from the MST of the mutual-reachability graph, edges sorted ascending by
  * (w2, lo, hi): single linkage -> condense(min_cluster_size) -> stability -> EOM ->
- * cluster_selection_epsilon -> labels (-1 = noise) and probabilities.  h_w2: SQUARED weights.
+ * cluster_selection_epsilon -> labels (-1 = noise) and probabilities.  h_w2: SQUARED weights, ascending;
+ * runs of equal weight are re-ordered by (lo, hi) internally.
  * Host pointers only; no GPU involved (runs in the CPU test-suite too). */
 int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, const double* h_w2, int n,
                          int min_cluster_size, double eps, int32_t* h_labels, double* h_probs,
                          int32_t* h_n_clusters);
+
+/* GPU half of the clustering: exact k-NN core distances and THE minimum spanning tree of the mutual
+ * reachability graph under the strict edge order (w2, min id, max id) (unique -> identical to the CPU oracle's). */
+typedef struct vg_cluster vg_cluster;
+int vg_cluster_create(vg_cluster** out, int max_points);
+void vg_cluster_destroy(vg_cluster* h);
+/* d_points [n,stride] f32 (x,y,z first; `points_ref_wo_ground[..., :3]`, zero_shot_detector.py:246).
+ * k = min_samples (= min_cluster_size in the reference's configuration; k <= 15): core distance = distance to the
+ * k-th nearest OTHER point.  Outputs (device): d_core2 [n] f64 squared core distances in input order (may be NULL);
+ * d_mst_lo/hi [n-1] int32 input indices (lo < hi); d_mst_w2 [n-1] f64 SQUARED weights, ascending.
+ * Synchronises `stream` once per Boruvka round (4-byte counter read).  h_rounds (host, may be NULL): rounds used. */
+int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
+                   int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream);
 
 #ifdef __cplusplus
 }

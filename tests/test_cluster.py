@@ -153,3 +153,95 @@ def test_detections_from_labels_matches_reference_rule():
     probs = np.array([1, .2, .9, 0, .31, .29, .1, .2])
     det = ho.detections_from_labels(labels, probs)
     assert [d.tolist() for d in det] == [[0], [2, 4]]
+
+
+# ------------------------------------------------------------------------------------------- GPU
+def _gpu_model(cuda, n):
+    from vilgod_amd.hdbscan import HDBSCAN
+    return HDBSCAN(cluster_selection_epsilon=0.15, min_cluster_size=15, metric='euclidean', core_dist_n_jobs=-1,
+                   max_points=n + 16, device=cuda)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['lidar4k', 'lidar10k', 'blob', 'dupes', 'line', 'shifted'])
+def test_hip_core_mst_labels_equal_oracle(cuda, case):
+    """Bit-exact: squared core distances, the MST edge set + weights, labels, probabilities."""
+    import torch
+    rng = np.random.default_rng(1)
+    if case == 'lidar4k':
+        X = lidar_scene(1, 4000)
+    elif case == 'lidar10k':
+        X = lidar_scene(5, 10000)
+    elif case == 'blob':
+        X = blob_scene(0)
+    elif case == 'dupes':        # exact duplicate points and many equal distances (integer lattice)
+        X = np.concatenate([rng.integers(0, 6, size=(400, 3)).astype(np.float32) * 0.25,
+                            rng.integers(0, 6, size=(300, 3)).astype(np.float32) * 0.25 + [20, 0, 0]])
+    elif case == 'line':         # extremely sparse: forces the coarse levels / brute-force fallback
+        X = np.stack([np.arange(200) * 7.0, np.zeros(200), np.zeros(200)], 1).astype(np.float32)
+    else:                        # far from the origin (ref frame after 100 m of driving) + outliers beyond the grid
+        X = lidar_scene(2, 4000) + np.array([140.0, -90.0, 3.0], dtype=np.float32)
+        X = np.concatenate([X, np.array([[500, 500, 40], [-400, 0, -30]], dtype=np.float32)]).astype(np.float32)
+    n = len(X)
+    model = _gpu_model(cuda, n)
+    lo, hi, w2, core2 = model.mst(torch.from_numpy(X).to(cuda), want_core=True)
+    lo, hi, w2, core2 = lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), core2.cpu().numpy()
+    want_core2 = ho.core_distances_sq(X)
+    assert np.array_equal(core2, want_core2)
+    edges, ew2 = ho.mst_prim(X, want_core2)
+    e, w2s = ho.sort_edges(edges, ew2)
+    assert np.array_equal(w2, w2s)                                   # weights, sorted
+    got = np.stack([lo, hi], 1)[np.lexsort((hi, lo, w2))]
+    assert np.array_equal(got, e)                                    # the same (unique) tree
+    want_l, want_p = ho.tree_from_mst(e, w2s, n)
+    got_model = model.fit(X)
+    assert np.array_equal(got_model.labels_, want_l)
+    assert np.array_equal(got_model.probabilities_, want_p)
+    print(f'{case}: n={n} clusters={want_l.max() + 1} rounds={model.n_rounds_}')
+
+
+@pytest.mark.gpu
+def test_hip_cluster_small_and_degenerate(cuda):
+    import torch
+    model = _gpu_model(cuda, 1000)
+    for n in [0, 1, 2, 15, 16, 17, 40]:
+        X = np.random.default_rng(n).normal(size=(n, 3)).astype(np.float32)
+        m = model.fit(X)
+        want_l, want_p = ho.fit(X)
+        assert np.array_equal(m.labels_, want_l), n
+        assert np.array_equal(m.probabilities_, want_p), n
+
+
+@pytest.mark.gpu
+def test_hip_cluster_full_size_properties(cuda):
+    """BASELINE size (150k-point frame -> ~80k non-ground points): properties that need no CPU run --
+    spanning tree, weights sorted, invariance of weights/labels under a permutation of the input points
+    up to tie-breaking (we compare the weight multiset exactly and the partition by ARI), cluster sizes."""
+    import torch
+    from sklearn.metrics import adjusted_rand_score
+    X = lidar_scene(0, 150_000)
+    n = len(X)
+    model = _gpu_model(cuda, n)
+    lo, hi, w2 = [t.cpu().numpy() for t in model.mst(torch.from_numpy(X).to(cuda))]
+    assert len(lo) == n - 1 and (lo < hi).all() and (np.diff(w2) >= 0).all()
+    parent = np.arange(n)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b in zip(lo, hi):
+        ra, rb = find(a), find(b)
+        assert ra != rb
+        parent[ra] = rb
+    labels = model.fit(X).labels_
+    sizes = np.bincount(labels[labels >= 0])
+    assert sizes.min() >= 15
+    perm = np.random.default_rng(0).permutation(n)
+    lo2, hi2, w22 = [t.cpu().numpy() for t in model.mst(torch.from_numpy(X[perm]).to(cuda))]
+    assert np.array_equal(w2, w22)
+    labels2 = model.fit(X[perm]).labels_
+    ari = adjusted_rand_score(labels[perm], labels2)
+    print(f'full size: n={n} clusters={labels.max() + 1} rounds={model.n_rounds_} ARI under permutation={ari:.5f}')
+    assert ari > 0.99

@@ -1,0 +1,585 @@
+// Spatial clustering on gfx950 (kernels K2a-K2c): the GPU half of HDBSCAN.
+//
+// Replaces the work hidden in `cluster_model.fit(points_ref_wo_ground)` (src/vilgod/zero_shot_detector.py:248;
+// hdbscan.HDBSCAN(min_cluster_size=15, cluster_selection_epsilon=0.15), tools/configs/preprocessor/waymo.yaml:10-15):
+//   K2a  k_cl_bbox / k_cl_codes / radix sort / k_cl_cell_marks + scan
+//        points -> 0.8 m cells, Morton order (5 interleaved bits + 3 high bits of x,y), dense cell-start table
+//        (any 2^l-aligned cube of cells is ONE contiguous range of the sorted points)
+//   K2b  k_cl_core        exact k-NN core distance: expanding 3x3x3 cell blocks, float64 distances, 16-entry
+//                         register-resident sorted list, stop when the k-th distance fits inside the block
+//   K2c  k_cl_boruvka_*   exact minimum spanning tree of the mutual-reachability graph, Boruvka rounds with
+//                         the same cell search ("nearest point of another component"), pure-cell skipping and
+//                         per-component upper bounds; edges are ordered by the STRICT total order
+//                         (w2, min id, max id) so the tree is unique and equals the oracle's
+//        radix sort of the n-1 edges by weight
+// The sequential hierarchy stage (K2d) is csrc/hdbscan_tree.cpp on the host.
+//
+// All distances are float64 with d2 = (dx*dx + dy*dy) + dz*dz on exactly converted float32 coordinates
+// (what the library computes after its float64 conversion); compiled with -ffp-contract=off.
+#include <string.h>
+#include <cstring>
+#include <math.h>
+#include <algorithm>
+#include "common.h"
+#include "vilgod_hip.h"
+#include <rocprim/rocprim.hpp>
+
+#define CL_CELL 0.8
+#define CL_NX 256
+#define CL_NY 256
+#define CL_NZ 32
+#define CL_LB 5                       // interleaved bits per axis
+#define CL_NCODES (1 << 21)           // 8 + 8 + 5 bits
+#define CL_LMAX 5                     // coarsest Morton-contiguous level (25.6 m cubes)
+#define CL_K 16                       // neighbours kept (k-th other point = entry k, entry 0 is the point itself)
+
+struct ClGrid {
+    double ox, oy, oz;                // world coordinate of cell (0,0,0)'s min corner
+    unsigned int kmin[3], kmax[3];    // ordered-int bbox keys (scratch for the reduction)
+};
+
+struct vg_cluster {
+    int max_points;
+    ClGrid* d_grid;
+    unsigned int *d_code, *d_code_s;      // Morton codes (unsorted / sorted)
+    int *d_perm_in, *d_perm;              // identity / sorted -> original index
+    float4* d_spts;                       // sorted points (x,y,z,-)
+    int* d_cell_start;                    // [CL_NCODES+1] reversed min-scan layout, see cl_cell_start()
+    int* d_cell_comp;                     // [CL_NCODES] component id if the cell is pure, else -1
+    double* d_core2;                      // [n] sorted order
+    int *d_comp, *d_parent, *d_parent2;   // Boruvka components (sorted index space)
+    unsigned long long *d_best_w, *d_best_e;
+    int *d_sel_a, *d_sel_b;
+    unsigned long long *d_pt_w, *d_pt_key;
+    int* d_pt_b;
+    int* d_counter;                       // [0] number of MST edges emitted
+    int *d_mst_a, *d_mst_b;               // original ids
+    unsigned long long *d_mst_w, *d_mst_w_s;
+    int *d_mst_idx, *d_mst_idx_s;
+    void* d_temp;
+    size_t temp_bytes;
+    int* h_counter;                       // pinned
+};
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int cl_spread5(unsigned int v) {   // 5 bits -> every third bit
+    v &= 31u;
+    v = (v | (v << 8)) & 0x100Fu;
+    v = (v | (v << 4)) & 0x10C3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+__device__ __forceinline__ unsigned int cl_code(int cx, int cy, int cz) {
+    unsigned int lo = cl_spread5(cx) | (cl_spread5(cy) << 1) | (cl_spread5(cz) << 2);
+    unsigned int hi = ((unsigned int)cx >> 5) | (((unsigned int)cy >> 5) << 3);
+    return (hi << 15) | lo;
+}
+__device__ __forceinline__ void cl_cell_of(const ClGrid& g, double x, double y, double z, int& cx, int& cy, int& cz) {
+    cx = (int)floor((x - g.ox) * (1.0 / CL_CELL));
+    cy = (int)floor((y - g.oy) * (1.0 / CL_CELL));
+    cz = (int)floor((z - g.oz) * (1.0 / CL_CELL));
+    cx = cx < 0 ? 0 : (cx > CL_NX - 1 ? CL_NX - 1 : cx);
+    cy = cy < 0 ? 0 : (cy > CL_NY - 1 ? CL_NY - 1 : cy);
+    cz = cz < 0 ? 0 : (cz > CL_NZ - 1 ? CL_NZ - 1 : cz);
+}
+// cell_start is stored reversed (index NCODES - code) so that the "first point with code >= c" table is a
+// forward inclusive min-scan.
+__device__ __forceinline__ int cl_start(const int* __restrict__ cs, unsigned int code) { return cs[CL_NCODES - code]; }
+
+__global__ void k_cl_bbox(const float* __restrict__ pts, int n, int stride, ClGrid* g) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = pts[(size_t)i * stride + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = vg_wave_min(mn[a]);
+        mx[a] = vg_wave_max(mx[a]);
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&g->kmin[a], vg_fkey(mn[a]));
+            atomicMax(&g->kmax[a], vg_fkey(mx[a]));
+        }
+}
+
+__global__ void k_cl_grid(ClGrid* g) {
+    if (threadIdx.x != 0) return;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = vg_fkey_inv(g->kmin[a]);
+        hi[a] = vg_fkey_inv(g->kmax[a]);
+    }
+    const double ext[3] = {CL_NX * CL_CELL, CL_NY * CL_CELL, CL_NZ * CL_CELL};
+    double o[3];
+    for (int a = 0; a < 3; ++a) {
+        // centre the data in the grid when it fits, otherwise anchor at the minimum (outliers clamp to border cells)
+        double span = hi[a] - lo[a];
+        double start = span < ext[a] ? lo[a] - 0.5 * (ext[a] - span) : lo[a];
+        o[a] = floor(start / CL_CELL) * CL_CELL;
+    }
+    g->ox = o[0]; g->oy = o[1]; g->oz = o[2];
+}
+
+__global__ void k_cl_codes(const float* __restrict__ pts, int n, int stride, const ClGrid* __restrict__ g,
+                           unsigned int* __restrict__ code, int* __restrict__ perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cx, cy, cz;
+    cl_cell_of(*g, pts[(size_t)i * stride], pts[(size_t)i * stride + 1], pts[(size_t)i * stride + 2], cx, cy, cz);
+    code[i] = cl_code(cx, cy, cz);
+    perm[i] = i;
+}
+
+__global__ void k_cl_gather(const float* __restrict__ pts, int n, int stride, const int* __restrict__ perm,
+                            const unsigned int* __restrict__ code_s, float4* __restrict__ spts,
+                            int* __restrict__ cell_start_rev) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + (size_t)perm[i] * stride;
+    spts[i] = make_float4(p[0], p[1], p[2], 0.f);
+    if (i == 0 || code_s[i] != code_s[i - 1]) cell_start_rev[CL_NCODES - code_s[i]] = i;
+}
+
+__global__ void k_cl_fill_int(int* p, int v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cl_d2(double ax, double ay, double az, const float4& b) {
+    double dx = ax - (double)b.x, dy = ay - (double)b.y, dz = az - (double)b.z;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// squared distance from q to the nearest face of the level-l block [b-1, b+2) (faces clipped by the grid do not count)
+__device__ __forceinline__ double cl_block_radius2(const ClGrid& g, double qx, double qy, double qz, int bx, int by,
+                                                   int bz, int l) {
+    const double s = CL_CELL * (double)(1 << l);
+    double r = INFINITY;
+    const int nb[3] = {CL_NX >> l, CL_NY >> l, CL_NZ >> l};
+    const int b[3] = {bx, by, bz};
+    const double q[3] = {qx, qy, qz}, o[3] = {g.ox, g.oy, g.oz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // a face only bounds the search if cells exist beyond it (points outside the grid are clamped INTO border cells)
+        if (b[a] - 2 >= 0) r = fmin(r, q[a] - (o[a] + (double)(b[a] - 1) * s));
+        if (b[a] + 2 < nb[a]) r = fmin(r, (o[a] + (double)(b[a] + 2) * s) - q[a]);
+    }
+    if (r < 0) r = 0;
+    return isinf(r) ? INFINITY : r * r;
+}
+
+__global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, int n, const ClGrid* __restrict__ gp,
+                                                 const int* __restrict__ cs, int k, double* __restrict__ core2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ClGrid g = *gp;
+    const float4 qf = spts[i];
+    const double qx = qf.x, qy = qf.y, qz = qf.z;
+    int cx, cy, cz;
+    cl_cell_of(g, qx, qy, qz, cx, cy, cz);
+    double h[CL_K];
+    double result = INFINITY;
+    for (int l = 0; l <= CL_LMAX + 1; ++l) {
+#pragma unroll
+        for (int j = 0; j < CL_K; ++j) h[j] = INFINITY;
+        if (l > CL_LMAX) {   // brute force over everything (tiny or extremely sparse inputs)
+            for (int j = 0; j < n; ++j) {
+                double d2 = cl_d2(qx, qy, qz, spts[j]);
+                if (d2 < h[CL_K - 1]) {
+#pragma unroll
+                    for (int t = 0; t < CL_K; ++t)
+                        if (d2 < h[t]) { double tmp = h[t]; h[t] = d2; d2 = tmp; }
+                }
+            }
+            result = h[k];
+            break;
+        }
+        const int bx = cx >> l, by = cy >> l, bz = cz >> l;
+        const int nbx = CL_NX >> l, nby = CL_NY >> l, nbz = CL_NZ >> l;
+        const unsigned int span = 1u << (3 * l);
+        int count = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int x = bx + dx, y = by + dy, z = bz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
+                    unsigned int c0 = cl_code(x << l, y << l, z << l);
+                    count += cl_start(cs, c0 + span) - cl_start(cs, c0);
+                }
+        if (count <= k) continue;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int x = bx + dx, y = by + dy, z = bz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
+                    unsigned int c0 = cl_code(x << l, y << l, z << l);
+                    const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + span);
+                    for (int j = j0; j < j1; ++j) {
+                        double d2 = cl_d2(qx, qy, qz, spts[j]);
+                        if (d2 < h[CL_K - 1]) {
+#pragma unroll
+                            for (int t = 0; t < CL_K; ++t)
+                                if (d2 < h[t]) { double tmp = h[t]; h[t] = d2; d2 = tmp; }
+                        }
+                    }
+                }
+        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, l);
+        if (h[k] <= r2) {
+            result = h[k];
+            break;
+        }
+    }
+    core2[i] = result;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Boruvka
+#define CL_INF_BITS 0x7FF0000000000000ull
+
+__global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) comp[i] = i;
+    if (i == 0) counter[0] = 0;
+}
+
+__global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned long long* __restrict__ best_w,
+                                  unsigned long long* __restrict__ best_e, int* __restrict__ sel_a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    best_w[i] = CL_INF_BITS;
+    best_e[i] = ~0ull;
+    sel_a[i] = -1;
+}
+
+__global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ comp,
+                              int* __restrict__ cell_comp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int c = code_s[i];
+    if (i > 0 && code_s[i - 1] == c) return;
+    const int k0 = comp[i];
+    int pure = k0;
+    for (int j = i + 1; j < n && code_s[j] == c; ++j)
+        if (comp[j] != k0) { pure = -1; break; }
+    cell_comp[c] = pure;
+}
+
+__device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
+    unsigned int lo = oa < ob ? oa : ob, hi = oa < ob ? ob : oa;
+    return ((unsigned long long)lo << 32) | hi;
+}
+
+__global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ spts, int n,
+                                                     const ClGrid* __restrict__ gp, const int* __restrict__ cs,
+                                                     const int* __restrict__ cell_comp, const int* __restrict__ perm,
+                                                     const double* __restrict__ core2, const int* __restrict__ comp,
+                                                     unsigned long long* __restrict__ best_w,
+                                                     unsigned long long* __restrict__ pt_w,
+                                                     unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const ClGrid g = *gp;
+    const float4 qf = spts[a];
+    const double qx = qf.x, qy = qf.y, qz = qf.z;
+    const int ca = comp[a];
+    const double core_a = core2[a];
+    const int oa = perm[a];
+    int cx, cy, cz;
+    cl_cell_of(g, qx, qy, qz, cx, cy, cz);
+    double bw = INFINITY;
+    unsigned long long bkey = ~0ull;
+    int bb = -1;
+
+    auto scan = [&](int j0, int j1) {
+        for (int j = j0; j < j1; ++j) {
+            if (comp[j] == ca) continue;
+            double d2 = cl_d2(qx, qy, qz, spts[j]);
+            if (d2 > bw) continue;
+            double w = fmax(fmax(d2, core_a), core2[j]);
+            if (w > bw) continue;
+            unsigned long long key = cl_edge_key(oa, perm[j]);
+            if (w < bw || key < bkey) { bw = w; bkey = key; bb = j; }
+        }
+    };
+
+    for (int l = 0; l <= CL_LMAX + 1; ++l) {
+        if (l > CL_LMAX) {
+            scan(0, n);
+            break;
+        }
+        const int bx = cx >> l, by = cy >> l, bz = cz >> l;
+        if (l <= 1) {
+            // level-0 granularity so that cells owned entirely by this component are skipped unread
+            const int w = 1 << l;
+            const int x0 = (bx - 1) * w, y0 = (by - 1) * w, z0 = (bz - 1) * w;
+            for (int z = z0; z < z0 + 3 * w; ++z) {
+                if (z < 0 || z >= CL_NZ) continue;
+                for (int y = y0; y < y0 + 3 * w; ++y) {
+                    if (y < 0 || y >= CL_NY) continue;
+                    for (int x = x0; x < x0 + 3 * w; ++x) {
+                        if (x < 0 || x >= CL_NX) continue;
+                        unsigned int c0 = cl_code(x, y, z);
+                        const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + 1);
+                        if (j0 == j1) continue;
+                        if (cell_comp[c0] == ca) continue;
+                        scan(j0, j1);
+                    }
+                }
+            }
+        } else {
+            const int nbx = CL_NX >> l, nby = CL_NY >> l, nbz = CL_NZ >> l;
+            const unsigned int span = 1u << (3 * l);
+            for (int dz = -1; dz <= 1; ++dz)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        int x = bx + dx, y = by + dy, z = bz + dz;
+                        if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
+                        unsigned int c0 = cl_code(x << l, y << l, z << l);
+                        scan(cl_start(cs, c0), cl_start(cs, c0 + span));
+                    }
+        }
+        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, l);
+        if (r2 > bw) break;                                   // nothing unseen can tie or win
+        const double lb = fmax(core_a, r2);
+        const double cbest = __longlong_as_double((long long)__hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (lb > cbest) { bb = (bw <= cbest) ? bb : -1; break; }   // this point cannot hold its component's best edge
+    }
+    if (bb >= 0) {
+        atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
+        pt_w[a] = (unsigned long long)__double_as_longlong(bw);
+        pt_key[a] = bkey;
+        pt_b[a] = bb;
+    } else {
+        pt_w[a] = CL_INF_BITS;
+        pt_key[a] = ~0ull;
+        pt_b[a] = -1;
+    }
+}
+
+__global__ void k_cl_b_select(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
+                              const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_key,
+                              unsigned long long* __restrict__ best_e) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int c = comp[a];
+    if (pt_w[a] != CL_INF_BITS && pt_w[a] == best_w[c]) atomicMin(&best_e[c], pt_key[a]);
+}
+
+__global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
+                            const unsigned long long* __restrict__ best_e, const unsigned long long* __restrict__ pt_w,
+                            const unsigned long long* __restrict__ pt_key, const int* __restrict__ pt_b,
+                            int* __restrict__ sel_a, int* __restrict__ sel_b) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int c = comp[a];
+    if (pt_w[a] != CL_INF_BITS && pt_w[a] == best_w[c] && pt_key[a] == best_e[c]) {
+        sel_a[c] = a;
+        sel_b[c] = pt_b[a];
+    }
+}
+
+__global__ void k_cl_b_link(int n, const int* __restrict__ comp, const int* __restrict__ sel_a,
+                            const int* __restrict__ sel_b, int* __restrict__ parent) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    if (comp[c] != c) return;
+    parent[c] = (sel_a[c] >= 0) ? comp[sel_b[c]] : c;
+}
+
+__global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __restrict__ parent,
+                            const int* __restrict__ sel_a, const int* __restrict__ sel_b,
+                            const unsigned long long* __restrict__ best_w, const int* __restrict__ perm,
+                            int* __restrict__ parent2, int* __restrict__ counter, int* __restrict__ mst_a,
+                            int* __restrict__ mst_b, unsigned long long* __restrict__ mst_w) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    if (comp[c] != c) return;
+    const int p = parent[c];
+    if (p == c) { parent2[c] = c; return; }
+    const bool mutual = parent[p] == c;
+    if (mutual && c < p) {
+        parent2[c] = c;            // the smaller id of a mutual pair becomes the root; its partner emits the edge
+        return;
+    }
+    parent2[c] = p;
+    int k = atomicAdd(counter, 1);
+    mst_a[k] = perm[sel_a[c]];
+    mst_b[k] = perm[sel_b[c]];
+    mst_w[k] = best_w[c];
+}
+
+__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = comp[i];
+    while (parent2[r] != r) r = parent2[r];
+    comp[i] = r;
+}
+
+__global__ void k_cl_iota(int n, int* p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+__global__ void k_cl_unsort_core(int n, const int* __restrict__ perm, const double* __restrict__ core2_s,
+                                 double* __restrict__ core2_orig) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) core2_orig[perm[i]] = core2_s[i];
+}
+
+__global__ void k_cl_gather_edges(int m, const int* __restrict__ idx_s, const int* __restrict__ a,
+                                  const int* __restrict__ b, int* __restrict__ lo, int* __restrict__ hi) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int e = idx_s[i];
+    int x = a[e], y = b[e];
+    lo[i] = x < y ? x : y;
+    hi[i] = x < y ? y : x;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct MinOp {
+    __device__ __host__ int operator()(int a, int b) const { return a < b ? a : b; }
+};
+
+extern "C" {
+
+int vg_cluster_create(vg_cluster** out, int max_points) {
+    if (!out || max_points <= 0) return VG_ERR_ARG;
+    vg_cluster* h = new vg_cluster();
+    memset(h, 0, sizeof(*h));
+    h->max_points = max_points;
+    const size_t n = (size_t)max_points;
+    VG_CHECK(hipMalloc(&h->d_grid, sizeof(ClGrid)));
+    VG_CHECK(hipMalloc(&h->d_code, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_code_s, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_perm_in, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_perm, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_spts, sizeof(float4) * n));
+    VG_CHECK(hipMalloc(&h->d_cell_start, 4 * (size_t)(CL_NCODES + 1)));
+    VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * (size_t)CL_NCODES));
+    VG_CHECK(hipMalloc(&h->d_core2, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_comp, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_parent, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_parent2, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_best_w, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_best_e, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_sel_a, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_sel_b, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_pt_w, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_pt_key, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_pt_b, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_counter, 64));
+    VG_CHECK(hipMalloc(&h->d_mst_a, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_mst_b, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_mst_w, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_mst_w_s, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_mst_idx, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_mst_idx_s, 4 * n));
+    VG_CHECK(hipHostMalloc((void**)&h->h_counter, 64));
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    VG_CHECK(rocprim::radix_sort_pairs(nullptr, t1, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, n, 0, 21));
+    VG_CHECK(rocprim::radix_sort_pairs(nullptr, t2, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, n, 0, 64));
+    VG_CHECK(rocprim::inclusive_scan(nullptr, t3, h->d_cell_start, h->d_cell_start, (size_t)(CL_NCODES + 1), MinOp()));
+    h->temp_bytes = std::max(t1, std::max(t2, t3)) + 256;
+    VG_CHECK(hipMalloc(&h->d_temp, h->temp_bytes));
+    *out = h;
+    return VG_OK;
+}
+
+void vg_cluster_destroy(vg_cluster* h) {
+    if (!h) return;
+    void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_cell_start, h->d_cell_comp,
+                    h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
+                    h->d_pt_w, h->d_pt_key, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
+                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp};
+    for (void* p : ptrs) (void)hipFree(p);
+    (void)hipHostFree(h->h_counter);
+    delete h;
+}
+
+/* Exact core distances + exact MST of the mutual reachability graph.  SYNCHRONOUS on `stream` (one small
+ * device->host counter read per Boruvka round).
+ *   d_points [n,stride] f32 (x,y,z first);  k = min_samples (<= 15): core = distance to the k-th nearest OTHER point
+ *   d_core2  [n] f64 squared core distances, ORIGINAL point order (may be NULL)
+ *   d_mst_lo/hi [n-1] int32 original point ids (lo < hi), d_mst_w2 [n-1] f64 squared weights, sorted ascending by
+ *   weight (equal weights in unspecified order: vg_hdbscan_tree_host callers sort ties by (lo,hi)).
+ *   h_rounds: number of Boruvka rounds (diagnostic, may be NULL). */
+int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
+                   int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream) {
+    if (!h || !d_points || n < 0 || stride < 3 || k < 1 || k >= CL_K) return VG_ERR_ARG;
+    if (n > h->max_points) return VG_ERR_CAPACITY;
+    if (h_rounds) *h_rounds = 0;
+    if (n < 2) return VG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = vg_div_up(n, 256);
+    ClGrid g0;
+    memset(&g0, 0, sizeof(g0));
+    for (int a = 0; a < 3; ++a) { g0.kmin[a] = 0xFFFFFFFFu; g0.kmax[a] = 0u; }
+    VG_CHECK(hipMemcpyAsync(h->d_grid, &g0, sizeof(g0), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_cl_bbox, dim3(std::min(nb, 1024)), dim3(256), 0, st, d_points, n, stride, h->d_grid);
+    hipLaunchKernelGGL(k_cl_grid, dim3(1), dim3(64), 0, st, h->d_grid);
+    hipLaunchKernelGGL(k_cl_codes, dim3(nb), dim3(256), 0, st, d_points, n, stride, h->d_grid, h->d_code, h->d_perm_in);
+    size_t tb = h->temp_bytes;
+    VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, (size_t)n, 0, 21, st));
+    {
+        size_t tot = (size_t)CL_NCODES + 1;
+        hipLaunchKernelGGL(k_cl_fill_int, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->d_cell_start, n, tot);
+    }
+    hipLaunchKernelGGL(k_cl_gather, dim3(nb), dim3(256), 0, st, d_points, n, stride, h->d_perm, h->d_code_s, h->d_spts,
+                       h->d_cell_start);
+    tb = h->temp_bytes;
+    VG_CHECK(rocprim::inclusive_scan(h->d_temp, tb, h->d_cell_start, h->d_cell_start, (size_t)(CL_NCODES + 1), MinOp(), st));
+    hipLaunchKernelGGL(k_cl_core, dim3(nb), dim3(256), 0, st, h->d_spts, n, h->d_grid, h->d_cell_start, k, h->d_core2);
+    if (d_core2) hipLaunchKernelGGL(k_cl_unsort_core, dim3(nb), dim3(256), 0, st, n, h->d_perm, h->d_core2, d_core2);
+    VG_LAUNCH_CHECK();
+    // ---- Boruvka ----
+    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter);
+    int rounds = 0, edges = 0;
+    while (edges < n - 1) {
+        if (++rounds > 64) {
+            fprintf(stderr, "[vilgod_hip] vg_cluster_mst: Boruvka did not converge (%d of %d edges)\n", edges, n - 1);
+            return VG_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_e, h->d_sel_a);
+        hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp);
+        hipLaunchKernelGGL(k_cl_b_search, dim3(nb), dim3(256), 0, st, h->d_spts, n, h->d_grid, h->d_cell_start, h->d_cell_comp,
+                           h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_pt_b);
+        hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_best_e);
+        hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_e, h->d_pt_w, h->d_pt_key,
+                           h->d_pt_b, h->d_sel_a, h->d_sel_b);
+        hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent);
+        hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent, h->d_sel_a, h->d_sel_b, h->d_best_w,
+                           h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w);
+        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2);
+        VG_CHECK(hipMemcpyAsync(h->h_counter, h->d_counter, 4, hipMemcpyDeviceToHost, st));
+        VG_CHECK(hipStreamSynchronize(st));
+        int e = h->h_counter[0];
+        if (e == edges) {
+            fprintf(stderr, "[vilgod_hip] vg_cluster_mst: no progress in round %d (%d of %d edges)\n", rounds, e, n - 1);
+            return VG_ERR_HIP;
+        }
+        edges = e;
+    }
+    if (h_rounds) *h_rounds = rounds;
+    // ---- sort edges by weight ----
+    const int m = n - 1;
+    hipLaunchKernelGGL(k_cl_iota, dim3(vg_div_up(m, 256)), dim3(256), 0, st, m, h->d_mst_idx);
+    tb = h->temp_bytes;
+    VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, (size_t)m, 0, 64, st));
+    if (d_mst_lo && d_mst_hi)
+        hipLaunchKernelGGL(k_cl_gather_edges, dim3(vg_div_up(m, 256)), dim3(256), 0, st, m, h->d_mst_idx_s, h->d_mst_a, h->d_mst_b,
+                           d_mst_lo, d_mst_hi);
+    if (d_mst_w2) VG_CHECK(hipMemcpyAsync(d_mst_w2, h->d_mst_w_s, 8 * (size_t)m, hipMemcpyDeviceToDevice, st));
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+}  // extern "C"

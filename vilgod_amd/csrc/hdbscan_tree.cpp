@@ -52,6 +52,24 @@ extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, co
     }
     if (n <= min_cluster_size) return 0;
     const int m = n - 1;
+    // ---- strict total order (w2, lo, hi): the GPU sorts by weight only, fix up runs of equal weight ----
+    std::vector<int32_t> lo_v(h_lo, h_lo + m), hi_v(h_hi, h_hi + m);
+    {
+        std::vector<std::pair<int32_t, int32_t>> run;
+        for (int i = 0; i < m;) {
+            int j = i + 1;
+            while (j < m && h_w2[j] == h_w2[i]) ++j;
+            if (j - i > 1) {
+                run.clear();
+                for (int k = i; k < j; ++k) run.emplace_back(lo_v[k], hi_v[k]);
+                std::sort(run.begin(), run.end());
+                for (int k = i; k < j; ++k) { lo_v[k] = run[k - i].first; hi_v[k] = run[k - i].second; }
+            }
+            i = j;
+        }
+    }
+    h_lo = lo_v.data();
+    h_hi = hi_v.data();
     // ---- single linkage ------------------------------------------------------------------------
     Tree t;
     t.n = n;
