@@ -162,6 +162,34 @@ void vg_cluster_destroy(vg_cluster* h);
 int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
                    int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream);
 
+/* ---- frame transform, validity filters, boxes (rows B1, B4, C1, C2, E1) --------------------------------
+ * dst[i] = float32(T * [src[i],1]), other columns copied: LidarFrame.points_ref
+ * (src/vilgod/lidar_frame.py:66-69 -> src/utils/pointcloud_utils.py:21-46). */
+int vg_ref_transform(const float* d_src, int n, int stride, const double* d_T4x4, float* d_dst, void* stream);
+
+/* Ground plane by RANSAC: LidarFrame.ground_plane_model_ref (lidar_frame.py:96-109) -> fit_plane
+ * (pointcloud_utils.py:375-387) -> pyransac3d.Plane.fit (un-vendored).  Same algorithm (3-point hypotheses,
+ * |distance| <= thresh inlier count, first strictly best of `iters`), sample indices from a counter-based hash of
+ * (seed, iteration) instead of python's global `random`.  Call twice (all ground points, then the inliers) like
+ * fit_plane does.  d_index: optional index list (NULL = first n rows).  d_work: iters*36+64 bytes scratch. */
+int vg_plane_ransac(const float* d_points, int stride, const int32_t* d_index, int n, double thresh, int iters,
+                    uint64_t seed, void* d_work, double* d_plane4, uint8_t* d_flags, int32_t* d_count, void* stream);
+
+/* Detection.filter with the three active filters of tools/configs/preprocessor/waymo.yaml:16-49
+ * (src/dataclass/objects.py:158-181; src/utils/cluster_utils.py:14-15 number_points, :48-49 height,
+ * :51-60 plane_distance; all `and` + `required`).  Clusters = segments of d_index (packed point indices into
+ * d_points).  d_stats6[c] = {n, zmin, zmax, dmin, dmax, height}; d_valid[c] = 0/1. */
+int vg_cluster_filter(const float* d_points, int stride, const int32_t* d_index, const int32_t* d_seg_off, int n_clusters,
+                      const double* d_plane4, int min_points, int max_points, double max_min_height, double min_max_height,
+                      double min_height, double max_height, float* d_stats6, uint8_t* d_valid, void* stream);
+
+/* fit_bounding_boxes_simple, static branch (src/vilgod/zero_shot_detector.py:444-462) with
+ * method minimum_bounding_rectangle (pointcloud_utils.py:309-372): d_box7[c] = {cx,cy,cz,l,w,h+0.3,rz} float64 in
+ * the frame of d_points; d_aux3[c] = {hull vertices, rectangle area, degenerate flag}.  All hull edges are tried
+ * (the reference omits the closing edge of qhull's vertex cycle, :329-330). */
+int vg_cluster_boxes(const float* d_points, int stride, const int32_t* d_index, const int32_t* d_seg_off, int n_clusters,
+                     double* d_box7, float* d_aux3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,7 +88,9 @@ def install():
     p3.ops = _mod("pytorch3d.ops")
     p3.ops.knn = _mod("pytorch3d.ops.knn", knn_gather=None, knn_points=None)
     pc = _mod("pcdet")
+    pc.__path__ = []
     pc.ops = _mod("pcdet.ops")
+    pc.utils = _mod("pcdet.utils", common_utils=None)
     pc.ops.roiaware_pool3d = _mod("pcdet.ops.roiaware_pool3d", roiaware_pool3d_utils=None)
     pc.ops.pointnet2 = _mod("pcdet.ops.pointnet2")
     pc.ops.pointnet2.pointnet2_stack = _mod("pcdet.ops.pointnet2.pointnet2_stack", pointnet2_utils=None)

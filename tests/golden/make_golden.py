@@ -94,6 +94,80 @@ def make_vit():
     print('vit_golden.npz')
 
 
+def make_detect():
+    """B3/C1/D10/E1/F1/T1: the reference's LidarFrame / Detection / cluster_utils / pointcloud_utils run
+    unchanged (stub imports) on a small seeded frame -> tests/golden/detect_golden.pkl."""
+    import logging
+    import pickle
+    from functools import partial
+    refstubs.install()
+    from src.vilgod.lidar_frame import LidarFrame
+    from src.utils import cluster_utils, pointcloud_utils
+    from vilgod_amd import synthetic
+    from oracle import hdbscan_oracle as ho, patchworkpp as opw
+    cfg = refstubs.AttrDict(preprocessor=dict(clustering=dict(propability_threshold=0.3,
+                            entropy_score_filter=dict(percentile=30, min_percentile_pp_score=0.5))))
+    pts = synthetic.make_frame(7, 12000, n_objects=10)
+    poses = synthetic.make_poses(3, step=0.5, seed=1)
+    pose, ref_pose = poses[2], poses[0]
+    frame = LidarFrame('seq', 2, pts, dict(gt_names=[], moving=[]), pose, ref_pose, cfg, logging.getLogger('g'))
+    params = opw.Parameters()
+    params.min_range = 1.5
+    gidx = opw.mask_ground_points(pts, opw.patchworkpp(params), 1.723)
+    frame.update_ground_indices(gidx)
+    X = frame.points_ref_wo_ground[..., :3]
+    labels, probs = ho.fit(X)
+    frame.generate_detections(labels.copy(), probs.copy(), assign_gt=False, entropy_scores=frame.entropy_scores)
+    plane = np.array([0.01, -0.005, 1.0, 0.02])
+    filters = []
+    for name, args in [('filter_by_number_points', dict(logic='and', required=True, min_points=10)),
+                       ('filter_by_height', dict(logic='and', required=True, min_height=0.3, max_height=6)),
+                       ('filter_by_plane_distance', dict(logic='and', required=True, max_min_height=1.0, min_max_height=0.5))]:
+        filters.append([partial(getattr(cluster_utils, name), **args), name, args.get('logic'), args.get('required', False)])
+    boxes, stats = [], []
+    for det in frame.detections:
+        det.filter(filters, plane_model=plane)                                            # objects.py:158
+        cp = det.cluster_points
+        corners, rz, area = pointcloud_utils.minimum_bounding_rectangle(cp[:, :2])        # pointcloud_utils.py:309
+        l = np.linalg.norm(corners[0] - corners[1])
+        w = np.linalg.norm(corners[0] - corners[-1])
+        c = (corners[0] + corners[2]) / 2
+        if w > l:
+            l, w = w, l
+            rz += np.pi / 2
+        height = cp[:, 2].max() - cp[:, 2].min()
+        box = np.array([c[0], c[1], cp[:, 2].min() + height / 2, l, w, height + 0.3, rz])  # zero_shot_detector.py:452-460
+        det.update_bounding_box(box)
+        boxes.append(box)
+    # voting with engineered ties (lidar_frame.py:260-291)
+    rng = np.random.default_rng(3)
+    n_det = len(frame.detections)
+    fine = ['car', 'truck', 'pedestrian', 'cyclist', 'pole', 'tree']
+    mapping = dict(car='Vehicle', truck='Vehicle', pedestrian='Pedestrian', cyclist='Cyclist', pole='Background', tree='Background')
+    detailed = rng.choice(fine, size=(n_det, 4))
+    detailed[0] = ['car', 'truck', 'pedestrian', 'pedestrian']          # 2-2 tie
+    detailed[1] = ['car', 'pole', 'cyclist', 'pedestrian']              # 1-1-1-1 tie
+    names = np.vectorize(mapping.get)(detailed)
+    scores = rng.uniform(0.1, 0.9, size=(n_det, 4)).astype(np.float32)
+    key = 'clip_a_point_representation_of_a'
+    upd = [d.valid for d in frame.detections]
+    nv = sum(upd)
+    frame.update_object_classes(names[:nv], detailed[:nv], scores[:nv], upd, key=key, aggregation='voting')
+    ser = frame.serialize                                                                  # lidar_frame.py:41-59
+    ego_boxes = pointcloud_utils.apply_transform(np.array(boxes), frame.transform_to_ego, box=True)   # zero_shot_detector.py:847
+    out = dict(points=pts, pose=pose, ref_pose=ref_pose, ground_idx=gidx, labels=labels, probs=probs, plane=plane,
+               points_ref=frame.points_ref, transform_to_ref=frame.transform_to_ref, transform_to_ego=frame.transform_to_ego,
+               det_ids=[d.cluster_id for d in frame.detections],
+               det_index=[d.cluster_points_index for d in frame.detections],
+               det_center=[d.cluster_center for d in frame.detections], det_median=[d.cluster_mass_center for d in frame.detections],
+               det_height=[d.height for d in frame.detections], valid=[bool(d.valid) for d in frame.detections],
+               boxes_ref=np.array(boxes), boxes_ego=ego_boxes, vote_names=names, vote_detailed=detailed, vote_scores=scores,
+               vote_key=key, serialized=ser)
+    with open(os.path.join(OUT, 'detect_golden.pkl'), 'wb') as f:
+        pickle.dump(out, f)
+    print('detect_golden.pkl', n_det, 'detections,', nv, 'valid')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['render', 'vit']
     for w in which:

@@ -176,7 +176,7 @@ def test_hip_core_mst_labels_equal_oracle(cuda, case):
         X = blob_scene(0)
     elif case == 'dupes':        # exact duplicate points and many equal distances (integer lattice)
         X = np.concatenate([rng.integers(0, 6, size=(400, 3)).astype(np.float32) * 0.25,
-                            rng.integers(0, 6, size=(300, 3)).astype(np.float32) * 0.25 + [20, 0, 0]])
+                            rng.integers(0, 6, size=(300, 3)).astype(np.float32) * 0.25 + [20, 0, 0]]).astype(np.float32)
     elif case == 'line':         # extremely sparse: forces the coarse levels / brute-force fallback
         X = np.stack([np.arange(200) * 7.0, np.zeros(200), np.zeros(200)], 1).astype(np.float32)
     else:                        # far from the origin (ref frame after 100 m of driving) + outliers beyond the grid

@@ -1,0 +1,72 @@
+"""End-to-end hot path [A]-[F] on one frame: GPU pipeline vs the chained CPU oracle (BASELINE config 1 shape:
+single synthetic 20k-point frame).  fp32 ViT: probabilities within 1e-3, identical classes / valid flags /
+ground set / cluster labels; boxes vs the all-edges oracle within 2 mm."""
+import numpy as np
+import pytest
+import torch
+
+from vilgod_amd import synthetic, clip_weights as cw
+
+
+@pytest.mark.gpu
+def test_pipeline_matches_oracle_20k(cuda):
+    from vilgod_amd.pipeline import PseudoLabelPipeline, default_preprocessor_cfg
+    from vilgod_amd.clip_wrapper import ClipWrapper
+    from oracle.pipeline_oracle import OraclePipeline
+    from oracle import segment_oracle as so
+    cfg = default_preprocessor_cfg()
+    pts = synthetic.make_frame(3, 20_000, n_objects=12)
+    poses = synthetic.make_poses(2, seed=4)
+    pipe = PseudoLabelPipeline(cfg, device=cuda, vit_dtype='f32', max_points=25_000, clip_model_path='/nonexistent')
+    assert pipe.clip.weights_source.startswith('synthetic')
+    assert pipe.cls_key == 'clip_a_point_representation_of_a'
+    fs, res = pipe.process_frame(pts, poses[1], poses[0], fnr=1)
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    text = cw.synthetic_text_features(0, 24, 512)
+    orc = OraclePipeline(wd, text, cfg['clip']['class_list'], cfg['clip']['class_mapping'])
+    o = orc.process_frame(pts, poses[1], poses[0])
+    assert np.array_equal(np.sort(fs.ground_point_indices), o['ground_idx'])
+    assert [int(c) for c in fs.cluster_ids] == [c for c, _ in o['dets']]
+    for c, (_, idx) in enumerate(o['dets']):
+        assert np.array_equal(fs.cluster_index(c), idx)
+    assert np.array_equal(pipe.ground_plane(pipe.to_ref(pipe.upload(pts), fs.transform_to_ref),
+                                            torch.from_numpy(o['ground_idx']).to(cuda)), o['plane'])
+    assert np.array_equal(fs.valid, o['valid'])
+    got_p = pipe.last_probs.cpu().numpy()
+    assert got_p.shape == o['probs_clip'].shape and got_p.shape[0] == 4 * int(o['valid'].sum())
+    err = np.abs(got_p - o['probs_clip']).max()
+    print('clusters', len(o['dets']), 'valid', int(o['valid'].sum()), 'max |dp|', err)
+    # crops can differ by the <=1 ulp view angle (test_render.py); on agreeing crops the bar is 1e-3
+    close = np.abs(got_p - o['probs_clip']).max(axis=1) < 1e-3
+    assert close.mean() >= 0.9
+    e = fs.cls[pipe.cls_key]
+    rows = np.flatnonzero(fs.valid)
+    agree = sum(str(e['name'][r]) == n for r, n in zip(rows, o['names']))
+    assert agree >= len(rows) - 1
+    assert np.allclose(fs.boxes[rows][:, [2, 5]], o['boxes_ref'][:, [2, 5]], atol=1e-6)
+    for r, want in zip(rows, o['boxes_ref']):
+        ca, cb = so.box_corners_bev(fs.boxes[r]), so.box_corners_bev(want)
+        assert np.abs(ca[:, None, :] - cb[None]).sum(-1).min(1).max() < 2e-3
+    assert set(res.keys()) == {'boxes_lidar', 'name', 'score', 'moving'}
+    assert res['boxes_lidar'].shape[1] == 7 and len(res['name']) == len(res['score']) == len(res['boxes_lidar'])
+    # serialisation survives a round trip
+    import pickle
+    from vilgod_amd.frame_state import FrameState
+    st = FrameState(1, poses[1], poses[0])
+    st.sync(pickle.loads(pickle.dumps(fs.serialize)))
+    assert np.array_equal(st.valid, fs.valid) and np.allclose(st.boxes[rows], fs.boxes[rows])
+
+
+@pytest.mark.gpu
+def test_pipeline_fp16_full_size_frame_runs(cuda):
+    """BASELINE config 3 shape: 150k points, fp16 ViT, 4 views; sanity on outputs + per-stage times."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    pipe = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=160_000, clip_model_path='/nonexistent')
+    poses = synthetic.make_poses(3)
+    for f in range(3):
+        fs, res = pipe.process_frame(synthetic.make_frame(f, 150_000), poses[f], poses[0], fnr=f, timing=True)
+        print(f, 'clusters', fs.n_detections, 'valid', int(fs.valid.sum()), 'labelled', len(res['name']),
+              {k: round(v * 1000, 2) for k, v in pipe.timings.items()})
+        assert fs.n_detections > 20 and fs.valid.sum() > 10
+        assert 0.35 < len(fs.ground_point_indices) / 150_000 < 0.6
+        assert np.isfinite(res['boxes_lidar']).all() and (res['score'] > 0).all()

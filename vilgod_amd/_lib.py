@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, 'libvilgod_hip.so')
 
 _SCALARS = {
     'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint32_t': ctypes.c_uint32,
-    'uint64_t': ctypes.c_uint64, 'size_t': ctypes.c_size_t, 'float': ctypes.c_float, 'double': ctypes.c_double,
+    'uint64_t': ctypes.c_uint64, 'uint8_t': ctypes.c_uint8, 'size_t': ctypes.c_size_t, 'float': ctypes.c_float, 'double': ctypes.c_double,
     'void': None,
 }
 

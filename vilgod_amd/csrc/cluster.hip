@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
 
 // ---------------------------------------------------------------------------------------------
 // Boruvka
-#define CL_INF_BITS 0x7FF0000000000000ull
+#define CL_NONE 0xFFFFFFFFFFFFFFFFull   // 'no candidate' (sorts after every weight, +inf included)
 
 __global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,7 +253,7 @@ __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned 
                                   unsigned long long* __restrict__ best_e, int* __restrict__ sel_a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    best_w[i] = CL_INF_BITS;
+    best_w[i] = CL_NONE;
     best_e[i] = ~0ull;
     sel_a[i] = -1;
 }
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
         const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, l);
         if (r2 > bw) break;                                   // nothing unseen can tie or win
         const double lb = fmax(core_a, r2);
-        const double cbest = __longlong_as_double((long long)__hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const unsigned long long cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
         if (lb > cbest) { bb = (bw <= cbest) ? bb : -1; break; }   // this point cannot hold its component's best edge
     }
     if (bb >= 0) {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
         pt_key[a] = bkey;
         pt_b[a] = bb;
     } else {
-        pt_w[a] = CL_INF_BITS;
+        pt_w[a] = CL_NONE;
         pt_key[a] = ~0ull;
         pt_b[a] = -1;
     }
@@ -369,7 +370,7 @@ __global__ void k_cl_b_select(int n, const int* __restrict__ comp, const unsigne
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
-    if (pt_w[a] != CL_INF_BITS && pt_w[a] == best_w[c]) atomicMin(&best_e[c], pt_key[a]);
+    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c]) atomicMin(&best_e[c], pt_key[a]);
 }
 
 __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
@@ -379,7 +380,7 @@ __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned 
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
-    if (pt_w[a] != CL_INF_BITS && pt_w[a] == best_w[c] && pt_key[a] == best_e[c]) {
+    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c] && pt_key[a] == best_e[c]) {
         sel_a[c] = a;
         sel_b[c] = pt_b[a];
     }

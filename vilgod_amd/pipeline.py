@@ -1,0 +1,295 @@
+"""The per-frame pseudo-label hot path on one GPU (SURVEY §3.2 [A]-[F]), every per-point / per-crop
+computation in the HIP kernels of csrc/, data resident in HBM from raw points to class scores.
+
+Stage functions are separate so that the reference-shaped stage dispatcher (zero_shot_detector.py) and the
+benchmark can call them one by one; `process_frame` chains them.
+
+    ground(points)                 A1-A5   csrc/ground.hip
+    to_ref + non-ground gather     B1      csrc/segment.hip (+ torch index plumbing)
+    cluster(X)                     B2-B3   csrc/cluster.hip (GPU) + csrc/hdbscan_tree.cpp (host)
+    ground plane + filters         C1-C2   csrc/segment.hip
+    render + encode + score        D1-D9   csrc/render.hip, csrc/vit.hip
+    vote                           D10     host numpy (<= ~150 clusters)
+    boxes                          E1      csrc/segment.hip
+    results                        F1      host numpy
+"""
+import time
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+from ._lib import lib, ptr, stream_ptr, check
+from .frame_state import FrameState, pack_clusters, vote
+from . import patchworkpp as gpw
+from .hdbscan import HDBSCAN
+from .projection import RealisticProjection, VIEWS_4, VIEWS_6
+from .clip_wrapper import ClipWrapper
+
+# tools/configs/preprocessor/waymo.yaml:104-140
+DEFAULT_CLASS_LIST = ['car', 'truck', 'bus', 'van', 'minivan', 'pickup truck', 'school bus', 'fire truck', 'ambulance',
+                      'pedestrian', 'human body', 'human', 'cyclist', 'rider', 'bicycle', 'bike',
+                      'traffic light', 'traffic sign', 'fence', 'pole', 'clutter', 'tree', 'house', 'wall']
+DEFAULT_CLASS_MAPPING = {**{k: 'Vehicle' for k in DEFAULT_CLASS_LIST[:9]}, **{k: 'Pedestrian' for k in DEFAULT_CLASS_LIST[9:12]},
+                         **{k: 'Cyclist' for k in DEFAULT_CLASS_LIST[12:16]}, **{k: 'Background' for k in DEFAULT_CLASS_LIST[16:]}}
+
+
+def default_preprocessor_cfg():
+    """The subset of tools/configs/preprocessor/waymo.yaml the hot path reads."""
+    return dict(
+        name='waymo', class_names=['Vehicle', 'Pedestrian', 'Cyclist'],
+        clustering=dict(
+            model=dict(cluster_selection_epsilon=0.15, min_cluster_size=15, metric='euclidean', core_dist_n_jobs=-1),
+            filters_active=['filter_by_number_points', 'filter_by_plane_distance', 'filter_by_height'],
+            filters=[dict(name='filter_by_number_points', args=dict(logic='and', required=True, min_points=10)),
+                     dict(name='filter_by_height', args=dict(logic='and', required=True, min_height=0.3, max_height=6)),
+                     dict(name='filter_by_plane_distance', args=dict(logic='and', required=True, max_min_height=1.0, min_max_height=0.5))],
+            propability_threshold=0.3),
+        lidar_image_projection=dict(depth_bias=0.2, obj_ratio=0.8, bg_clr=0.0, resolution=112, depth=8,
+                                    gaussian_kernel=dict(sigma=3, zsigma=1)),
+        clip=dict(name='clip', model_name='ViT-B-16.pt', top_k=1, split_size=50,
+                  prompt_template='a point representation of a {}', class_list=DEFAULT_CLASS_LIST,
+                  class_mapping=DEFAULT_CLASS_MAPPING))
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if hasattr(cfg, key) else default
+
+
+class PseudoLabelPipeline:
+    def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
+                 clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None):
+        cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.z_offset = float(z_offset)
+        self.max_points = int(max_points)
+        params = gpw.Parameters()
+        params.min_range = float(min_range)
+        self._pw_params = params
+        self.ground_model = gpw.patchworkpp(params, max_points=self.max_points, device=self.device)
+        ccfg = _get(cfg, 'clustering')
+        mcfg = dict(_get(ccfg, 'model'))
+        mcfg.pop('_target_', None)
+        self.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **mcfg)
+        self.prob_threshold = float(_get(ccfg, 'propability_threshold', 0.3))
+        self._filters = self._parse_filters(ccfg)
+        self.projection = RealisticProjection(_get(cfg, 'lidar_image_projection'), device=self.device,
+                                              views=VIEWS_4 if n_views == 4 else VIEWS_6)
+        clip_cfg = _get(cfg, 'clip')
+        self.clip = clip if clip is not None else ClipWrapper(clip_cfg, clip_model_path, device=self.device, dtype=vit_dtype)
+        self.vit_dtype = vit_dtype
+        self.class_list = list(_get(clip_cfg, 'class_list'))
+        mapping = _get(clip_cfg, 'class_mapping')
+        self.mapped_names = sorted(set(mapping[c] for c in self.class_list))          # alphabetical = np.unique order
+        self.fine_to_mapped = np.array([self.mapped_names.index(mapping[c]) for c in self.class_list])
+        self.class_names = list(_get(cfg, 'class_names', ['Vehicle', 'Pedestrian', 'Cyclist']))
+        self.cls_key = f"{_get(clip_cfg, 'name', 'clip')}_" + '_'.join(str(_get(clip_cfg, 'prompt_template')).format('').split(' ')[:-1])
+        self.plane_seed = int(plane_seed)
+        self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
+        self.timings = {}
+
+    @staticmethod
+    def _parse_filters(ccfg):
+        active = list(_get(ccfg, 'filters_active', []))
+        f = dict(min_points=0, max_points=999999, max_min_height=np.inf, min_max_height=-np.inf, min_height=-np.inf,
+                 max_height=np.inf, use_plane=False)
+        known = {'filter_by_number_points', 'filter_by_plane_distance', 'filter_by_height'}
+        for flt in _get(ccfg, 'filters', []):
+            name, args = _get(flt, 'name'), dict(_get(flt, 'args', {}))
+            if name not in active:
+                continue
+            if name not in known:
+                # zero_shot_detector.py:283: filters that do not exist in cluster_utils are skipped silently
+                # (filter_by_density); the others of cluster_utils are not used by the shipped configs
+                if name in ('filter_by_aspect_ratio', 'filter_by_volume', 'filter_by_area', 'filter_by_ephemeral_score'):
+                    raise NotImplementedError(f'{name} is not active in the reference configs and has no GPU kernel')
+                continue
+            if not (args.get('logic') == 'and' and args.get('required', False)):
+                raise NotImplementedError('only `logic: and, required: True` filters (the shipped configuration)')
+            if name == 'filter_by_number_points':
+                f['min_points'], f['max_points'] = args.get('min_points', 0), args.get('max_points', 999999)
+            elif name == 'filter_by_height':
+                f['min_height'], f['max_height'] = args['min_height'], args['max_height']
+            else:
+                f['max_min_height'], f['min_max_height'], f['use_plane'] = args['max_min_height'], args['min_max_height'], True
+        return f
+
+    # ---------------------------------------------------------------------------------------------
+    def new_sequence(self):
+        """A fresh Patchwork++ state per sequence (zero_shot_detector.py:137-140)."""
+        self.ground_model.reset()
+
+    def upload(self, points):
+        if isinstance(points, torch.Tensor):
+            return points.to(self.device, non_blocking=True)
+        return torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(self.device, non_blocking=True)
+
+    # [A]
+    def ground(self, d_points):
+        return self.ground_model.estimate_mask(d_points, self.z_offset)
+
+    # [B1]
+    def to_ref(self, d_points, transform_to_ref):
+        T = torch.from_numpy(np.ascontiguousarray(transform_to_ref, dtype=np.float64)).to(self.device)
+        out = torch.empty_like(d_points)
+        check(lib.vg_ref_transform(ptr(d_points), d_points.shape[0], d_points.stride(0), ptr(T), ptr(out), stream_ptr()),
+              'vg_ref_transform')
+        return out
+
+    # [B2] + [B3]
+    def cluster(self, d_X):
+        """d_X: [M,>=3] CUDA float32 (points_ref_wo_ground).  -> labels, probs (host)."""
+        n = d_X.shape[0]
+        if n < 2:
+            return np.full(n, -1, np.int64), np.zeros(n)
+        lo, hi, w2 = self.cluster_model.mst(d_X)
+        labels, probs, _ = self.cluster_model.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), n)
+        return labels, probs
+
+    # [C2]
+    def ground_plane(self, d_points_ref, d_ground_idx):
+        """fit_plane(points_ref[ground_mask]) (lidar_frame.py:96-109; pointcloud_utils.py:375-387): two RANSAC stages."""
+        n = int(d_ground_idx.numel())
+        if n < 3:
+            return np.array([0.0, 0.0, 1.0, 0.0])
+        dev = self.device
+        plane = torch.empty(4, dtype=torch.float64, device=dev)
+        flags = torch.empty(n, dtype=torch.uint8, device=dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=dev)
+        idx = d_ground_idx.to(torch.int32)
+        check(lib.vg_plane_ransac(ptr(d_points_ref), d_points_ref.stride(0), ptr(idx), n, 0.1, 100, self.plane_seed,
+                                  ptr(self._ransac_work), ptr(plane), ptr(flags), ptr(cnt), stream_ptr()), 'vg_plane_ransac')
+        idx2 = idx[flags.bool()].contiguous()
+        n2 = int(idx2.numel())
+        if n2 >= 3:
+            flags2 = torch.empty(n2, dtype=torch.uint8, device=dev)
+            check(lib.vg_plane_ransac(ptr(d_points_ref), d_points_ref.stride(0), ptr(idx2), n2, 0.1, 100, self.plane_seed + 1,
+                                      ptr(self._ransac_work), ptr(plane), ptr(flags2), ptr(cnt), stream_ptr()), 'vg_plane_ransac')
+        p = plane.cpu().numpy()
+        if p[2] < 0:
+            p = p * -1
+        return p
+
+    # [B4] + [C1]
+    def filter(self, d_X, d_index, d_seg, plane):
+        C = d_seg.numel() - 1
+        stats = torch.empty((C, 6), dtype=torch.float32, device=self.device)
+        valid = torch.empty(C, dtype=torch.uint8, device=self.device)
+        f = self._filters
+        d_plane = torch.from_numpy(np.ascontiguousarray(plane, dtype=np.float64)).to(self.device)
+        big = 1e300
+        check(lib.vg_cluster_filter(ptr(d_X), d_X.stride(0), ptr(d_index), ptr(d_seg), C, ptr(d_plane), int(f['min_points']),
+                                    int(f['max_points']), float(min(f['max_min_height'], big)), float(max(f['min_max_height'], -big)),
+                                    float(max(f['min_height'], -big)), float(min(f['max_height'], big)), ptr(stats), ptr(valid),
+                                    stream_ptr()), 'vg_cluster_filter')
+        return valid, stats
+
+    # [D1]-[D9]
+    def classify(self, d_X, d_index, d_seg, transform_to_ego):
+        out = 'f16' if self.vit_dtype == 'f16' else 'f32'
+        crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out=out)
+        return self.clip.predict_probs(crops)
+
+    # [E1]
+    def boxes(self, d_X, d_index, d_seg):
+        C = d_seg.numel() - 1
+        box = torch.empty((C, 7), dtype=torch.float64, device=self.device)
+        aux = torch.empty((C, 3), dtype=torch.float32, device=self.device)
+        check(lib.vg_cluster_boxes(ptr(d_X), d_X.stride(0), ptr(d_index), ptr(d_seg), C, ptr(box), ptr(aux), stream_ptr()),
+              'vg_cluster_boxes')
+        return box, aux
+
+    # [F1]
+    @staticmethod
+    def boxes_to_ego(boxes_ref, transform_to_ego):
+        """apply_transform(boxes, transform_to_ego, box=True) (pointcloud_utils.py:21-46; zero_shot_detector.py:847)."""
+        if len(boxes_ref) == 0:
+            return np.zeros((0, 7))
+        out = np.array(boxes_ref, dtype=np.float64, copy=True)
+        h = np.hstack((out[:, :3], np.ones((len(out), 1))))
+        out[:, :3] = np.einsum('ij,kj->ki', transform_to_ego, h)[:, :3]
+        out[:, 6] += Rotation.from_matrix(transform_to_ego[:3, :3]).as_euler('xyz')[-1]
+        return out
+
+    # ---------------------------------------------------------------------------------------------
+    def process_frame(self, points, pose, ref_pose, fnr=0, state=None, timing=False):
+        """One frame through [A]-[F].  points: (N,>=4) float32 numpy/CUDA [x,y,z,intensity,...].
+        Returns (FrameState, result dict {'boxes_lidar','name','score','moving'})."""
+        t = {}
+        sync = torch.cuda.synchronize if timing else (lambda: None)
+
+        def tick(name, t0):
+            sync()
+            t[name] = time.perf_counter() - t0
+            return time.perf_counter()
+
+        t0 = time.perf_counter()
+        fs = state if state is not None else FrameState(fnr, pose, ref_pose)
+        d_pts = self.upload(points)
+        fs.n_points = d_pts.shape[0]
+        mask = self.ground(d_pts)
+        t0 = tick('ground', t0)
+        d_ref = self.to_ref(d_pts, fs.transform_to_ref)
+        ng = torch.nonzero(mask == 0).squeeze(1)
+        gidx = torch.nonzero(mask).squeeze(1)
+        d_X = d_ref.index_select(0, ng).contiguous()
+        fs.ground_point_indices = gidx.cpu().numpy()
+        t0 = tick('to_ref', t0)
+        labels, probs = self.cluster(d_X)
+        t0 = tick('cluster', t0)
+        ids, index, seg = pack_clusters(labels, probs, self.prob_threshold)
+        fs.set_clusters(ids, index, seg)
+        C = len(ids)
+        result = {'boxes_lidar': np.zeros((0, 7)), 'name': np.array([]), 'score': np.array([]), 'moving': np.array([])}
+        if C == 0:
+            self.timings = t
+            return fs, result
+        d_index = torch.from_numpy(index).to(self.device)
+        d_seg = torch.from_numpy(seg).to(self.device)
+        plane = self.ground_plane(d_ref, gidx) if self._filters['use_plane'] else np.array([0.0, 0.0, 1.0, 0.0])
+        fs.ground_plane_model_ref = plane
+        valid, _ = self.filter(d_X, d_index, d_seg, plane)
+        fs.valid = valid.cpu().numpy().astype(bool)
+        fs.filtered = True
+        t0 = tick('filter', t0)
+        vrows = np.flatnonzero(fs.valid)
+        if len(vrows) == 0:
+            self.timings = t
+            return fs, result
+        # packed sub-list of the valid clusters (classification and boxes are `valid_only`, preprocessing.yaml:81,89)
+        parts = [index[seg[c]:seg[c + 1]] for c in vrows]
+        v_index = np.concatenate(parts)
+        v_seg = np.r_[0, np.cumsum([len(p) for p in parts])].astype(np.int32)
+        d_vindex = torch.from_numpy(v_index).to(self.device)
+        d_vseg = torch.from_numpy(v_seg).to(self.device)
+        probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
+        box, _ = self.boxes(d_X, d_vindex, d_vseg)
+        top1 = top1.cpu().numpy()
+        score = score.cpu().numpy()
+        box = box.cpu().numpy()
+        t0 = tick('classify+boxes', t0)
+        V = self.projection.num_views
+        nv = len(vrows)
+        fine = top1.reshape(nv, V)
+        sc = score.reshape(nv, V).astype(np.float32)
+        mapped = self.fine_to_mapped[fine]
+        win, final = vote(mapped, sc, self.mapped_names)
+        names = np.array(self.mapped_names, dtype=object)
+        fine_names = np.array(self.class_list, dtype=object)
+        fs.set_classes(self.cls_key, fs.valid.copy(), names[mapped], fine_names[fine], sc, names[win], final)
+        fs.boxes = np.full((C, 7), np.nan)
+        fs.boxes[vrows] = box
+        # [F1] evaluate_sequence (zero_shot_detector.py:832-857)
+        keep = np.array([names[w] in self.class_names for w in win], dtype=bool)
+        result = {'boxes_lidar': self.boxes_to_ego(box[keep], fs.transform_to_ego),
+                  'name': np.array([str(names[w]) for w in win[keep]]),
+                  'score': np.array(final[keep]),
+                  'moving': np.zeros(int(keep.sum()), dtype=bool)}
+        t0 = tick('vote+results', t0)
+        self.timings = t
+        self.last_probs = probs_d
+        return fs, result
