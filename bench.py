@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the pseudo-label hot path (BASELINE.json metric: pseudo-labeled LiDAR frames/sec,
+150k-pt frames, ~60 clusters, at 1/2/4/8 MI355X).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one synthetic 150k-point frame through the whole per-frame path on every rank
+(ground removal -> ref transform -> HDBSCAN -> filters -> multi-view render -> CLIP ViT-B/16 fp16 encode ->
+scores -> vote -> boxes -> result dict).  Frames are sharded across ranks (weak scaling: K frames per GPU);
+the only collective is ONE all-gather of the per-crop score matrices after the K frames (north_star).
+Inputs are resident in HBM before the timed region starts.
+
+The JSON line also carries
+  roofline      the dominant kernel (ViT projection GEMM, k_gemm_f16): algorithmic FLOPs / launch duration, measured
+                live with HIP event pairs on the launch stream (csrc/vit.hip vg_vit_profile), vs the dense fp16
+                MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md
+  cpu_baseline  the CPU oracle (oracle/pipeline_oracle.py, kind "port": the reference cannot travel to the GPU box)
+                timed on a bounded sample on the host cores of the same box (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VIT_FLOP_PER_CROP = 2 * 17_563_453_440
+PEAK_F16_MFMA_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+
+
+def cpu_baseline(n_points=20_000, n_objects=12):
+    """Whole path on the host cores for one bounded frame (BASELINE config 0 shape)."""
+    from oracle.pipeline_oracle import OraclePipeline
+    from vilgod_amd import synthetic, clip_weights as cw
+    from vilgod_amd.pipeline import default_preprocessor_cfg
+    torch.set_num_threads(os.cpu_count())
+    cfg = default_preprocessor_cfg()
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    text = cw.synthetic_text_features(0, 24, 512)
+    orc = OraclePipeline(wd, text, cfg['clip']['class_list'], cfg['clip']['class_mapping'], clusterer='sklearn')
+    pts = synthetic.make_frame(1000, n_points, n_objects=n_objects)
+    poses = synthetic.make_poses(2)
+    t0 = time.perf_counter()
+    o = orc.process_frame(pts, poses[1], poses[0])
+    dt = time.perf_counter() - t0
+    return {
+        'value': round(1.0 / dt, 5), 'unit': 'frames/s', 'cores': os.cpu_count(), 'kind': 'port',
+        'sample': (f'1 synthetic frame of {n_points} points / {int(o["valid"].sum())} valid clusters / {len(o["u8"])} crops '
+                   f'(BASELINE config 0 shape; a 150k-pt frame carries ~5x the crops and ~8x the points), all stages, '
+                   f'{dt:.1f} s: ' + ', '.join(f'{k} {v:.2f}s' for k, v in orc.timings.items()) +
+                   '; clustering = sklearn.cluster.HDBSCAN stand-in (the reference\'s hdbscan package is absent), '
+                   'ViT = torch-CPU fp32, same synthetic weights'),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--points', type=int, default=150_000)
+    ap.add_argument('--objects', type=int, default=60)
+    ap.add_argument('--views', type=int, default=4)
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--stage-times', action='store_true', help='print per-stage ms (adds synchronisation; not for the metric)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                device_id=torch.device(f'cuda:{local_rank}'))
+    dev = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+
+    from vilgod_amd import synthetic
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    pipe = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=args.views, max_points=args.points + 1024,
+                               clip_model_path='/nonexistent')
+    # a short synthetic sequence per rank: frames differ, poses follow a smooth trajectory; resident in HBM
+    n_distinct = 4
+    poses = synthetic.make_poses(args.steps + args.warmup + 1, seed=rank)
+    frames = [pipe.upload(synthetic.make_frame(1 + rank * 100 + i, args.points, n_objects=args.objects)) for i in range(n_distinct)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        fs, res = pipe.process_frame(frames[i % n_distinct], poses[i + 1], poses[0], fnr=i, timing=args.stage_times)
+        return fs, res, pipe.last_probs
+
+    pipe.new_sequence()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    pipe.clip.encoder.profile(True)
+    crops = clusters = labelled = 0
+    stage = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    score_mats = []
+    for i in range(args.steps):
+        fs, res, probs = step(args.warmup + i)
+        score_mats.append(probs)
+        crops += probs.shape[0]
+        clusters += fs.n_detections
+        labelled += len(res['name'])
+        for k, v in pipe.timings.items():
+            stage[k] = stage.get(k, 0.0) + v
+    # the one collective of the path: all-gather of the per-crop score matrices (padded to a common length)
+    scores = torch.cat(score_mats) if score_mats else torch.zeros((0, 24), device=dev)
+    if dist is not None:
+        n_loc = torch.tensor([scores.shape[0]], device=dev, dtype=torch.int64)
+        n_all = [torch.zeros_like(n_loc) for _ in range(world)]
+        dist.all_gather(n_all, n_loc)
+        mx = int(max(int(x.item()) for x in n_all))
+        pad = torch.zeros((mx, scores.shape[1]), device=dev, dtype=scores.dtype)
+        pad[:scores.shape[0]] = scores
+        gathered = torch.empty((world * mx, scores.shape[1]), device=dev, dtype=scores.dtype)
+        dist.all_gather_into_tensor(gathered, pad)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    launches, gemm_ms, gemm_flops = pipe.clip.encoder.profile_read()
+    pipe.clip.encoder.profile(False)
+
+    if rank == 0:
+        frames_total = world * args.steps
+        value = frames_total / elapsed
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        out = {
+            'metric': 'pseudo-labeled LiDAR frames/sec (150k pts, ~60 clusters)',
+            'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f16' if args.dtype == 'f16' else 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': (f'full per-frame path (ground removal, HDBSCAN, filters, {args.views}-view render, CLIP ViT-B/16 '
+                             f'{args.dtype} encode, scores, vote, boxes) on synthetic {args.points}-pt frames, '
+                             f'{args.objects} objects (BASELINE config 3 shape), frames sharded {world}-way, '
+                             'one all-gather of the score matrices'),
+                'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': args.steps,
+                'clusters_per_frame': round(clusters / max(args.steps, 1), 1),
+                'crops_per_frame': round(crops / max(args.steps, 1), 1),
+                'labelled_per_frame': round(labelled / max(args.steps, 1), 1),
+                'weights': pipe.clip.weights_source, 'parallelism': f'frame-sharded x{world}',
+            },
+            'roofline': {
+                'kernel': 'k_gemm_f16 (ViT projection GEMMs: in_proj, out_proj, c_fc, c_proj, patch embedding)',
+                'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches': launches, 'avg_launch_us': round(1000.0 * gemm_ms / max(launches, 1), 2),
+                'algorithmic_flops_per_launch': round(gemm_flops / max(launches, 1)),
+                'gemm_share_of_step_time': round(gemm_ms * 1e-3 / (elapsed) * 1.0, 4) if world == 1 else None,
+            },
+        }
+        if args.stage_times:
+            out['stage_ms_per_frame'] = {k: round(1000.0 * v / args.steps, 3) for k, v in stage.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -77,6 +77,12 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops);
  * writes).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
 int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                   void* stream);
+/* Measurement hooks (bench.py `roofline`): HIP event pairs around every projection-GEMM launch of
+ * vg_vit_encode, on the stream the kernels are launched on.  vg_vit_profile(v,1) arms and clears,
+ * vg_vit_profile_read synchronises and returns launches, summed ms and algorithmic FLOPs (2*M*N*K each). */
+int vg_vit_profile(vg_vit* v, int on);
+int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_flops);
+
 /* One projection GEMM of the tower, C = X @ Wt^T with the fused epilogue the block uses
  * (model.py:175-191: in_proj, out_proj + residual, c_fc + QuickGELU, c_proj + residual), exposed so the
  * GEMM can be unit-tested and timed alone.  dtype 1: f16 operands (M%128, N%128, K%64 == 0); 0: f32

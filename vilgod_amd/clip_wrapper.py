@@ -54,6 +54,15 @@ class VitEncoder:
             self._ws_crops = n
         return self._ws
 
+    def profile(self, on=True):
+        check(lib.vg_vit_profile(self._h, 1 if on else 0), 'vg_vit_profile')
+
+    def profile_read(self):
+        """-> (launches, total ms, total algorithmic FLOPs) of the projection GEMMs since profile(True)."""
+        n, ms, fl = ctypes.c_int32(0), ctypes.c_double(0), ctypes.c_double(0)
+        check(lib.vg_vit_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'vg_vit_profile_read')
+        return n.value, ms.value, fl.value
+
     def encode(self, crops, stream=None):
         """crops: [n,3,res,res] float32 or float16 CUDA tensor -> [n,output_dim] float32 features."""
         assert crops.is_cuda and crops.is_contiguous()

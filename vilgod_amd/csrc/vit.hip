@@ -526,8 +526,14 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 }
 
 // ---------------------------------------------------------------------------------------------
+#define VG_PROF_MAX 4096
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
+    // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
+    int prof_on = 0, prof_n = 0;
+    hipEvent_t prof_ev[2 * VG_PROF_MAX];
+    double prof_flops[VG_PROF_MAX];
+    bool prof_init = false;
     std::map<std::string, void*> w;        // device pointers (f32 or f16 depending on role)
     std::map<std::string, size_t> numel;
 };
@@ -539,8 +545,15 @@ static bool is_gemm_weight(const std::string& n) {
 }
 
 template <int EPI>
-static int launch_gemm(const vg_vit* v, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
+static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
                        int N, int K, hipStream_t st) {
+    vg_vit* v = const_cast<vg_vit*>(cv);
+    const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
+    if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
+    struct Closer {
+        vg_vit* v; bool prof; hipStream_t st; double fl;
+        ~Closer() { if (prof) { (void)hipEventRecord(v->prof_ev[2 * v->prof_n + 1], st); v->prof_flops[v->prof_n++] = fl; } }
+    } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K};
     if (v->dtype == 1) {
         if (M % GT || N % GT || K % GK) return VG_ERR_ARG;
         int nwg = (M / GT) * (N / GT);
@@ -572,6 +585,7 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
 
 void vg_vit_destroy(vg_vit* v) {
     if (!v) return;
+    if (v->prof_init) for (int i = 0; i < 2 * VG_PROF_MAX; ++i) (void)hipEventDestroy(v->prof_ev[i]);
     for (auto& kv : v->w) (void)hipFree(kv.second);
     delete v;
 }
@@ -732,6 +746,34 @@ int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* 
         case 3: return launch_gemm<EPI_NONE_F32>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
     }
     return VG_ERR_ARG;
+}
+
+/* on != 0: record a HIP event pair around every projection-GEMM launch of vg_vit_encode (on the launch stream);
+ * resets the collected samples. */
+int vg_vit_profile(vg_vit* v, int on) {
+    if (!v) return VG_ERR_ARG;
+    if (on && !v->prof_init) {
+        for (int i = 0; i < 2 * VG_PROF_MAX; ++i) VG_CHECK(hipEventCreate(&v->prof_ev[i]));
+        v->prof_init = true;
+    }
+    v->prof_on = on;
+    v->prof_n = 0;
+    return VG_OK;
+}
+
+/* synchronises, then returns the number of GEMM launches sampled, their summed duration (ms) and algorithmic FLOPs */
+int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_flops) {
+    if (!v || !h_launches || !h_ms || !h_flops) return VG_ERR_ARG;
+    *h_launches = 0; *h_ms = 0; *h_flops = 0;
+    for (int i = 0; i < v->prof_n; ++i) {
+        VG_CHECK(hipEventSynchronize(v->prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        VG_CHECK(hipEventElapsedTime(&ms, v->prof_ev[2 * i], v->prof_ev[2 * i + 1]));
+        *h_ms += ms;
+        *h_flops += v->prof_flops[i];
+    }
+    *h_launches = v->prof_n;
+    return VG_OK;
 }
 
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
