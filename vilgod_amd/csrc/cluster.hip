@@ -3,13 +3,16 @@
 // Replaces the work hidden in `cluster_model.fit(points_ref_wo_ground)` (src/vilgod/zero_shot_detector.py:248;
 // hdbscan.HDBSCAN(min_cluster_size=15, cluster_selection_epsilon=0.15), tools/configs/preprocessor/waymo.yaml:10-15):
 //   K2a  k_cl_bbox / k_cl_codes / radix sort / k_cl_cell_marks + scan
-//        points -> 0.8 m cells, Morton order (5 interleaved bits + 3 high bits of x,y), dense cell-start table
+//        points -> 0.4 m cells, Morton order (6 interleaved bits + 3 high bits of x,y), dense cell-start table
 //        (any 2^l-aligned cube of cells is ONE contiguous range of the sorted points)
-//   K2b  k_cl_core        exact k-NN core distance: expanding 3x3x3 cell blocks, float64 distances, 16-entry
-//                         register-resident sorted list, stop when the k-th distance fits inside the block
-//   K2c  k_cl_boruvka_*   exact minimum spanning tree of the mutual-reachability graph, Boruvka rounds with
-//                         the same cell search ("nearest point of another component"), pure-cell skipping and
-//                         per-component upper bounds; edges are ordered by the STRICT total order
+//   K2b  k_cl_core        exact k-NN core distance: pruned depth-first walk of the implicit octree (nearest child
+//                         first, box-distance pruning against the current k-th distance, nodes with <= 48 points
+//                         scanned directly), float64 distances, 16-entry register-resident sorted list
+//   K2c  k_cl_b_*         exact minimum spanning tree of the mutual-reachability graph, Boruvka rounds with the
+//                         same walk ("nearest point of another component"): subtrees owned entirely by the
+//                         query's component are skipped through per-round purity tables (levels 0..3), and
+//                         per-component upper bounds published with atomicMin prune the rest of the component;
+//                         edges are ordered by the STRICT total order
 //                         (w2, min id, max id) so the tree is unique and equals the oracle's
 //        radix sort of the n-1 edges by weight
 // The sequential hierarchy stage (K2d) is csrc/hdbscan_tree.cpp on the host.
@@ -24,13 +27,16 @@
 #include "vilgod_hip.h"
 #include <rocprim/rocprim.hpp>
 
-#define CL_CELL 0.8
-#define CL_NX 256
-#define CL_NY 256
-#define CL_NZ 32
-#define CL_LB 5                       // interleaved bits per axis
-#define CL_NCODES (1 << 21)           // 8 + 8 + 5 bits
-#define CL_LMAX 5                     // coarsest Morton-contiguous level (25.6 m cubes)
+#define CL_CELL 0.4
+#define CL_NX 512
+#define CL_NY 512
+#define CL_NZ 64
+#define CL_LB 6                       // interleaved bits per axis
+#define CL_NCODES (1 << 24)           // 9 + 9 + 6 bits
+#define CL_LMAX 6                     // coarsest Morton-contiguous level (25.6 m cubes): 8 x 8 x 1 roots
+#define CL_PUR_LEVELS 4               // purity tables for levels 0..3 (0.4 .. 3.2 m)
+#define CL_LEAF 48                    // nodes with at most this many points are scanned instead of subdivided
+#define CL_STACK 64
 #define CL_K 16                       // neighbours kept (k-th other point = entry k, entry 0 is the point itself)
 
 struct ClGrid {
@@ -45,7 +51,7 @@ struct vg_cluster {
     int *d_perm_in, *d_perm;              // identity / sorted -> original index
     float4* d_spts;                       // sorted points (x,y,z,-)
     int* d_cell_start;                    // [CL_NCODES+1] reversed min-scan layout, see cl_cell_start()
-    int* d_cell_comp;                     // [CL_NCODES] component id if the cell is pure, else -1
+    int* d_cell_comp;                     // purity tables, levels 0..3 back to back: component id if pure, else -1
     double* d_core2;                      // [n] sorted order
     int *d_comp, *d_parent, *d_parent2;   // Boruvka components (sorted index space)
     unsigned long long *d_best_w, *d_best_e;
@@ -62,17 +68,17 @@ struct vg_cluster {
 };
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned int cl_spread5(unsigned int v) {   // 5 bits -> every third bit
-    v &= 31u;
-    v = (v | (v << 8)) & 0x100Fu;
-    v = (v | (v << 4)) & 0x10C3u;
-    v = (v | (v << 2)) & 0x1249u;
+__device__ __forceinline__ unsigned int cl_spread6(unsigned int v) {   // 6 bits -> every third bit
+    v &= 63u;
+    v = (v | (v << 8)) & 0x300Fu;
+    v = (v | (v << 4)) & 0x30C3u;
+    v = (v | (v << 2)) & 0x9249u;
     return v;
 }
 __device__ __forceinline__ unsigned int cl_code(int cx, int cy, int cz) {
-    unsigned int lo = cl_spread5(cx) | (cl_spread5(cy) << 1) | (cl_spread5(cz) << 2);
-    unsigned int hi = ((unsigned int)cx >> 5) | (((unsigned int)cy >> 5) << 3);
-    return (hi << 15) | lo;
+    unsigned int lo = cl_spread6(cx) | (cl_spread6(cy) << 1) | (cl_spread6(cz) << 2);
+    unsigned int hi = ((unsigned int)cx >> 6) | (((unsigned int)cy >> 6) << 3);
+    return (hi << 18) | lo;
 }
 __device__ __forceinline__ void cl_cell_of(const ClGrid& g, double x, double y, double z, int& cx, int& cy, int& cz) {
     cx = (int)floor((x - g.ox) * (1.0 / CL_CELL));
@@ -175,68 +181,88 @@ __device__ __forceinline__ double cl_block_radius2(const ClGrid& g, double qx, d
     return isinf(r) ? INFINITY : r * r;
 }
 
+// ---- pruned depth-first traversal of the implicit octree ---------------------------------------------------
+// A node = (level l, cell coordinates at that level); its points are the contiguous range
+// [start(code), start(code + 8^l)) of the Morton-sorted array.  Stack entries pack (l, x, y, z) in 32 bits and live
+// in LDS, interleaved by thread (bank-conflict free).
+__device__ __forceinline__ unsigned int cl_pack(int l, int x, int y, int z) {
+    return ((unsigned int)l << 27) | ((unsigned int)x << 18) | ((unsigned int)y << 9) | (unsigned int)z;
+}
+__device__ __forceinline__ void cl_unpack(unsigned int e, int& l, int& x, int& y, int& z) {
+    l = (int)(e >> 27); x = (int)((e >> 18) & 511u); y = (int)((e >> 9) & 511u); z = (int)(e & 511u);
+}
+// squared distance from q to the axis-aligned box of node (l,x,y,z); 0 inside.  Border nodes extend to infinity on
+// the outside (points beyond the grid are clamped INTO border cells).
+__device__ __forceinline__ double cl_box_d2(const ClGrid& g, double qx, double qy, double qz, int l, int x, int y, int z) {
+    const double s = CL_CELL * (double)(1 << l);
+    const int nb[3] = {CL_NX >> l, CL_NY >> l, CL_NZ >> l};
+    const int c[3] = {x, y, z};
+    const double q[3] = {qx, qy, qz}, o[3] = {g.ox, g.oy, g.oz};
+    double d2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double lo = o[a] + (double)c[a] * s, hi = lo + s;
+        double d = 0.0;
+        if (q[a] < lo && c[a] > 0) d = lo - q[a];
+        else if (q[a] > hi && c[a] < nb[a] - 1) d = q[a] - hi;
+        d2 += d * d;
+    }
+    return d2;
+}
+
 __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, int n, const ClGrid* __restrict__ gp,
                                                  const int* __restrict__ cs, int k, double* __restrict__ core2) {
+    __shared__ unsigned int stack[CL_STACK * 256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[i];
     const double qx = qf.x, qy = qf.y, qz = qf.z;
     int cx, cy, cz;
     cl_cell_of(g, qx, qy, qz, cx, cy, cz);
     double h[CL_K];
-    double result = INFINITY;
-    for (int l = 0; l <= CL_LMAX + 1; ++l) {
 #pragma unroll
-        for (int j = 0; j < CL_K; ++j) h[j] = INFINITY;
-        if (l > CL_LMAX) {   // brute force over everything (tiny or extremely sparse inputs)
-            for (int j = 0; j < n; ++j) {
-                double d2 = cl_d2(qx, qy, qz, spts[j]);
-                if (d2 < h[CL_K - 1]) {
+    for (int j = 0; j < CL_K; ++j) h[j] = INFINITY;
+    const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
+    const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
+    for (int rr = 0; rr < nrx * nry; ++rr) {
+        // own root first, then the others (pruned by distance)
+        int rx = rr % nrx, ry = rr / nrx;
+        if (rr == 0) { rx = rx0; ry = ry0; }
+        else if (rx == rx0 && ry == ry0) { rx = 0; ry = 0; }
+        int sp = 0;
+        st[0] = cl_pack(CL_LMAX, rx, ry, 0);
+        sp = 1;
+        while (sp > 0) {
+            int l, x, y, z;
+            cl_unpack(st[(--sp) * 256], l, x, y, z);
+            const unsigned int c0 = cl_code(x << l, y << l, z << l);
+            const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
+            if (j0 == j1) continue;
+            if (cl_box_d2(g, qx, qy, qz, l, x, y, z) >= h[k]) continue;     // cannot lower the k-th distance
+            if (l == 0 || j1 - j0 <= CL_LEAF) {
+                for (int j = j0; j < j1; ++j) {
+                    double d2 = cl_d2(qx, qy, qz, spts[j]);
+                    if (d2 < h[CL_K - 1]) {
 #pragma unroll
-                    for (int t = 0; t < CL_K; ++t)
-                        if (d2 < h[t]) { double tmp = h[t]; h[t] = d2; d2 = tmp; }
-                }
-            }
-            result = h[k];
-            break;
-        }
-        const int bx = cx >> l, by = cy >> l, bz = cz >> l;
-        const int nbx = CL_NX >> l, nby = CL_NY >> l, nbz = CL_NZ >> l;
-        const unsigned int span = 1u << (3 * l);
-        int count = 0;
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    int x = bx + dx, y = by + dy, z = bz + dz;
-                    if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
-                    unsigned int c0 = cl_code(x << l, y << l, z << l);
-                    count += cl_start(cs, c0 + span) - cl_start(cs, c0);
-                }
-        if (count <= k) continue;
-        for (int dz = -1; dz <= 1; ++dz)
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx) {
-                    int x = bx + dx, y = by + dy, z = bz + dz;
-                    if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
-                    unsigned int c0 = cl_code(x << l, y << l, z << l);
-                    const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + span);
-                    for (int j = j0; j < j1; ++j) {
-                        double d2 = cl_d2(qx, qy, qz, spts[j]);
-                        if (d2 < h[CL_K - 1]) {
-#pragma unroll
-                            for (int t = 0; t < CL_K; ++t)
-                                if (d2 < h[t]) { double tmp = h[t]; h[t] = d2; d2 = tmp; }
-                        }
+                        for (int u = 0; u < CL_K; ++u)
+                            if (d2 < h[u]) { double tmp = h[u]; h[u] = d2; d2 = tmp; }
                     }
                 }
-        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, l);
-        if (h[k] <= r2) {
-            result = h[k];
-            break;
+                continue;
+            }
+            // children, nearest octant LAST on the stack -> popped first
+            const int l1 = l - 1;
+            const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
+            const int near = ox | (oy << 1) | (oz << 2);
+            for (int c = 7; c >= 0; --c) {
+                const int ch = c ^ near;
+                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, 2 * x + (ch & 1), 2 * y + ((ch >> 1) & 1), 2 * z + ((ch >> 2) & 1));
+            }
         }
     }
-    core2[i] = result;
+    core2[i] = h[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,6 +284,12 @@ __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned 
     sel_a[i] = -1;
 }
 
+__device__ __forceinline__ size_t cl_pur_off(int l) {   // offset of level l inside the purity tables
+    size_t o = 0;
+    for (int i = 0; i < l; ++i) o += (size_t)CL_NCODES >> (3 * i);
+    return o;
+}
+
 __global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ comp,
                               int* __restrict__ cell_comp) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,6 +301,27 @@ __global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, co
     for (int j = i + 1; j < n && code_s[j] == c; ++j)
         if (comp[j] != k0) { pure = -1; break; }
     cell_comp[c] = pure;
+}
+
+// level l >= 1 from level l-1: thread per OCCUPIED level-l cell (first point of the cell)
+__global__ void k_cl_b_purity_up(int n, int l, const unsigned int* __restrict__ code_s, const int* __restrict__ cs,
+                                 int* __restrict__ cell_comp) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int key = code_s[i] >> (3 * l);
+    if (i > 0 && (code_s[i - 1] >> (3 * l)) == key) return;
+    const int* below = cell_comp + cl_pur_off(l - 1);
+    int pure = -2;
+    for (unsigned int ch = 0; ch < 8; ++ch) {
+        const unsigned int ck = key * 8 + ch;                          // child key at level l-1
+        const unsigned int c0 = ck << (3 * (l - 1));
+        if (cl_start(cs, c0) == cl_start(cs, c0 + (1u << (3 * (l - 1))))) continue;   // empty child
+        const int p = below[ck];
+        if (p < 0) { pure = -1; break; }
+        if (pure == -2) pure = p;
+        else if (pure != p) { pure = -1; break; }
+    }
+    cell_comp[cl_pur_off(l) + key] = pure;
 }
 
 __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
@@ -283,8 +336,10 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      unsigned long long* __restrict__ best_w,
                                                      unsigned long long* __restrict__ pt_w,
                                                      unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b) {
+    __shared__ unsigned int stack[CL_STACK * 256];
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
+    unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[a];
     const double qx = qf.x, qy = qf.y, qz = qf.z;
@@ -293,67 +348,60 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     const int oa = perm[a];
     int cx, cy, cz;
     cl_cell_of(g, qx, qy, qz, cx, cy, cz);
-    double bw = INFINITY;
+    double bw = INFINITY;          // best weight found by this point
+    double cbest = INFINITY;       // best weight published for the whole component (refreshed now and then)
     unsigned long long bkey = ~0ull;
     int bb = -1;
-
-    auto scan = [&](int j0, int j1) {
-        for (int j = j0; j < j1; ++j) {
-            if (comp[j] == ca) continue;
-            double d2 = cl_d2(qx, qy, qz, spts[j]);
-            if (d2 > bw) continue;
-            double w = fmax(fmax(d2, core_a), core2[j]);
-            if (w > bw) continue;
-            unsigned long long key = cl_edge_key(oa, perm[j]);
-            if (w < bw || key < bkey) { bw = w; bkey = key; bb = j; }
-        }
-    };
-
-    for (int l = 0; l <= CL_LMAX + 1; ++l) {
-        if (l > CL_LMAX) {
-            scan(0, n);
-            break;
-        }
-        const int bx = cx >> l, by = cy >> l, bz = cz >> l;
-        if (l <= 1) {
-            // level-0 granularity so that cells owned entirely by this component are skipped unread
-            const int w = 1 << l;
-            const int x0 = (bx - 1) * w, y0 = (by - 1) * w, z0 = (bz - 1) * w;
-            for (int z = z0; z < z0 + 3 * w; ++z) {
-                if (z < 0 || z >= CL_NZ) continue;
-                for (int y = y0; y < y0 + 3 * w; ++y) {
-                    if (y < 0 || y >= CL_NY) continue;
-                    for (int x = x0; x < x0 + 3 * w; ++x) {
-                        if (x < 0 || x >= CL_NX) continue;
-                        unsigned int c0 = cl_code(x, y, z);
-                        const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + 1);
-                        if (j0 == j1) continue;
-                        if (cell_comp[c0] == ca) continue;
-                        scan(j0, j1);
-                    }
+    int since_refresh = 0;
+    const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
+    const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
+    for (int rr = 0; rr < nrx * nry; ++rr) {
+        int rx = rr % nrx, ry = rr / nrx;
+        if (rr == 0) { rx = rx0; ry = ry0; }
+        else if (rx == rx0 && ry == ry0) { rx = 0; ry = 0; }
+        int sp = 0;
+        st[0] = cl_pack(CL_LMAX, rx, ry, 0);
+        sp = 1;
+        while (sp > 0) {
+            int l, x, y, z;
+            cl_unpack(st[(--sp) * 256], l, x, y, z);
+            const unsigned int c0 = cl_code(x << l, y << l, z << l);
+            const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
+            if (j0 == j1) continue;
+            // every edge into this node weighs at least lb; it must be able to tie or beat both bounds
+            const double lb = fmax(core_a, cl_box_d2(g, qx, qy, qz, l, x, y, z));
+            if (lb > bw || lb > cbest) continue;
+            if (l < CL_PUR_LEVELS && cell_comp[cl_pur_off(l) + (c0 >> (3 * l))] == ca) continue;   // all ours
+            if (l == 0 || j1 - j0 <= CL_LEAF) {
+                bool improved = false;
+                for (int j = j0; j < j1; ++j) {
+                    if (comp[j] == ca) continue;
+                    const double d2 = cl_d2(qx, qy, qz, spts[j]);
+                    if (d2 > bw) continue;
+                    const double w = fmax(fmax(d2, core_a), core2[j]);
+                    if (w > bw) continue;
+                    const unsigned long long key = cl_edge_key(oa, perm[j]);
+                    if (w < bw || key < bkey) { bw = w; bkey = key; bb = j; improved = true; }
                 }
+                if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
+                since_refresh = 64;     // force a refresh below
             }
-        } else {
-            const int nbx = CL_NX >> l, nby = CL_NY >> l, nbz = CL_NZ >> l;
-            const unsigned int span = 1u << (3 * l);
-            for (int dz = -1; dz <= 1; ++dz)
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        int x = bx + dx, y = by + dy, z = bz + dz;
-                        if (x < 0 || y < 0 || z < 0 || x >= nbx || y >= nby || z >= nbz) continue;
-                        unsigned int c0 = cl_code(x << l, y << l, z << l);
-                        scan(cl_start(cs, c0), cl_start(cs, c0 + span));
-                    }
+            if (++since_refresh >= 16) {
+                const unsigned long long cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
+                since_refresh = 0;
+            }
+            if (l == 0 || j1 - j0 <= CL_LEAF) continue;
+            const int l1 = l - 1;
+            const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
+            const int near = ox | (oy << 1) | (oz << 2);
+            for (int c = 7; c >= 0; --c) {
+                const int ch = c ^ near;
+                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, 2 * x + (ch & 1), 2 * y + ((ch >> 1) & 1), 2 * z + ((ch >> 2) & 1));
+            }
         }
-        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, l);
-        if (r2 > bw) break;                                   // nothing unseen can tie or win
-        const double lb = fmax(core_a, r2);
-        const unsigned long long cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
-        if (lb > cbest) { bb = (bw <= cbest) ? bb : -1; break; }   // this point cannot hold its component's best edge
     }
-    if (bb >= 0) {
-        atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
+    if (bb >= 0 && bw <= cbest) {
         pt_w[a] = (unsigned long long)__double_as_longlong(bw);
         pt_key[a] = bkey;
         pt_b[a] = bb;
@@ -465,7 +513,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_perm, 4 * n));
     VG_CHECK(hipMalloc(&h->d_spts, sizeof(float4) * n));
     VG_CHECK(hipMalloc(&h->d_cell_start, 4 * (size_t)(CL_NCODES + 1)));
-    VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * (size_t)CL_NCODES));
+    VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * (size_t)(CL_NCODES + (CL_NCODES >> 3) + (CL_NCODES >> 6) + (CL_NCODES >> 9))));
     VG_CHECK(hipMalloc(&h->d_core2, 8 * n));
     VG_CHECK(hipMalloc(&h->d_comp, 4 * n));
     VG_CHECK(hipMalloc(&h->d_parent, 4 * n));
@@ -486,7 +534,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_mst_idx_s, 4 * n));
     VG_CHECK(hipHostMalloc((void**)&h->h_counter, 64));
     size_t t1 = 0, t2 = 0, t3 = 0;
-    VG_CHECK(rocprim::radix_sort_pairs(nullptr, t1, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, n, 0, 21));
+    VG_CHECK(rocprim::radix_sort_pairs(nullptr, t1, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, n, 0, 24));
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t2, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, n, 0, 64));
     VG_CHECK(rocprim::inclusive_scan(nullptr, t3, h->d_cell_start, h->d_cell_start, (size_t)(CL_NCODES + 1), MinOp()));
     h->temp_bytes = std::max(t1, std::max(t2, t3)) + 256;
@@ -529,7 +577,7 @@ int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int 
     hipLaunchKernelGGL(k_cl_grid, dim3(1), dim3(64), 0, st, h->d_grid);
     hipLaunchKernelGGL(k_cl_codes, dim3(nb), dim3(256), 0, st, d_points, n, stride, h->d_grid, h->d_code, h->d_perm_in);
     size_t tb = h->temp_bytes;
-    VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, (size_t)n, 0, 21, st));
+    VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, (size_t)n, 0, 24, st));
     {
         size_t tot = (size_t)CL_NCODES + 1;
         hipLaunchKernelGGL(k_cl_fill_int, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->d_cell_start, n, tot);
@@ -551,6 +599,8 @@ int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int 
         }
         hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_e, h->d_sel_a);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp);
+        for (int l = 1; l < CL_PUR_LEVELS; ++l)
+            hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp);
         hipLaunchKernelGGL(k_cl_b_search, dim3(nb), dim3(256), 0, st, h->d_spts, n, h->d_grid, h->d_cell_start, h->d_cell_comp,
                            h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_pt_b);
         hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_best_e);
