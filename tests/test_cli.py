@@ -1,0 +1,85 @@
+"""Drop-in boundary on the GPU: the `preprocessor=` CLI, the stage dispatcher with the reference's stage names,
+stage-granular resume, the two pickle families, and the frame-sharded N=2 path (two processes on
+one GPU, gloo) producing the same pickles as N=1."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+OVR = ['dataset.SYNTHETIC.frames_per_sequence=4', 'dataset.SYNTHETIC.points_per_frame=20000',
+       'dataset.SYNTHETIC.objects_per_frame=10', 'dataset.SYNTHETIC.n_sequences=1', 'end_sequence=0',
+       'device.max_points=24000', 'paths.clip_model=/nonexistent']
+
+
+def _load(root, seq='synthetic_train_0000'):
+    stages = 'mask_ground_points_spatial_clustering_filter_detections_classification_fit_bounding_boxes_simple_evaluate_sequence'
+    with open(f'{root}/preprocessed_data/results/vilgod_mi355x/{stages}/{seq}.pkl', 'rb') as f:
+        res = pickle.load(f)
+    with open(f'{root}/preprocessed_data/results/vilgod_mi355x/{stages}/{seq}_indices.pkl', 'rb') as f:
+        idx = pickle.load(f)
+    with open(f'{root}/preprocessed_data/vilgod_mi355x_seq/{seq}.pkl', 'rb') as f:
+        state = pickle.load(f)
+    return res, idx, state
+
+
+@pytest.mark.gpu
+def test_cli_single_process_and_resume(cuda, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import preprocess_data
+    root = str(tmp_path / 'd1')
+    res = preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}'] + OVR)
+    out, idx, state = _load(root)
+    assert len(out) == 4 and idx == [0, 1, 2, 3] and len(state) == 4
+    for fr in out:
+        assert set(fr) == {'boxes_lidar', 'name', 'score', 'moving'}
+        assert fr['boxes_lidar'].shape[1] == 7 and fr['boxes_lidar'].dtype == np.float64
+        assert len(fr['name']) == len(fr['score']) == len(fr['moving']) == len(fr['boxes_lidar'])
+        assert set(fr['name']) <= {'Vehicle', 'Pedestrian', 'Cyclist'}
+    key = 'clip_a_point_representation_of_a'
+    for st in state:
+        assert set(st) >= {'_detections', '_ground_point_indices', '_gt_cluster_mapping'}
+        for d in st['_detections']:
+            assert {'cluster_id', 'valid', 'static', 'gt_assigned', 'cluster_points_index', 'tid'} <= set(d)
+            if d['valid']:
+                assert len(d['_bounding_box']) == 7 and key in d['object_class'] and len(d['object_class_predictions'][key]) == 4
+    assert sum(len(fr['name']) for fr in out) > 0
+    # second run: every stage finds its output in the sequence pickle and skips (zero_shot_detector.py resume logic)
+    os.remove(f'{root}/preprocessed_data/results/vilgod_mi355x/' + '_'.join(
+        ['mask_ground_points', 'spatial_clustering', 'filter_detections', 'classification', 'fit_bounding_boxes_simple',
+         'evaluate_sequence']) + '/synthetic_train_0000.pkl')
+    res2 = preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}', 'pipeline.6.args.force=False'] + OVR)
+    out2, _, _ = _load(root)
+    for a, b in zip(out, out2):
+        assert np.array_equal(a['name'], b['name']) and np.allclose(a['boxes_lidar'], b['boxes_lidar'])
+
+
+@pytest.mark.gpu
+def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
+    root1, root2 = str(tmp_path / 'one'), str(tmp_path / 'two')
+    cli = os.path.join(ROOT, 'tools', 'preprocess_data.py')
+    r = subprocess.run([sys.executable, cli, 'preprocessor=waymo', f'dataset.DATA_PATH={root1}'] + OVR,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29544', WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
+    procs = [subprocess.Popen([sys.executable, cli, 'preprocessor=waymo', f'dataset.DATA_PATH={root2}'] + OVR,
+                              env=dict(env, RANK=str(k), LOCAL_RANK='0'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for k in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    a, ia, sa = _load(root1)
+    b, ib, sb = _load(root2)
+    assert ia == ib and len(a) == len(b) == 4
+    for x, y in zip(a, b):
+        assert np.array_equal(x['name'], y['name'])
+        assert np.array_equal(x['boxes_lidar'], y['boxes_lidar']) and np.array_equal(x['score'], y['score'])
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x['_ground_point_indices'], y['_ground_point_indices'])
+        assert len(x['_detections']) == len(y['_detections'])
+        for d, e in zip(x['_detections'], y['_detections']):
+            assert np.array_equal(d['cluster_points_index'], e['cluster_points_index']) and d['valid'] == e['valid']

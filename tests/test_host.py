@@ -1,0 +1,101 @@
+"""Host logic that needs no GPU: config loader (Hydra syntax of the reference CLI), dataset duck-type, frame
+sharding, and the N>1 score/result gather on a world_size-2 gloo group."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from vilgod_amd import config as vconfig
+from vilgod_amd import dist as vdist
+
+CFG = os.path.join(ROOT, 'tools', 'configs')
+
+
+def test_config_defaults_and_resolvers():
+    c = vconfig.load(CFG)
+    assert c.preprocessor.name == 'waymo' and c.dataset.DATASET == 'SyntheticDataset'
+    key = [t for t in c.pipeline if t['name'] == 'classification'][0].args.key
+    assert key == 'clip_a_point_representation_of_a'                    # the resolved classification key
+    assert c.preprocessor.lidar_image_projection.maxpool.kernel_size == (1, 5, 5)
+    assert c.preprocessor.clustering.model.min_cluster_size == 15 and c.preprocessor.clustering.propability_threshold == 0.3
+    assert c.paths.pseudo_label.endswith('pseudo_labels_vilgod_waymo')
+    assert len(c.preprocessor.clip.class_list) == 24 and set(c.preprocessor.clip.class_mapping.values()) == {'Vehicle', 'Pedestrian', 'Cyclist', 'Background'}
+
+
+def test_config_cli_overrides_like_hydra():
+    c = vconfig.load(CFG, 'preprocessing', ['preprocessor=argoverse', 'start_sequence=3', 'end_sequence=7', 'split=val',
+                                            'pipeline_active=[mask_ground_points,spatial_clustering]',
+                                            'preprocessor.clustering.model.min_cluster_size=20', 'pipeline.2.args.force=True',
+                                            'paths.clip_model=/models', 'device.vit_dtype=f32'])
+    assert c.preprocessor.name == 'argo2' and c.dataset.SYNTHETIC.points_per_frame == 200000
+    assert (c.start_sequence, c.end_sequence, c.split) == (3, 7, 'val')
+    assert c.pipeline_active == ['mask_ground_points', 'spatial_clustering']
+    assert c.preprocessor.clustering.model.min_cluster_size == 20 and c.pipeline[2].args.force is True
+    assert c.paths.clip_model == '/models' and c.device.vit_dtype == 'f32'
+
+
+def test_dataset_duck_type():
+    c = vconfig.load(CFG, overrides=['dataset.SYNTHETIC.frames_per_sequence=3', 'dataset.SYNTHETIC.points_per_frame=5000',
+                                     'dataset.SYNTHETIC.objects_per_frame=4', 'end_sequence=1'])
+    ds = vconfig.instantiate(c.dataset_class, logger=None, training=True, start_sequence=c.start_sequence, end_sequence=c.end_sequence)
+    names = list(ds.next_sequence())
+    assert len(names) == 2 and ds.sequence_length == 3 and len(ds.sequence_indices) == 3
+    pts = ds.get_lidar_points(1)
+    assert pts.shape == (5000, 5) and pts.dtype == np.float32
+    assert np.array_equal(pts, ds.get_lidar_points(1))                  # deterministic
+    assert ds.sequence_infos[2]['pose'].shape == (4, 4) and set(ds.get_annos(0)) >= {'gt_names', 'moving'}
+    assert ds.class_names == ['Vehicle', 'Pedestrian', 'Cyclist']
+
+
+def test_shard_frames_partition():
+    for n in [0, 1, 7, 199]:
+        for w in [1, 2, 3, 8]:
+            parts = [vdist.shard_frames(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+            assert all(p == list(range(p[0], p[0] + len(p))) for p in parts if p)
+
+
+WORKER = textwrap.dedent('''
+    import os, sys, torch, numpy as np
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from vilgod_amd import dist as vdist
+    rank, ws = vdist.init_from_env('gloo')
+    assert ws == 2
+    frames = vdist.shard_frames(5, rank, ws)
+    g = torch.Generator().manual_seed(100)
+    allm = {f: torch.rand((3 + f, 24), generator=g) for f in range(5)}       # same on both ranks
+    local = {f: allm[f] for f in frames}
+    got = vdist.gather_scores(local, 24, torch.device('cpu'))
+    assert sorted(got) == list(range(5))
+    for f in range(5):
+        assert torch.equal(got[f], allm[f]), f
+    objs = vdist.gather_objects({f: {'name': np.array(['Vehicle'] * f)} for f in frames})
+    merged = {}
+    for o in objs:
+        merged.update(o)
+    assert sorted(merged) == list(range(5)) and len(merged[4]['name']) == 4
+    # empty shard on one rank
+    got = vdist.gather_scores(local if rank == 0 else {}, 24, torch.device('cpu'))
+    assert sorted(got) == vdist.shard_frames(5, 0, 2)
+    dist.barrier()
+    print('rank', rank, 'ok')
+''')
+
+
+def test_two_rank_gather_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2', OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f'rank {r} ok' in o

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Pseudo-label generation entry point (MI355X build) -- same command line as the reference's
+tools/preprocess_data.py (README.md:128-144):
+
+    cd tools && python preprocess_data.py preprocessor=waymo [key=value ...]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 preprocess_data.py preprocessor=waymo
+
+Per sequence it writes the reference's two pickle families:
+    <paths.sequence_data>/<seq>.pkl                                   list of per-frame state dicts
+    <paths.results>/<results_folder>/<'_'.join(pipeline_active)>/<seq>.pkl  and  <seq>_indices.pkl
+With several processes the frames of each sequence are sharded over the GPUs (vilgod_amd/dist.py); rank 0 writes.
+"""
+import gc
+import logging
+import os
+import pickle
+import random
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from vilgod_amd import config as vconfig          # noqa: E402
+from vilgod_amd import dist as vdist              # noqa: E402
+
+
+def set_random_seed(seed):
+    """src/utils/common_utils.py:13-19."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    logging.basicConfig(level=logging.INFO, format='[%(asctime)s][%(levelname)s] - %(message)s', stream=sys.stdout)
+    logger = logging.getLogger('preprocess_data')
+    cfg = vconfig.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs'), 'preprocessing', argv)
+    logger.info('Working directory: {}'.format(os.getcwd()))
+    if cfg.get('random_seed', False):
+        set_random_seed(cfg.random_seed)
+
+    rank, world = vdist.init_from_env(os.environ.get('VILGOD_DIST_BACKEND'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+
+    dataset = vconfig.instantiate(cfg.dataset_class, logger=logger, training=True,
+                                  start_sequence=cfg.start_sequence, end_sequence=cfg.end_sequence)
+    if cfg.split != 'train':
+        dataset.set_split(cfg.split)
+    dataset.training = False
+
+    from vilgod_amd.zero_shot_detector import ZeroShotDetector
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    dev = cfg.get('device', {})
+    ga = [t for t in cfg.pipeline if t['name'] == 'mask_ground_points'][0]['args']
+    # the cluster model, the projection and the CLIP tower are built once and shared by all sequences
+    # (tools/preprocess_data.py:42-48 of the reference builds cluster_model and clip_model the same way)
+    pipeline = PseudoLabelPipeline(cfg.preprocessor, device=f'cuda:{torch.cuda.current_device()}',
+                                   vit_dtype=dev.get('vit_dtype', 'f16'), n_views=dev.get('n_views', 4),
+                                   max_points=dev.get('max_points', 300_000), clip_model_path=cfg.paths.clip_model,
+                                   min_range=ga['min_range'], z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666))
+    logger.info(f'CLIP weights: {pipeline.clip.weights_source}')
+
+    result_path = Path(cfg.paths.results) / cfg.results_folder / '_'.join(cfg.pipeline_active)
+    if rank == 0:
+        result_path.mkdir(parents=True, exist_ok=True)
+    logger.info('_' * 40)
+    logger.info('Pipeline:')
+    for i, name in enumerate([t['name'] for t in cfg.pipeline if t['name'] in cfg.pipeline_active], 1):
+        logger.info(f'[{i}] {name}')
+    logger.info('_' * 40)
+
+    indices, detection_results = [], []
+    for sequence_name in dataset.next_sequence():
+        result_file = result_path / f'{sequence_name}.pkl'
+        indices_file = result_path / f'{sequence_name}_indices.pkl'
+        if cfg.use_cached_results and 'evaluate_sequence' in cfg.pipeline_active and result_file.exists():
+            with result_file.open('rb') as f:
+                detection_results.extend(pickle.load(f))
+            with indices_file.open('rb') as f:
+                indices.extend(pickle.load(f))
+            continue
+        zsd = ZeroShotDetector(dataset, sequence_name, cfg=cfg, logger=logger, pipeline=pipeline)
+        zsd.process()
+        detection_results.extend(zsd.detection_3d_result_list)
+        indices.extend(dataset.sequence_indices)
+        if 'evaluate_sequence' in cfg.pipeline_active and rank == 0:
+            with open(result_file, 'wb') as f:
+                pickle.dump(zsd.detection_3d_result_list, f)
+            with open(indices_file, 'wb') as f:
+                pickle.dump(dataset.sequence_indices, f)
+        del zsd
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    if len(detection_results) > 0 and rank == 0:
+        logger.info('_' * 100)
+        summary = dataset.evaluation(detection_results, class_names=dataset.class_names, indices=indices)
+        logger.info(f'Summary over all sequences: {summary}')
+        logger.info('_' * 100)
+    return detection_results
+
+
+if __name__ == '__main__':
+    main()

@@ -155,6 +155,7 @@ class FrameState:
         self.valid = np.array([bool(d.get('valid', True)) for d in dets])
         self.static = np.array([bool(d.get('static', True)) for d in dets])
         self.tid = np.array([int(d.get('tid', -1)) for d in dets], dtype=np.int64)
+        self.filtered = bool((~self.valid).any())      # zero_shot_detector.py:265-274: any invalid detection = already filtered
         if any('_bounding_box' in d for d in dets):
             self.boxes = np.full((C, 7), np.nan)
             for c, d in enumerate(dets):
