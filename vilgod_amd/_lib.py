@@ -8,6 +8,10 @@ import ctypes
 import os
 import re
 
+# torch ships its own libamdhip64; it must be in the process BEFORE our library is loaded so that both resolve to
+# ONE HIP runtime (otherwise our hipMalloc lands in a second, uninitialised runtime: "no ROCm-capable device").
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'vilgod_hip.h')
 LIB_PATH = os.path.join(HERE, 'libvilgod_hip.so')
