@@ -85,11 +85,15 @@ int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_
 
 /* One projection GEMM of the tower, C = X @ Wt^T with the fused epilogue the block uses
  * (model.py:175-191: in_proj, out_proj + residual, c_fc + QuickGELU, c_proj + residual), exposed so the
- * GEMM can be unit-tested and timed alone.  dtype 1: f16 operands (M%128, N%128, K%64 == 0); 0: f32
+ * GEMM can be unit-tested and timed alone.  dtype 1: f16 operands (M%256, N%128, K%64 == 0); 0: f32
  * (M%64, N%64, K%16).  epi 0: +bias -> C   1: +bias, QuickGELU -> C   2: d_resid(f32) += X@Wt^T + bias
  * 3: C float32, no bias (patch embedding, model.py:224). */
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream);
+
+/* development aid: ablation variants of the f16 GEMM kernel (1 no in-loop DMA, 2 DMA only, 3 no epilogue) */
+int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
+                    void* stream);
 
 /* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
  * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */

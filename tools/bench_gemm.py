@@ -6,7 +6,7 @@ from vilgod_amd._lib import lib, ptr, stream_ptr, check
 
 def main():
     dev = torch.device('cuda:0')
-    M = (240 * 197 + 127) // 128 * 128
+    M = (240 * 197 + 255) // 256 * 256
     shapes = [('qkv', 0, 2304, 768), ('out_proj', 2, 768, 768), ('c_fc', 1, 3072, 768), ('c_proj', 2, 768, 3072)]
     tot_t = tot_f = 0
     for name, epi, N, K in shapes:

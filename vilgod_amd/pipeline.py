@@ -91,6 +91,51 @@ class PseudoLabelPipeline:
         self.plane_seed = int(plane_seed)
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         self.timings = {}
+        self._clip_cfg, self._clip_model_path, self._mcfg, self._n_views = clip_cfg, clip_model_path, mcfg, n_views
+        self._workers = None
+
+    # ---- several frames in flight ------------------------------------------------------------------------------
+    def _clone_for_worker(self):
+        """A shallow copy that shares configuration and constants but owns its stream-bound handles (cluster buffers,
+        ViT workspace + weights, RANSAC scratch): handles are not thread-safe, like the reference objects."""
+        import copy
+        w = copy.copy(self)
+        w.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **self._mcfg)
+        w.projection = RealisticProjection(_get(self.cfg, 'lidar_image_projection'), device=self.device,
+                                           views=VIEWS_4 if self._n_views == 4 else VIEWS_6)
+        w.clip = ClipWrapper(self._clip_cfg, self._clip_model_path, device=self.device, dtype=self.vit_dtype)
+        w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
+        w.timings = {}
+        w.stream = torch.cuda.Stream(device=self.device)
+        return w
+
+    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0):
+        """Throughput mode: frames (list of CUDA/numpy point arrays) are processed with `n_workers` frames in flight,
+        each on its own HIP stream with its own handles.  Ground segmentation is stateful across frames and runs in
+        frame order on the caller's stream; everything else of a frame runs on a worker stream after an event wait.
+        Returns [(FrameState, result dict, probs tensor)] in frame order."""
+        from concurrent.futures import ThreadPoolExecutor
+        if self._workers is None or len(self._workers) < n_workers:
+            self._workers = [self._clone_for_worker() for _ in range(n_workers)]
+            self._pool = ThreadPoolExecutor(max_workers=n_workers)
+        main = torch.cuda.current_stream(self.device)
+
+        def run(worker, i, d_pts, mask, ev):
+            with torch.cuda.stream(worker.stream):
+                worker.stream.wait_event(ev)
+                fs, res = worker.process_frame(d_pts, poses[i], ref_pose, fnr=first_fnr + i, mask=mask)
+                probs = getattr(worker, 'last_probs', None)
+                worker.stream.synchronize()
+            return fs, res, probs
+
+        futures = []
+        for i, pts in enumerate(frames):
+            d_pts = self.upload(pts)
+            mask = self.ground(d_pts)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            futures.append(self._pool.submit(run, self._workers[i % n_workers], i, d_pts, mask, ev))
+        return [f.result() for f in futures]
 
     @staticmethod
     def _parse_filters(ccfg):
@@ -216,7 +261,7 @@ class PseudoLabelPipeline:
         return out
 
     # ---------------------------------------------------------------------------------------------
-    def process_frame(self, points, pose, ref_pose, fnr=0, state=None, timing=False):
+    def process_frame(self, points, pose, ref_pose, fnr=0, state=None, timing=False, mask=None):
         """One frame through [A]-[F].  points: (N,>=4) float32 numpy/CUDA [x,y,z,intensity,...].
         Returns (FrameState, result dict {'boxes_lidar','name','score','moving'})."""
         t = {}
@@ -231,7 +276,8 @@ class PseudoLabelPipeline:
         fs = state if state is not None else FrameState(fnr, pose, ref_pose)
         d_pts = self.upload(points)
         fs.n_points = d_pts.shape[0]
-        mask = self.ground(d_pts)
+        if mask is None:
+            mask = self.ground(d_pts)
         t0 = tick('ground', t0)
         d_ref = self.to_ref(d_pts, fs.transform_to_ref)
         ng = torch.nonzero(mask == 0).squeeze(1)
