@@ -24,6 +24,7 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <map>
@@ -77,12 +78,16 @@ typedef const __attribute__((address_space(1))) void glb_void;
 template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_f16(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                      const float* __restrict__ bias, void* __restrict__ Cout,
-                                                     float* __restrict__ resid, int M, int N, int K, int ldc) {
+                                                     float* __restrict__ resid, int M, int N, int K, int ldc, int cw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntn = N / GBN;
+    // tile order: column CHUNKS of cw tiles (<= ~2.4 MB of weights, so the chunk stays in one XCD's 4 MB L2 next to the
+    // streaming activations), inside a chunk row-tile major; each XCD walks a contiguous run of this order.
+    const int ntm = M / GBM;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = t / ntn, tn = t - tm * ntn;
+    const int per_chunk = ntm * cw;
+    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
     const int m0 = tm * GBM, n0 = tn * GBN;
     const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, 64x64 each
 
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ p
 }
 
 // LayerNorm (fp32 statistics, model.py:157-163): x f32 [rows,W] -> h (f16 or f32). one wave per row.
+// W % 256 == 0 takes the vectorised path: float4 loads (1 KB per wave instruction), packed stores.
 template <typename TO>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ lw,
                                                    const float* __restrict__ lb, TO* __restrict__ h, int n_rows, int W,
@@ -309,6 +315,42 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n_rows) return;
     const float* src = x + (size_t)row * row_stride_in * W;
+    if ((W & 255) == 0 && W <= 1024) {
+        const int nv = W >> 8;                       // float4 per lane
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nv) {
+                v[i] = *(const float4*)(src + (i * 64 + lane) * 4);
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        const float mean = vg_wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nv) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        const float rstd = rsqrtf(vg_wave_sum(q) / (float)W + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 w4 = *(const float4*)(lw + c), b4 = *(const float4*)(lb + c);
+                const float o0 = (v[i].x - mean) * rstd * w4.x + b4.x, o1 = (v[i].y - mean) * rstd * w4.y + b4.y;
+                const float o2 = (v[i].z - mean) * rstd * w4.z + b4.z, o3 = (v[i].w - mean) * rstd * w4.w + b4.w;
+                TO* dst = h + (size_t)row * W + c;
+                if (sizeof(TO) == 2) {
+                    f16x4 h4 = {(f16)o0, (f16)o1, (f16)o2, (f16)o3};
+                    *(f16x4*)dst = h4;
+                } else {
+                    *(float4*)dst = make_float4(o0, o1, o2, o3);
+                }
+            }
+        return;
+    }
     float v[16];
     const int per = W / 64;
     float s = 0.f;
@@ -348,6 +390,16 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     const f16* kbase = qbase + W;
     const f16* vbase = qbase + 2 * W;
 
+    // this lane's Q fragments first: their latency hides behind the K/V staging below
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int q0 = wave * 32;
+    const int q = q0 + r31;
+    f16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        qf[s] = (q < T) ? *(const f16x8*)(qbase + (size_t)q * ld + s * 16 + hh * 8) : z;
+    }
     // K -> LDS rows (zero beyond T)
     for (int c = tid; c < AT_MAXT * 8; c += 448) {
         int key = c >> 3, part = c & 7;
@@ -364,18 +416,9 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
     }
     __syncthreads();
-    const int q0 = wave * 32;
     if (q0 >= T) return;
-    const int r31 = lane & 31, hh = lane >> 5;
-    const int q = q0 + r31;
     const int nkb = (T + 31) / 32;
 
-    f16x8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        qf[s] = (q < T) ? *(const f16x8*)(qbase + (size_t)q * ld + s * 16 + hh * 8) : z;
-    }
     f32x16 sacc[7];
 #pragma unroll
     for (int kb = 0; kb < 7; ++kb) {
@@ -591,6 +634,19 @@ static bool is_gemm_weight(const std::string& n) {
            n.find("c_proj.weight") != std::string::npos;
 }
 
+// column tiles per L2 chunk: the largest divisor-friendly count whose weight rows (128*K fp16 each) fit ~2.4 MB
+static int gemm_chunk_tiles(int N, int K) {
+    const int ntn = N / GBN;
+    if (getenv("VG_GEMM_NO_CHUNK")) return ntn;
+    const long tile_bytes = (long)GBN * K * 2;
+    int cw_max = (int)(2400000L / tile_bytes);
+    if (cw_max < 1) cw_max = 1;
+    if (cw_max >= ntn) return ntn;
+    int nchunks = (ntn + cw_max - 1) / cw_max;
+    while (ntn % nchunks) ++nchunks;
+    return ntn / nchunks;
+}
+
 template <int EPI>
 static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
                        int N, int K, hipStream_t st, int ldc = 0) {
@@ -611,7 +667,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
             attr_set = true;
         }
         hipLaunchKernelGGL((k_gemm_f16<EPI>), dim3(nwg), dim3(512), G_LDS_BYTES, st, (const f16*)X, (const f16*)Wt, bias, C,
-                           resid, M, N, K, ldc);
+                           resid, M, N, K, ldc, gemm_chunk_tiles(N, K));
     } else {
         if (M % 64 || N % 64 || K % 16) return VG_ERR_ARG;
         int nwg = (M / 64) * (N / 64);
@@ -795,7 +851,7 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
     case V:                                                                                                                \
         (void)hipFuncSetAttribute((const void*)k_gemm_f16<EPI_BIAS, V>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); \
         hipLaunchKernelGGL((k_gemm_f16<EPI_BIAS, V>), dim3(nwg), dim3(512), G_LDS_BYTES, st, (const f16*)d_X, (const f16*)d_Wt, \
-                           d_bias, d_C, nullptr, M, N, K, ldc);                                                           \
+                           d_bias, d_C, nullptr, M, N, K, ldc, gemm_chunk_tiles(N, K));                                   \
         break;
     switch (var) { VG_VAR(0) VG_VAR(1) VG_VAR(2) VG_VAR(3) default: return VG_ERR_ARG; }
 #undef VG_VAR
