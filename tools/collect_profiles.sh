@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace summary + separate PMC passes for the dominant kernel
+# (ViT projection GEMM) on the SAME command the bench uses, sequential mode (1 frame in flight) so that kernel
+# durations are not inflated by other streams.  PMC passes are separate from --stats as the guide prescribes
+# (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: one pass each).
+# usage: tools/collect_profiles.sh <tag>     -> gpurun_out/prof_<tag>/{trace,fetch,write}
+set -u
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+BENCH="$GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline --no-roofline-pass"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $BENCH > $OUT.trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python3 $BENCH > $OUT.fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python3 $BENCH > $OUT.write.log 2>&1
+ls $OUT/*

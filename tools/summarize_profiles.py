@@ -1,0 +1,45 @@
+"""Post-process gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_*.{csv,json}.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+FETCH_SIZE under-reports wide coalesced streaming reads by 2x on gfx950 (TCC_EA0_RDREQ x 64 B with 128-B requests
+tallied at 64 B); we report both the raw and the corrected (x2) figure, WRITE_SIZE is exact for 16-B/lane stores."""
+import csv, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, 'gpurun_out', f'prof_{tag}')
+dst = os.path.join(root, 'profiles')
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
+def per_kernel(path, counter):
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name']
+        a = acc.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r['Counter_Value'])
+    return acc
+fetch = per_kernel(os.path.join(src, 'fetch', 'bench_counter_collection.csv'), 'FETCH_SIZE')
+write = per_kernel(os.path.join(src, 'write', 'bench_counter_collection.csv'), 'WRITE_SIZE')
+stats = {r['Name']: r for r in csv.DictReader(open(os.path.join(src, 'trace', 'bench_kernel_stats.csv')))}
+out = {'tag': tag, 'command': 'bench.py --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline --no-roofline-pass', 'kernels': {}}
+g = {'launches': 0, 'fetch_kb': 0.0, 'write_kb': 0.0, 'dur_ns': 0.0, 'calls_trace': 0}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
+    st = stats.get(k)
+    out['kernels'][k[:80]] = {'launches': f[0], 'fetch_kb_per_launch_raw': f[1] / max(f[0], 1), 'write_kb_per_launch': w[1] / max(w[0], 1),
+                              'avg_ns': float(st['AverageNs']) if st else None}
+    if 'k_gemm_f16' in k:
+        g['launches'] += f[0]; g['fetch_kb'] += f[1]; g['write_kb'] += w[1]
+        if st:
+            g['dur_ns'] += float(st['TotalDurationNs']); g['calls_trace'] += int(st['Calls'])
+n = max(g['launches'], 1)
+out['k_gemm_f16'] = {
+    'launches_pmc': g['launches'], 'avg_launch_us_trace': g['dur_ns'] / max(g['calls_trace'], 1) / 1e3,
+    'fetch_bytes_per_launch_raw': 1024 * g['fetch_kb'] / n, 'fetch_bytes_per_launch_corrected_x2': 2048 * g['fetch_kb'] / n,
+    'write_bytes_per_launch': 1024 * g['write_kb'] / n,
+    'hbm_bytes_per_launch': (2048 * g['fetch_kb'] + 1024 * g['write_kb']) / n,
+}
+json.dump(out, open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
+json.dump(out['k_gemm_f16'], open(os.path.join(dst, 'gemm_traffic.json'), 'w'), indent=1)
+print(json.dumps(out['k_gemm_f16'], indent=1))
