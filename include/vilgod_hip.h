@@ -51,7 +51,9 @@ int vg_to_origin(const float* d_ego, const int32_t* d_point_cluster, int n, cons
  * d_view_rot: [n_views,9] f32 (points @ rot).  d_lut: [3*256+3] f32 = CLIP-normalised value of
  * every uint8 level per channel, then the 3 distinct taps (corner, edge, centre) of the 3x3 Gaussian.
  * out_kind 0: uint8 [n,224,224,3] (the arrays given to PIL)   1: f32 [n,3,224,224]   2: f16 same
- *          3: f32 [n,110,110], one channel of get_img()'s output before the resize (parity tests). */
+ *          3: f32 [n,110,110], one channel of get_img()'s output before the resize (parity tests)
+ *          4: f16 [n*196,768] patch rows (= im2col of kind 2 for 16x16 patches), the A operand of the ViT-B/16
+ *             patch-embedding GEMM; vg_vit_encode input_kind 2 consumes it directly. */
 int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clusters, const float* d_view_rot,
                     int n_views, const float* d_lut, void* d_out, int out_kind, void* stream);
 
@@ -74,7 +76,8 @@ int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t 
 /* bytes of device workspace for n_crops; the caller zero-fills it once. */
 int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops);
 /* d_crops: [n,3,res,res] CHW, input_kind 0 = float32, 1 = float16 (what vg_render_crops out_kind 1/2
- * writes).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
+ * writes); input_kind 2 = f16 patch rows [n*(res/patch)^2, 3*patch^2] (vg_render_crops out_kind 4, fp16 mode only;
+ * row count must be padded by the caller to a multiple of 256 rows of readable memory).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
 int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                   void* stream);
 /* Measurement hooks (bench.py `roofline`): HIP event pairs around every projection-GEMM launch of

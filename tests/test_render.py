@@ -195,3 +195,24 @@ def test_hip_gather_ego_transform(cuda):
     check(lib.vg_gather_ego(ptr(d_pts), 5, ptr(d_idx), 3000, ptr(d_T), ptr(ego), stream_ptr()))
     got = ego.cpu().numpy()
     assert (got != want).sum() <= 2 and np.allclose(got, want, atol=4e-6, rtol=0)
+
+
+@pytest.mark.gpu
+def test_hip_patch16_output_equals_im2col_of_f16_crops(cuda, golden):
+    """out='patch16' (rows fed straight to the patch-embedding GEMM) == im2col of the CHW fp16 crops, and the ViT
+    features from both input forms are identical."""
+    from vilgod_amd.projection import RealisticProjection
+    from vilgod_amd.clip_wrapper import VitEncoder
+    from vilgod_amd import clip_weights as cw
+    g = golden
+    clusters = [g[f'pts_{i}'] for i in range(n_cases(g))]
+    pts, seg = _pack(clusters, cuda)
+    proj = RealisticProjection({}, device=cuda)
+    crops = proj.render_frame(pts, None, seg, np.eye(4), out='f16')
+    patches = proj.render_frame(pts, None, seg, np.eye(4), out='patch16')
+    n = crops.shape[0]
+    want = crops.reshape(n, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(n * 196, 768)
+    assert patches.shape[0] % 256 == 0 and torch.equal(patches[:n * 196], want)
+    assert not patches[n * 196:].any()
+    enc = VitEncoder(cw.synthetic_vit_weights(0, **cw.VIT_B16), dtype='f16', device=cuda)
+    assert torch.equal(enc.encode(crops), enc.encode_patches(patches, n))

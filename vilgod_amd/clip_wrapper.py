@@ -64,7 +64,8 @@ class VitEncoder:
         return n.value, ms.value, fl.value
 
     def encode(self, crops, stream=None):
-        """crops: [n,3,res,res] float32 or float16 CUDA tensor -> [n,output_dim] float32 features."""
+        """crops: [n,3,res,res] float32 or float16 CUDA tensor, or patch rows (see `encode_patches`)
+        -> [n,output_dim] float32 features."""
         assert crops.is_cuda and crops.is_contiguous()
         n = crops.shape[0]
         feat = torch.empty((n, self.cfg['output_dim']), dtype=torch.float32, device=crops.device)
@@ -74,6 +75,19 @@ class VitEncoder:
         ws = self._workspace(n)
         check(lib.vg_vit_encode(self._h, ptr(crops), kind, n, ptr(ws), ptr(feat), stream_ptr(stream)), 'vg_vit_encode')
         return feat
+
+
+def _encode_patches(self, patches, n, stream=None):
+    """patches: f16 [rows>=n*196 (multiple of 256), 768] from RealisticProjection.render_frame(out='patch16')."""
+    assert patches.is_cuda and patches.dtype == torch.float16 and self.dtype == 'f16'
+    feat = torch.empty((n, self.cfg['output_dim']), dtype=torch.float32, device=patches.device)
+    if n:
+        ws = self._workspace(n)
+        check(lib.vg_vit_encode(self._h, ptr(patches), 2, n, ptr(ws), ptr(feat), stream_ptr(stream)), 'vg_vit_encode')
+    return feat
+
+
+VitEncoder.encode_patches = _encode_patches
 
 
 def clip_scores(feat, text_features, stream=None):

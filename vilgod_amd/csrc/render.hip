@@ -154,6 +154,8 @@ struct RenderArgs {
     int n_views;
     int out_kind;          // 0: uint8 [n,224,224,3] (PIL layout)  1: f32 [n,3,224,224]  2: f16 [n,3,224,224]
                            // 3: f32 [n,110,110] = one channel of get_img() before the resize
+                           // 4: f16 patch rows [n*196, 768] = the im2col of kind 2 for 16x16 patches (ViT-B/16 input of
+                           //    the patch-embedding GEMM: row = crop*196 + py*14 + px, column = ch*256 + i*16 + j)
 };
 
 __device__ __forceinline__ void quantise_point(float px, float py, float pz, const float* pc, float prange,
@@ -409,6 +411,19 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
                                         a.lut[ch * 256 + u[3]]);
                 *(float4*)(of + (size_t)ch * OUT * OUT) = f4;
             }
+        } else if (a.out_kind == 4) {
+            // 4 consecutive j stay inside one 16-wide patch row (j0 % 4 == 0): one 8-byte store per channel
+            const int py = i >> 4, pi = i & 15, px = j0 >> 4, pj = j0 & 15;
+            __half* oh = (__half*)a.out + ((crop * 196 + (size_t)(py * 14 + px)) * 768 + pi * 16 + pj);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                __half2 h01 = __floats2half2_rn(a.lut[ch * 256 + u[0]], a.lut[ch * 256 + u[1]]);
+                __half2 h23 = __floats2half2_rn(a.lut[ch * 256 + u[2]], a.lut[ch * 256 + u[3]]);
+                uint2 pk;
+                pk.x = *(unsigned int*)&h01;
+                pk.y = *(unsigned int*)&h23;
+                *(uint2*)(oh + ch * 256) = pk;
+            }
         } else {
             __half* oh = (__half*)a.out + crop * 3 * OUT * OUT + (size_t)i * OUT + j0;
 #pragma unroll
@@ -460,7 +475,7 @@ int vg_to_origin(const float* d_ego, const int32_t* d_point_cluster, int n, cons
 int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clusters, const float* d_view_rot,
                     int n_views, const float* d_lut, void* d_out, int out_kind, void* stream) {
     if (n_clusters <= 0 || n_views <= 0) return VG_OK;
-    if (!d_origin || !d_seg_off || !d_view_rot || !d_lut || !d_out || out_kind < 0 || out_kind > 3)
+    if (!d_origin || !d_seg_off || !d_view_rot || !d_lut || !d_out || out_kind < 0 || out_kind > 4)
         return VG_ERR_ARG;
     static bool attr_set = false;
     const size_t lds_bytes = (size_t)(GR * GR + GR * GO) * sizeof(float);

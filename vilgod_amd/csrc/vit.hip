@@ -743,7 +743,8 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops) {
 /* input_kind 0: f32 CHW crops [n,3,res,res]; 1: f16 CHW crops; d_feat: [n,out_dim] f32 */
 int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                   void* stream) {
-    if (!v || !d_crops || !d_workspace || !d_feat || n_crops <= 0 || input_kind < 0 || input_kind > 1) return VG_ERR_ARG;
+    if (!v || !d_crops || !d_workspace || !d_feat || n_crops <= 0 || input_kind < 0 || input_kind > 2) return VG_ERR_ARG;
+    if (input_kind == 2 && v->dtype != 1) return VG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int W = v->width, T = v->T, L = v->layers, H = v->heads;
     const int64_t M = (int64_t)n_crops * T, Mp = pad128(M), es = v->dtype == 1 ? 2 : 4;
@@ -768,8 +769,9 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             fprintf(stderr, "[vilgod_hip] vg_vit_encode: weight %s not set\n", n);
             return VG_ERR_ARG;
         }
-    // im2col
-    {
+    // im2col (skipped when the renderer already wrote patch rows)
+    if (input_kind == 2) patches = const_cast<void*>(d_crops);
+    else {
         int blocks = (int)((P * Kp + 255) / 256);
         if (blocks > 65535 * 8) blocks = 65535 * 8;
         if (v->dtype == 1) {

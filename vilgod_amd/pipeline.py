@@ -235,8 +235,14 @@ class PseudoLabelPipeline:
 
     # [D1]-[D9]
     def classify(self, d_X, d_index, d_seg, transform_to_ego):
-        out = 'f16' if self.vit_dtype == 'f16' else 'f32'
-        crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out=out)
+        n = (d_seg.numel() - 1) * self.projection.num_views
+        enc = self.clip.encoder
+        if self.vit_dtype == 'f16' and enc.cfg['patch'] == 16 and enc.cfg['resolution'] == 224:
+            # the renderer writes the patch-embedding GEMM's A operand directly (no CHW crops, no im2col pass)
+            patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16')
+            from .clip_wrapper import clip_scores
+            return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
+        crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='f16' if self.vit_dtype == 'f16' else 'f32')
         return self.clip.predict_probs(crops)
 
     # [E1]

@@ -16,7 +16,7 @@ from ._lib import lib, ptr, stream_ptr, check
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # third_party/CLIP/clip/clip.py:85
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
-OUT_U8, OUT_F32, OUT_F16, OUT_RAW110 = 0, 1, 2, 3
+OUT_U8, OUT_F32, OUT_F16, OUT_RAW110, OUT_PATCH16 = 0, 1, 2, 3, 4
 
 # the 4 views hard-coded at mv_utils.py:134-141 plus the two commented-out ones (:139-140) that
 # make up the 2x3 grid of waymo.yaml:97-102 (BASELINE config "6-view render")
@@ -80,7 +80,7 @@ class RealisticProjection:
         index: [Ptot] int32 packed cluster point indices (cluster after cluster) or None;
         seg_off: [C+1] int32 CUDA; transform_to_ego: 4x4 float64 (numpy or tensor).
         Returns crops for all C*V (cluster-major, like torch.cat of get_img results)."""
-        kind = {'u8': OUT_U8, 'f32': OUT_F32, 'f16': OUT_F16, 'raw110': OUT_RAW110}[out]
+        kind = {'u8': OUT_U8, 'f32': OUT_F32, 'f16': OUT_F16, 'raw110': OUT_RAW110, 'patch16': OUT_PATCH16}[out]
         dev = points.device
         n_clusters = seg_off.numel() - 1
         ptot = int(index.numel()) if index is not None else int(points.shape[0])
@@ -92,6 +92,10 @@ class RealisticProjection:
             result = torch.empty((n, 3, 224, 224), dtype=torch.float32, device=dev)
         elif kind == OUT_F16:
             result = torch.empty((n, 3, 224, 224), dtype=torch.float16, device=dev)
+        elif kind == OUT_PATCH16:
+            # ViT-B/16 patch rows; rows padded to the GEMM's 256-row tile (padding rows are never written: zeros)
+            rows = (n * 196 + 255) // 256 * 256
+            result = torch.zeros((rows, 768), dtype=torch.float16, device=dev)
         else:
             result = torch.empty((n, 110, 110), dtype=torch.float32, device=dev)
         if n_clusters == 0 or ptot == 0:
