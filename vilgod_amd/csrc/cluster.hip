@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
         while (sp > 0) {
             int l, x, y, z;
             cl_unpack(st[(--sp) * 256], l, x, y, z);
+            if (cl_box_d2(g, qx, qy, qz, l, x, y, z) >= h[k]) continue;     // cannot lower the k-th distance (ALU only)
             const unsigned int c0 = cl_code(x << l, y << l, z << l);
             const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
             if (j0 == j1) continue;
-            if (cl_box_d2(g, qx, qy, qz, l, x, y, z) >= h[k]) continue;     // cannot lower the k-th distance
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 for (int j = j0; j < j1; ++j) {
                     double d2 = cl_d2(qx, qy, qz, spts[j]);
@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             const int near = ox | (oy << 1) | (oz << 2);
             for (int c = 7; c >= 0; --c) {
                 const int ch = c ^ near;
-                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, 2 * x + (ch & 1), 2 * y + ((ch >> 1) & 1), 2 * z + ((ch >> 2) & 1));
+                const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
+                if (cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz) >= h[k]) continue;
+                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, nx, ny, nz);
             }
         }
     }
@@ -365,12 +367,12 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
         while (sp > 0) {
             int l, x, y, z;
             cl_unpack(st[(--sp) * 256], l, x, y, z);
+            // every edge into this node weighs at least lb; it must be able to tie or beat both bounds (ALU only)
+            const double lb = fmax(core_a, cl_box_d2(g, qx, qy, qz, l, x, y, z));
+            if (lb > bw || lb > cbest) continue;
             const unsigned int c0 = cl_code(x << l, y << l, z << l);
             const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
             if (j0 == j1) continue;
-            // every edge into this node weighs at least lb; it must be able to tie or beat both bounds
-            const double lb = fmax(core_a, cl_box_d2(g, qx, qy, qz, l, x, y, z));
-            if (lb > bw || lb > cbest) continue;
             if (l < CL_PUR_LEVELS && cell_comp[cl_pur_off(l) + (c0 >> (3 * l))] == ca) continue;   // all ours
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 bool improved = false;
@@ -397,7 +399,10 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             const int near = ox | (oy << 1) | (oz << 2);
             for (int c = 7; c >= 0; --c) {
                 const int ch = c ^ near;
-                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, 2 * x + (ch & 1), 2 * y + ((ch >> 1) & 1), 2 * z + ((ch >> 2) & 1));
+                const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
+                const double clb = fmax(core_a, cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz));
+                if (clb > bw || clb > cbest) continue;
+                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, nx, ny, nz);
             }
         }
     }
