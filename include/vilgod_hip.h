@@ -85,6 +85,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
  * vg_vit_profile_read synchronises and returns launches, summed ms and algorithmic FLOPs (2*M*N*K each). */
 int vg_vit_profile(vg_vit* v, int on);
 int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_flops);
+/* the same, restricted to one kernel: kind 0 = k_gemm_f16 (residual epilogue), 1 = k_gemm_f16_pp, -1 = both */
+int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h_ms, double* h_flops);
 
 /* One projection GEMM of the tower, C = X @ Wt^T with the fused epilogue the block uses
  * (model.py:175-191: in_proj, out_proj + residual, c_fc + QuickGELU, c_proj + residual), exposed so the
@@ -94,9 +96,16 @@ int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream);
 
-/* development aid: ablation variants of the f16 GEMM kernel (1 no in-loop DMA, 2 DMA only, 3 no epilogue) */
+/* development aid: ablation variants of the f16 GEMM kernels (k_gemm_f16: 0 shipped, 1 no in-loop DMA, 2 DMA only,
+ * 3 no epilogue; k_gemm_f16_pp: 22 shipped, 20 two phases per K-step, 21/23 five stages) */
 int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
                     void* stream);
+
+/* development aid: k_gemm_f16_pp (var 20..23) with per-wave cycle stamps.  d_trace receives, per (workgroup, wave),
+ * eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, epilogue cycles, LOAD-segment
+ * cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks. */
+int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
+                  int K, int ldc, void* stream);
 
 /* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
  * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */

@@ -57,10 +57,12 @@ class VitEncoder:
     def profile(self, on=True):
         check(lib.vg_vit_profile(self._h, 1 if on else 0), 'vg_vit_profile')
 
-    def profile_read(self):
-        """-> (launches, total ms, total algorithmic FLOPs) of the projection GEMMs since profile(True)."""
+    def profile_read(self, kind=-1):
+        """-> (launches, total ms, total algorithmic FLOPs) of the projection GEMMs since profile(True);
+        kind 1: k_gemm_f16_pp launches only, 0: k_gemm_f16 (residual epilogue) only, -1: both."""
         n, ms, fl = ctypes.c_int32(0), ctypes.c_double(0), ctypes.c_double(0)
-        check(lib.vg_vit_profile_read(self._h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'vg_vit_profile_read')
+        check(lib.vg_vit_profile_read_kind(self._h, int(kind), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
+              'vg_vit_profile_read_kind')
         return n.value, ms.value, fl.value
 
     def encode(self, crops, stream=None):

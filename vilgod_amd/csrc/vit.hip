@@ -205,6 +205,278 @@ __global__ __launch_bounds__(512, 2) void k_gemm_f16(const f16* __restrict__ X, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ping-pong GEMM: 256 x 256 x 32 tiles, 8 waves = two groups of four (group = 128-row half of the tile, one wave of each
+// group per SIMD), each wave 128 (m) x 64 (n).  A PHASE is one k16 sub-step of one wave: LOAD segment (6 ds_read_b128 for
+// this sub-step's fragments + 2 LDS-DMA pieces of a tile several K-steps ahead), s_barrier, MFMA segment (8
+// v_mfma_f32_32x32x16_f16 under s_setprio 1), s_barrier.  Group 1 runs ONE BARRIER behind group 0, so on every SIMD one
+// wave's MFMA segment overlaps the other wave's LOAD segment: an LDS-DMA piece costs its issuing wave 60-185 cycles
+// (MI355X_MICROARCH.md, cycle constants), which a lock-step schedule pays with an idle MFMA pipe.
+// Ring of STAGES tiles (32 KB each: X rows 16 KB | W rows 16 KB).  Flat phase p = 2 kt + s issues half-tile q = p + LEAD
+// (q even = X rows of tile q/2, odd = W rows), LEAD = 2 STAGES - 3: the slot's previous tile was last read two phases
+// earlier by either group (WAR), and the counted wait for tile kt+1 (vmcnt = 2 (LEAD - 2) pieces may stay in flight) sits
+// in the LOAD segment of phase (kt, 1), one full barrier before any wave reads that tile (RAW).
+template <int EPI, int STAGES, bool TRACE = false, int PH = 2>
+__global__ __launch_bounds__(512, 1) void k_gemm_f16_pp(const f16* __restrict__ X, const f16* __restrict__ Wt,
+                                                        const float* __restrict__ bias, void* __restrict__ Cout,
+                                                        float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
+                                                        long long* __restrict__ trace) {
+    constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2;
+    constexpr int STAGE_BYTES = (BM + BN) * 64, W_OFF = BM * 64;
+    constexpr int LEAD = 2 * STAGES - 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntm = M / BM;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = ntm * cw;
+    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int grp = wave >> 2, wn = wave & 3;
+
+    // DMA: this wave stages rows [wave*32, +32) of the X half and of the W half (2 pieces of 16 rows each)
+    const int l2 = lane >> 2, pslot = lane & 3;
+    const int R0 = wave * 32 + l2, R1 = R0 + 16;
+    const f16* xs0 = X + (size_t)(m0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
+    const f16* xs1 = X + (size_t)(m0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
+    const f16* ws0 = Wt + (size_t)(n0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
+    const f16* ws1 = Wt + (size_t)(n0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
+    char* const dma_base = smem + wave * 2048;
+#define PP_ISSUE_X(TILE)                                                                                      \
+    do {                                                                                                      \
+        char* sb_ = dma_base + ((TILE) % STAGES) * STAGE_BYTES;                                               \
+        __builtin_amdgcn_global_load_lds((glb_void*)(xs0 + (size_t)(TILE) * GK), (lds_void*)sb_, 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((glb_void*)(xs1 + (size_t)(TILE) * GK), (lds_void*)(sb_ + 1024), 16, 0, 0); \
+    } while (0)
+#define PP_ISSUE_W(TILE)                                                                                      \
+    do {                                                                                                      \
+        char* sb_ = dma_base + ((TILE) % STAGES) * STAGE_BYTES + W_OFF;                                       \
+        __builtin_amdgcn_global_load_lds((glb_void*)(ws0 + (size_t)(TILE) * GK), (lds_void*)sb_, 16, 0, 0);  \
+        __builtin_amdgcn_global_load_lds((glb_void*)(ws1 + (size_t)(TILE) * GK), (lds_void*)(sb_ + 1024), 16, 0, 0); \
+    } while (0)
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+    const int r31 = lane & 31, hh = lane >> 5;
+    const int sw = (r31 >> 2) & 3;
+    const int xrow = (grp * 128 + r31) * 64, wrow = W_OFF + (wn * 64 + r31) * 64;
+    const int po0 = ((0 + hh) ^ sw) * 16, po1 = ((2 + hh) ^ sw) * 16;
+    const int nk = K / GK;            // host guarantees nk >= STAGES
+    const int nh = 2 * nk;            // half-tiles
+
+    f16x8 fa[TN], fb[TM];
+#define PP_READ(SB, PO)                                                                      \
+    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const f16x8*)((SB) + wrow + ni * 2048 + (PO)); \
+    _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const f16x8*)((SB) + xrow + mi * 2048 + (PO));
+#define PP_MMA()                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                           \
+    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                        \
+        _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                    \
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define PP_BAR()                                  \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    __builtin_amdgcn_sched_barrier(0);
+    // at most `newer` HALF-tiles issued after the wanted tile may stay in flight (2 pieces each)
+#define PP_WAIT(newer)                                                                       \
+    do {                                                                                     \
+        const int nw_ = (newer);                                                             \
+        if (nw_ >= LEAD - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory"); \
+        else if (nw_ == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 \
+        else if (nw_ == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 \
+        else if (nw_ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
+        else if (nw_ == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  \
+        else if (nw_ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  \
+        else if (nw_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+    } while (0)
+
+    long long tr_wait = 0, tr_bar = 0, tr_t0 = 0, tr_load = 0, tr_mma = 0, tr_w0 = 0;
+    if (TRACE) tr_w0 = wall_clock64();
+  if (PH == 1) {
+    // one phase per K-step: LOAD = 12 ds_reads + 4 DMA pieces (tile kt + D) + counted wait for tile kt+1; 16 MFMAs
+    constexpr int D = STAGES - 2;
+    f16x8 fa1[TN], fb1[TM];
+#pragma unroll
+    for (int q = 0; q < D; ++q) { PP_ISSUE_X(q); PP_ISSUE_W(q); }
+    PP_WAIT(2 * (D - 1));
+    PP_BAR()
+    if (grp == 1) { PP_BAR() }
+    if (TRACE) tr_t0 = clock64();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
+        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+        if (TRACE) c0 = clock64();
+        PP_READ(sb, po0)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fa1[ni] = *(const f16x8*)(sb + wrow + ni * 2048 + po1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) fb1[mi] = *(const f16x8*)(sb + xrow + mi * 2048 + po1);
+        if (kt + D < nk) { PP_ISSUE_X(kt + D); PP_ISSUE_W(kt + D); }
+        if (TRACE) c1 = clock64();
+        if (kt + 1 < nk) {
+            const int newest = (kt + D < nk - 1) ? kt + D : nk - 1;
+            PP_WAIT(2 * (newest - (kt + 1)));
+        }
+        if (TRACE) c2 = clock64();
+        PP_BAR()
+        if (TRACE) c3 = clock64();
+        PP_MMA()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ni], fb1[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (TRACE) c4 = clock64();
+        PP_BAR()
+        if (TRACE) { const long long c5 = clock64(); tr_load += c1 - c0; tr_wait += c2 - c1; tr_bar += (c3 - c2) + (c5 - c4); tr_mma += c4 - c3; }
+    }
+  } else {
+    // prologue: half-tiles 0 .. LEAD-1, then tile 0 (halves 0,1) must have landed
+#pragma unroll
+    for (int q = 0; q < LEAD; ++q) {
+        if (q & 1) PP_ISSUE_W(q >> 1); else PP_ISSUE_X(q >> 1);
+    }
+    PP_WAIT(LEAD - 2);
+    PP_BAR()
+    if (grp == 1) { PP_BAR() }          // group 1 runs one barrier behind group 0
+    if (TRACE) tr_t0 = clock64();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
+        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+        // ---- phase (kt, 0): LEAD is odd -> half-tile 2kt+LEAD is the W half of tile kt + (LEAD-1)/2
+        if (TRACE) c0 = clock64();
+        PP_READ(sb, po0)
+        if (2 * kt + LEAD < nh) PP_ISSUE_W(kt + (LEAD >> 1));
+        if (TRACE) c1 = clock64();
+        PP_BAR()
+        if (TRACE) c2 = clock64();
+        PP_MMA()
+        if (TRACE) c3 = clock64();
+        PP_BAR()
+        if (TRACE) { c4 = clock64(); tr_load += c1 - c0; tr_bar += (c2 - c1) + (c4 - c3); tr_mma += c3 - c2; }
+        // ---- phase (kt, 1): half-tile 2kt+1+LEAD is the X half of tile kt + (LEAD+1)/2
+        if (TRACE) c0 = clock64();
+        PP_READ(sb, po1)
+        if (2 * kt + 1 + LEAD < nh) PP_ISSUE_X(kt + ((LEAD + 1) >> 1));
+        if (TRACE) c1 = clock64();
+        if (kt + 1 < nk) {
+            // newest half-tile issued so far: min(2kt+1+LEAD, nh-1); tile kt+1 = halves 2kt+2, 2kt+3
+            const int newest = (2 * kt + 1 + LEAD < nh - 1) ? 2 * kt + 1 + LEAD : nh - 1;
+            PP_WAIT(newest - (2 * kt + 3));
+        }
+        if (TRACE) { c2 = clock64(); tr_load += c1 - c0; tr_wait += c2 - c1; }
+        PP_BAR()
+        if (TRACE) c3 = clock64();
+        PP_MMA()
+        if (TRACE) c4 = clock64();
+        PP_BAR()
+        if (TRACE) { const long long c5 = clock64(); tr_bar += (c3 - c2) + (c5 - c4); tr_mma += c4 - c3; }
+    }
+  }
+    if (grp == 0) { PP_BAR() }
+#undef PP_ISSUE_X
+#undef PP_ISSUE_W
+#undef PP_READ
+#undef PP_MMA
+#undef PP_BAR
+#undef PP_WAIT
+    long long tr_t1 = 0;
+    if (TRACE) tr_t1 = clock64();
+    // ---- epilogue through LDS (the whole ring is free: every DMA landed, every fragment is in registers) ----
+    // The tile is laid down with its 16-byte chunks XOR-swizzled by (row & 31) instead of row padding, so a full
+    // 256 x 256 fp16 tile (128 KB) or a 128-row fp32 half fits the ring exactly and both the lane-per-row writes and
+    // the row-contiguous reads are bank-conflict free.  Bias / QuickGELU are applied in registers (a lane's n is fixed).
+    __syncthreads();
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nloc = wn * 64 + ni * 32 + 8 * g + 4 * hh;
+                const float4 b4 = *(const float4*)(bias + n0 + nloc);
+                const int ch = nloc >> 3;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int m = grp * 128 + mi * 32 + r31;
+                    float v[4] = {acc[ni][mi][4 * g] + b4.x, acc[ni][mi][4 * g + 1] + b4.y, acc[ni][mi][4 * g + 2] + b4.z,
+                                  acc[ni][mi][4 * g + 3] + b4.w};
+                    f16x4 h4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));   // QuickGELU (model.py:166-168)
+                        h4[e] = (f16)x;
+                    }
+                    *(f16x4*)(smem + m * 512 + ((ch ^ r31) << 4) + hh * 8) = h4;
+                }
+            }
+        __syncthreads();
+        const int j = tid & 31, rr = tid >> 5;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int m = pass * 16 + rr;
+            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
+            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (grp == half) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nloc = wn * 64 + ni * 32 + 8 * g + 4 * hh;
+                        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
+                        const int ch = nloc >> 2;
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi) {
+                            const int m = mi * 32 + r31;
+                            *(float4*)(smem + m * 1024 + ((ch ^ r31) << 4)) =
+                                make_float4(acc[ni][mi][4 * g] + b4.x, acc[ni][mi][4 * g + 1] + b4.y,
+                                            acc[ni][mi][4 * g + 2] + b4.z, acc[ni][mi][4 * g + 3] + b4.w);
+                        }
+                    }
+            }
+            __syncthreads();
+            const int j = tid & 63, rr = tid >> 6;
+#pragma unroll 4
+            for (int pass = 0; pass < 16; ++pass) {
+                const int m = pass * 8 + rr;
+                float4 v = *(const float4*)(smem + m * 1024 + j * 16);
+                const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+                if (EPI == EPI_BIAS_RESID) {
+                    float* p = resid + off;
+                    const float4 x4 = *(const float4*)p;
+                    v.x += x4.x; v.y += x4.y; v.z += x4.z; v.w += x4.w;
+                    *(float4*)p = v;
+                } else {
+                    *(float4*)((float*)Cout + off) = v;
+                }
+            }
+        }
+    }
+    if (TRACE) {
+        const long long tr_t2 = clock64();
+        if (lane == 0 && trace) {
+            long long* o = trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = tr_t1 - tr_t0; o[1] = tr_wait; o[2] = tr_bar; o[3] = tr_t2 - tr_t1; o[4] = tr_load; o[5] = tr_mma; o[6] = wave; o[7] = wall_clock64() - tr_w0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fp32 parity-mode GEMM (VALU): 64x64 tile, 256 threads, 4x4 micro-tile, same epilogues.
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ X, const float* __restrict__ Wt,
@@ -623,6 +895,7 @@ struct vg_vit {
     int prof_on = 0, prof_n = 0;
     hipEvent_t prof_ev[2 * VG_PROF_MAX];
     double prof_flops[VG_PROF_MAX];
+    int prof_kind[VG_PROF_MAX];      // 0 = k_gemm_f16 / k_gemm_f32, 1 = k_gemm_f16_pp
     bool prof_init = false;
     std::map<std::string, void*> w;        // device pointers (f32 or f16 depending on role)
     std::map<std::string, size_t> numel;
@@ -647,19 +920,52 @@ static int gemm_chunk_tiles(int N, int K) {
     return ntn / nchunks;
 }
 
+template <int EPI, int STAGES, bool TRACE, int PH = 2>
+static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
+                          hipStream_t st, long long* trace) {
+    if (M % 256 || N % 256 || K % GK || K / GK < STAGES) return VG_ERR_ARG;
+    auto kern = k_gemm_f16_pp<EPI, STAGES, TRACE, PH>;
+    const int lds = STAGES * 32768;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ntn = N / 256;
+    int cwt = (int)(2400000L / (256L * K * 2));
+    if (cwt < 1) cwt = 1;
+    if (cwt > ntn) cwt = ntn;
+    while (ntn % cwt) --cwt;
+    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
+                       ldc, cwt, trace);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
 template <int EPI>
 static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
                        int N, int K, hipStream_t st, int ldc = 0) {
     if (ldc == 0) ldc = N;
     vg_vit* v = const_cast<vg_vit*>(cv);
+    // f16 ViT shapes (N % 256 == 0, K >= 128) with a streaming epilogue take the ping-pong kernel.  The residual
+    // epilogue (fp32 read-modify-write of the stream, HBM bound) stays on k_gemm_f16, whose two workgroups per CU
+    // overlap one block's epilogue traffic with the other's MFMAs; so do the remaining legal shapes.
+    const bool use_pp = v->dtype == 1 && EPI != EPI_BIAS_RESID && N % 256 == 0 && K / GK >= 4 && !getenv("VG_GEMM_V4");
     const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
     if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
     struct Closer {
-        vg_vit* v; bool prof; hipStream_t st; double fl;
-        ~Closer() { if (prof) { (void)hipEventRecord(v->prof_ev[2 * v->prof_n + 1], st); v->prof_flops[v->prof_n++] = fl; } }
-    } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K};
+        vg_vit* v; bool prof; hipStream_t st; double fl; int kind;
+        ~Closer() {
+            if (prof) {
+                (void)hipEventRecord(v->prof_ev[2 * v->prof_n + 1], st);
+                v->prof_kind[v->prof_n] = kind;
+                v->prof_flops[v->prof_n++] = fl;
+            }
+        }
+    } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K, use_pp ? 1 : 0};
     if (v->dtype == 1) {
         if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
+        if (use_pp) return launch_gemm_pp<EPI, 4, false, 1>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr);
         int nwg = (M / GBM) * (N / GBN);
         static bool attr_set = false;
         if (!attr_set) {
@@ -843,8 +1149,9 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     return VG_OK;
 }
 
-/* ablation variants of the f16 GEMM (development aid, epi 0 only): var 1 = no DMA inside the K loop,
- * 2 = DMA only (no LDS reads / MFMA), 3 = no epilogue */
+/* ablation variants of the f16 GEMMs (development aid, epi 0 only): k_gemm_f16 var 0 = as shipped, 1 = no DMA inside the
+ * K loop, 2 = DMA only (no LDS reads / MFMA), 3 = no epilogue; k_gemm_f16_pp var 22 = as shipped (4 stages, one phase per
+ * K-step), 20 = two phases per K-step, 21 / 23 = 5 stages */
 int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc, void* stream) {
     if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
     int nwg = (M / GBM) * (N / GBN);
@@ -855,8 +1162,26 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
         hipLaunchKernelGGL((k_gemm_f16<EPI_BIAS, V>), dim3(nwg), dim3(512), G_LDS_BYTES, st, (const f16*)d_X, (const f16*)d_Wt, \
                            d_bias, d_C, nullptr, M, N, K, ldc, gemm_chunk_tiles(N, K));                                   \
         break;
-    switch (var) { VG_VAR(0) VG_VAR(1) VG_VAR(2) VG_VAR(3) default: return VG_ERR_ARG; }
+    switch (var) { VG_VAR(0) VG_VAR(1) VG_VAR(2) VG_VAR(3)
+        case 20: return launch_gemm_pp<EPI_BIAS, 4, false>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
+        case 21: return launch_gemm_pp<EPI_BIAS, 5, false>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
+        case 22: return launch_gemm_pp<EPI_BIAS, 4, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
+        case 23: return launch_gemm_pp<EPI_BIAS, 5, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
+        default: return VG_ERR_ARG; }
 #undef VG_VAR
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
+                  int K, int ldc, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (var) {
+        case 20: return launch_gemm_pp<EPI_BIAS, 4, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        case 21: return launch_gemm_pp<EPI_BIAS, 5, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        case 22: return launch_gemm_pp<EPI_BIAS, 4, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        case 23: return launch_gemm_pp<EPI_BIAS, 5, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        default: return VG_ERR_ARG; }
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
@@ -891,19 +1216,25 @@ int vg_vit_profile(vg_vit* v, int on) {
     return VG_OK;
 }
 
-/* synchronises, then returns the number of GEMM launches sampled, their summed duration (ms) and algorithmic FLOPs */
-int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_flops) {
+/* synchronises, then returns the number of GEMM launches sampled, their summed duration (ms) and algorithmic FLOPs;
+ * kind -1: every projection GEMM, 0: k_gemm_f16 (residual epilogue), 1: k_gemm_f16_pp */
+int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h_ms, double* h_flops) {
     if (!v || !h_launches || !h_ms || !h_flops) return VG_ERR_ARG;
     *h_launches = 0; *h_ms = 0; *h_flops = 0;
     for (int i = 0; i < v->prof_n; ++i) {
+        if (kind >= 0 && v->prof_kind[i] != kind) continue;
         VG_CHECK(hipEventSynchronize(v->prof_ev[2 * i + 1]));
         float ms = 0.f;
         VG_CHECK(hipEventElapsedTime(&ms, v->prof_ev[2 * i], v->prof_ev[2 * i + 1]));
         *h_ms += ms;
         *h_flops += v->prof_flops[i];
+        ++*h_launches;
     }
-    *h_launches = v->prof_n;
     return VG_OK;
+}
+
+int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_flops) {
+    return vg_vit_profile_read_kind(v, -1, h_launches, h_ms, h_flops);
 }
 
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
