@@ -183,6 +183,39 @@ void vg_cluster_destroy(vg_cluster* h);
  * Synchronises `stream` once per Boruvka round (4-byte counter read).  h_rounds (host, may be NULL): rounds used. */
 int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
                    int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream);
+/* The same over the first `dim` (3, 4 or 5) columns: dim = 5 is the two-frame clustering input
+ * [x, y, z, entropy score, 0.1 * relative frame] of zero_shot_detector.py:232-239 (preprocessing.yaml:68 n_frames: 2).
+ * float64 distances summed left to right over the coordinates; the cell grid and all pruning use x,y,z only. */
+int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, int dim, int k, double* d_core2,
+                      int32_t* d_mst_lo, int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream);
+
+/* ---- fixed-radius neighbour queries (entropy scores, two-frame clustering) -------------------
+ * vg_cluster_grid builds the handle's 0.4 m cell grid over a TARGET set; it stays valid until the next
+ * vg_cluster_grid / vg_cluster_mst[_nd] call on the handle. */
+int vg_cluster_grid(vg_cluster* h, const float* d_points, int n, int stride, void* stream);
+/* d_counts[i] = min(cap, #{target t : d2(query_i, t) < r2}) with float32 d2 = fma(dz,dz,fma(dy,dy,dx*dx)):
+ * what pointcloud_utils.py:74-107 derives from pcdet's ball_query (r2 = float32(radius)^2; count_neighbors: radius
+ * 0.3, cap 1000, per neighbouring frame; count_neighbors_inter_frame: radius 0.2, cap 100), and the `dists < 0.1`
+ * test on pytorch3d's squared k-NN distances (zero_shot_detector.py:226-227: r2 = 0.1f).  A query that is itself a
+ * target counts (the reference subtracts 1 for the seek frame on the host side, pointcloud_utils.py:90-91). */
+int vg_cluster_ball_count(vg_cluster* h, const float* d_query, int nq, int qstride, float r2, int cap, int32_t* d_counts,
+                          void* stream);
+/* Nearest target with float32 d2 <= max_d2 -> d_idx (row in the array given to vg_cluster_grid; lowest row among
+ * equidistant targets; -1 if none) and d_d2 (+inf if none): knn_labels (pointcloud_utils.py:505-513; K=1 and the
+ * 0.2 gate on pytorch3d's SQUARED distance). */
+int vg_cluster_nearest(vg_cluster* h, const float* d_query, int nq, int qstride, float max_d2, int32_t* d_idx, float* d_d2,
+                       void* stream);
+
+/* PP / ephemerality score from the per-neighbour-frame counts (pointcloud_utils.py:110-117 compute_ephe_score):
+ * d_counts [n_frames][nq] int32 (row f = counts against neighbour frame f); seek_row >= 0: that row is the query frame
+ * itself, 1 is subtracted (pointcloud_utils.py:90-91).  P = c / (sum c + 1e-8), H = sum(-P log(P + 1e-8)) / log(n_frames),
+ * float64, sums in numpy's pairwise order.  d_H [nq] f64. */
+int vg_entropy_scores(const int32_t* d_counts, int n_frames, int nq, int seek_row, double* d_H, void* stream);
+
+/* Counter-based replacement for `np.random.choice(n, n / n_frames, replace=False)` (zero_shot_detector.py:228):
+ * d_keys[i] = splitmix64(seed * 0x100000001B3 + (tag << 32) + i) >> 1; the caller keeps the n / n_frames smallest keys
+ * (stable order).  tag = absolute frame number. */
+int vg_subsample_keys(uint64_t seed, uint64_t tag, int n, int64_t* d_keys, void* stream);
 
 /* ---- frame transform, validity filters, boxes (rows B1, B4, C1, C2, E1) --------------------------------
  * dst[i] = float32(T * [src[i],1]), other columns copied: LidarFrame.points_ref

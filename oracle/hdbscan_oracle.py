@@ -34,15 +34,24 @@ PROB_THRESHOLD = 0.3      # waymo.yaml:63 `propability_threshold`
 
 
 # ------------------------------------------------------------------------------------------------
+def _d2(d):
+    """float64 squared norm over the last axis, summed left to right: (((dx2 + dy2) + dz2) + de2) + dt2 --
+    3-D for single-frame clustering, 5-D for the two-frame input (zero_shot_detector.py:232-239)."""
+    acc = d[..., 0] * d[..., 0]
+    for c in range(1, d.shape[-1]):
+        acc = acc + d[..., c] * d[..., c]
+    return acc
+
+
 def core_distances_sq(X, k=MIN_CLUSTER_SIZE):
-    """Squared distance to the k-th nearest other point, float64, d2 = (dx*dx + dy*dy) + dz*dz."""
+    """Squared distance to the k-th nearest other point, float64, d2 = (dx*dx + dy*dy) + dz*dz (+ ...)."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     n = len(X)
     kk = min(n, k + 9)
     _, idx = cKDTree(X).query(X, k=kk)
     idx = idx.reshape(n, kk)
     d = X[:, None, :] - X[idx]
-    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2] if X.shape[1] == 3 else (d * d).sum(-1)
+    d2 = _d2(d)
     d2.sort(axis=1)
     if n <= k:
         return np.full(n, np.inf)
@@ -67,7 +76,7 @@ def mst_prim(X, core2):
     in_tree[0] = True
     for e in range(n - 1):
         d = X - X[cur]
-        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2] if X.shape[1] == 3 else (d * d).sum(-1)
+        d2 = _d2(d)
         w = np.maximum(np.maximum(d2, core2), core2[cur])
         lo, hi = np.minimum(ids, cur), np.maximum(ids, cur)
         upd = ~in_tree & ((w < best) | ((w == best) & ((lo < blo) | ((lo == blo) & (hi < bhi)))))

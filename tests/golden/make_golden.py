@@ -168,6 +168,73 @@ def make_detect():
     print('detect_golden.pkl', n_det, 'detections,', nv, 'valid')
 
 
+def make_entropy():
+    """N1: the reference's pure-numpy pieces run unchanged -- pointcloud_utils.compute_ephe_score on seeded count
+    matrices (several column counts), cluster_utils.filter_by_ephemeral_score on seeded float32 score vectors, and the
+    sliding-window bookkeeping of ZeroShotDetector.calculate_entropy_scores (which frames are in the buffer and where the
+    query sits) traced by running the method itself with `pointcloud_utils.calculate_entropy_scores` replaced by a
+    recorder -> tests/golden/entropy_golden.npz."""
+    refstubs.install()
+    import types
+    import torch
+    from src.utils import cluster_utils, pointcloud_utils
+    rng = np.random.default_rng(11)
+    out = {}
+    for N in (2, 3, 5, 8, 15, 20):
+        c = rng.integers(0, 1001, size=(400, N)).astype(np.int64)
+        c[rng.uniform(size=c.shape) < 0.25] = 0
+        c[:5] = 0                                            # all-zero rows (no neighbour anywhere)
+        c[5:10] = 1000
+        out[f'count_{N}'] = c
+        out[f'H_{N}'] = pointcloud_utils.compute_ephe_score(c)
+    sc = [rng.uniform(0.2, 1.0, size=int(n)).astype(np.float32) for n in rng.integers(10, 300, size=64)]
+    for v in sc[:16]:
+        v[rng.uniform(size=len(v)) < 0.5] = 1.0              # stored scores >= 0.9 read back as 1.0
+    out['eph_values'] = np.concatenate(sc)
+    out['eph_seg'] = np.r_[0, np.cumsum([len(v) for v in sc])].astype(np.int64)
+    out['eph_moving'] = np.array([cluster_utils.filter_by_ephemeral_score(v, percentile=30, min_percentile_pp_score=0.5) for v in sc])
+    out['eph_moving_20_07'] = np.array([cluster_utils.filter_by_ephemeral_score(v, percentile=20, min_percentile_pp_score=0.7) for v in sc])
+    # ---- window bookkeeping: run the reference method with a recording scorer ----
+    from src.vilgod import zero_shot_detector as zsd
+    trace = {}
+    for L, n in ((40, 15), (15, 15), (23, 7)):
+        rec = []
+
+        class LF:
+            def __init__(self, i):
+                self.fnr = i
+                self._entropy_scores = None
+                self.points_ref_wo_ground = np.full((3, 5), float(i), np.float32)
+            entropy_scores = None
+
+            def update_entropy_scores(self, s, i):
+                pass
+
+        def fake(frame_buffer, seek, **kw):
+            rec.append(([int(t[0, 0].item()) for t in frame_buffer], int(seek)))
+            return np.ones(3)
+
+        self_ = types.SimpleNamespace(lidar_frame_list=[LF(i) for i in range(L)], lenght=L,
+                                      reset_progress_bar=lambda *a, **k: None,
+                                      progress_bar=types.SimpleNamespace(update=lambda *a, **k: None),
+                                      sync_lidar_frames=lambda: None)
+        orig, orig_cuda = pointcloud_utils.calculate_entropy_scores, torch.Tensor.cuda
+        pointcloud_utils.calculate_entropy_scores = fake
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        empty = torch.cuda.empty_cache
+        torch.cuda.empty_cache = lambda: None
+        try:
+            zsd.ZeroShotDetector.calculate_entropy_scores(self_, n)
+        finally:
+            pointcloud_utils.calculate_entropy_scores, torch.Tensor.cuda, torch.cuda.empty_cache = orig, orig_cuda, empty
+        out[f'win_{L}_{n}_start'] = np.array([r[0][0] for r in rec])
+        out[f'win_{L}_{n}_len'] = np.array([len(r[0]) for r in rec])
+        out[f'win_{L}_{n}_seek'] = np.array([r[1] for r in rec])
+        assert all(r[0] == list(range(r[0][0], r[0][0] + len(r[0]))) for r in rec)
+    np.savez_compressed(os.path.join(OUT, 'entropy_golden.npz'), **out)
+    print('entropy_golden.npz', sorted(out)[:6], '...')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['render', 'vit']
     for w in which:

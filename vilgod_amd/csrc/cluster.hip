@@ -49,7 +49,9 @@ struct vg_cluster {
     ClGrid* d_grid;
     unsigned int *d_code, *d_code_s;      // Morton codes (unsorted / sorted)
     int *d_perm_in, *d_perm;              // identity / sorted -> original index
-    float4* d_spts;                       // sorted points (x,y,z,-)
+    float4* d_spts;                       // sorted points (x,y,z,e): e = 4th clustering coordinate (0 in 3-D)
+    float* d_st;                          // sorted 5th clustering coordinate (5-D only)
+    int grid_n;                           // points in the grid currently built (vg_cluster_grid / vg_cluster_mst_nd)
     int* d_cell_start;                    // [CL_NCODES+1] reversed min-scan layout, see cl_cell_start()
     int* d_cell_comp;                     // purity tables, levels 0..3 back to back: component id if pure, else -1
     double* d_core2;                      // [n] sorted order
@@ -142,13 +144,14 @@ __global__ void k_cl_codes(const float* __restrict__ pts, int n, int stride, con
     perm[i] = i;
 }
 
-__global__ void k_cl_gather(const float* __restrict__ pts, int n, int stride, const int* __restrict__ perm,
-                            const unsigned int* __restrict__ code_s, float4* __restrict__ spts,
+__global__ void k_cl_gather(const float* __restrict__ pts, int n, int stride, int dim, const int* __restrict__ perm,
+                            const unsigned int* __restrict__ code_s, float4* __restrict__ spts, float* __restrict__ st,
                             int* __restrict__ cell_start_rev) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = pts + (size_t)perm[i] * stride;
-    spts[i] = make_float4(p[0], p[1], p[2], 0.f);
+    spts[i] = make_float4(p[0], p[1], p[2], dim >= 4 ? p[3] : 0.f);
+    if (dim >= 5) st[i] = p[4];
     if (i == 0 || code_s[i] != code_s[i - 1]) cell_start_rev[CL_NCODES - code_s[i]] = i;
 }
 
@@ -158,9 +161,15 @@ __global__ void k_cl_fill_int(int* p, int v, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double cl_d2(double ax, double ay, double az, const float4& b) {
+// squared distance in float64, summed left to right over the DIM coordinates: ((((dx2 + dy2) + dz2) + de2) + dt2)
+template <int DIM>
+__device__ __forceinline__ double cl_d2(double ax, double ay, double az, double ae, double at, const float4& b,
+                                        const float* __restrict__ st, int j) {
     double dx = ax - (double)b.x, dy = ay - (double)b.y, dz = az - (double)b.z;
-    return (dx * dx + dy * dy) + dz * dz;
+    double d2 = (dx * dx + dy * dy) + dz * dz;
+    if (DIM >= 4) { const double de = ae - (double)b.w; d2 = d2 + de * de; }
+    if (DIM >= 5) { const double dt = at - (double)st[j]; d2 = d2 + dt * dt; }
+    return d2;
 }
 
 // squared distance from q to the nearest face of the level-l block [b-1, b+2) (faces clipped by the grid do not count)
@@ -210,15 +219,17 @@ __device__ __forceinline__ double cl_box_d2(const ClGrid& g, double qx, double q
     return d2;
 }
 
-__global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, int n, const ClGrid* __restrict__ gp,
-                                                 const int* __restrict__ cs, int k, double* __restrict__ core2) {
+template <int DIM>
+__global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
+                                                 const ClGrid* __restrict__ gp, const int* __restrict__ cs, int k,
+                                                 double* __restrict__ core2) {
     __shared__ unsigned int stack[CL_STACK * 256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[i];
-    const double qx = qf.x, qy = qf.y, qz = qf.z;
+    const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[i] : 0.0;
     int cx, cy, cz;
     cl_cell_of(g, qx, qy, qz, cx, cy, cz);
     double h[CL_K];
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             if (j0 == j1) continue;
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 for (int j = j0; j < j1; ++j) {
-                    double d2 = cl_d2(qx, qy, qz, spts[j]);
+                    double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
                     if (d2 < h[CL_K - 1]) {
 #pragma unroll
                         for (int u = 0; u < CL_K; ++u)
@@ -331,7 +342,8 @@ __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
     return ((unsigned long long)lo << 32) | hi;
 }
 
-__global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ spts, int n,
+template <int DIM>
+__global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                      const ClGrid* __restrict__ gp, const int* __restrict__ cs,
                                                      const int* __restrict__ cell_comp, const int* __restrict__ perm,
                                                      const double* __restrict__ core2, const int* __restrict__ comp,
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[a];
-    const double qx = qf.x, qy = qf.y, qz = qf.z;
+    const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[a] : 0.0;
     const int ca = comp[a];
     const double core_a = core2[a];
     const int oa = perm[a];
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                 bool improved = false;
                 for (int j = j0; j < j1; ++j) {
                     if (comp[j] == ca) continue;
-                    const double d2 = cl_d2(qx, qy, qz, spts[j]);
+                    const double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
                     if (d2 > bw) continue;
                     const double w = fmax(fmax(d2, core_a), core2[j]);
                     if (w > bw) continue;
@@ -499,6 +511,67 @@ __global__ void k_cl_gather_edges(int m, const int* __restrict__ idx_s, const in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fixed-radius queries against the grid of a TARGET point set (entropy scores / two-frame clustering).
+// float32 arithmetic in the order the reference's CUDA ops compile to under nvcc's default FMA contraction:
+//   d2 = fma(dz, dz, fma(dy, dy, dx * dx))      (pcdet ball_query_kernel_stack; pytorch3d KNearestNeighbor dist += diff*diff)
+__device__ __forceinline__ float cl_d2_f32(float qx, float qy, float qz, const float4& b) {
+    const float dx = qx - b.x, dy = qy - b.y, dz = qz - b.z;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+// counts[i] = min(cap, #{ target j : d2(q_i, t_j) < r2 })  -- pointcloud_utils.py:74-107 (ball_query + count_nonzero)
+__global__ __launch_bounds__(256) void k_cl_ball_count(const float* __restrict__ q, int nq, int qstride,
+                                                       const float4* __restrict__ spts, const ClGrid* __restrict__ gp,
+                                                       const int* __restrict__ cs, float r2, int reach, int cap,
+                                                       int* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const ClGrid g = *gp;
+    const float qx = q[(size_t)i * qstride], qy = q[(size_t)i * qstride + 1], qz = q[(size_t)i * qstride + 2];
+    int cx, cy, cz;
+    cl_cell_of(g, qx, qy, qz, cx, cy, cz);
+    int cnt = 0;
+    for (int z = max(cz - reach, 0); z <= min(cz + reach, CL_NZ - 1); ++z)
+        for (int y = max(cy - reach, 0); y <= min(cy + reach, CL_NY - 1); ++y)
+            for (int x = max(cx - reach, 0); x <= min(cx + reach, CL_NX - 1); ++x) {
+                const unsigned int c = cl_code(x, y, z);
+                const int j0 = cl_start(cs, c), j1 = cl_start(cs, c + 1u);
+                for (int j = j0; j < j1; ++j) cnt += cl_d2_f32(qx, qy, qz, spts[j]) < r2 ? 1 : 0;
+            }
+    counts[i] = cnt < cap ? cnt : cap;
+}
+
+// nearest target point with d2 <= r2max: idx (ORIGINAL target index, lowest index among equidistant ones) and d2, or
+// (-1, +inf)  -- pointcloud_utils.py:496-513 (knn K=1 + distance gate)
+__global__ __launch_bounds__(256) void k_cl_nearest(const float* __restrict__ q, int nq, int qstride,
+                                                    const float4* __restrict__ spts, const int* __restrict__ perm,
+                                                    const ClGrid* __restrict__ gp, const int* __restrict__ cs, float r2max,
+                                                    int reach, int* __restrict__ idx, float* __restrict__ d2out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const ClGrid g = *gp;
+    const float qx = q[(size_t)i * qstride], qy = q[(size_t)i * qstride + 1], qz = q[(size_t)i * qstride + 2];
+    int cx, cy, cz;
+    cl_cell_of(g, qx, qy, qz, cx, cy, cz);
+    float best = INFINITY;
+    int bi = -1;
+    for (int z = max(cz - reach, 0); z <= min(cz + reach, CL_NZ - 1); ++z)
+        for (int y = max(cy - reach, 0); y <= min(cy + reach, CL_NY - 1); ++y)
+            for (int x = max(cx - reach, 0); x <= min(cx + reach, CL_NX - 1); ++x) {
+                const unsigned int c = cl_code(x, y, z);
+                const int j0 = cl_start(cs, c), j1 = cl_start(cs, c + 1u);
+                for (int j = j0; j < j1; ++j) {
+                    const float d2 = cl_d2_f32(qx, qy, qz, spts[j]);
+                    if (d2 > r2max) continue;
+                    const int o = perm[j];
+                    if (d2 < best || (d2 == best && o < bi)) { best = d2; bi = o; }
+                }
+            }
+    idx[i] = bi;
+    d2out[i] = best;
+}
+
+// ---------------------------------------------------------------------------------------------
 struct MinOp {
     __device__ __host__ int operator()(int a, int b) const { return a < b ? a : b; }
 };
@@ -517,6 +590,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_perm_in, 4 * n));
     VG_CHECK(hipMalloc(&h->d_perm, 4 * n));
     VG_CHECK(hipMalloc(&h->d_spts, sizeof(float4) * n));
+    VG_CHECK(hipMalloc(&h->d_st, 4 * n));
     VG_CHECK(hipMalloc(&h->d_cell_start, 4 * (size_t)(CL_NCODES + 1)));
     VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * (size_t)(CL_NCODES + (CL_NCODES >> 3) + (CL_NCODES >> 6) + (CL_NCODES >> 9))));
     VG_CHECK(hipMalloc(&h->d_core2, 8 * n));
@@ -550,7 +624,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
 
 void vg_cluster_destroy(vg_cluster* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_cell_start, h->d_cell_comp,
+    void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
                     h->d_pt_w, h->d_pt_key, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
                     h->d_mst_idx, h->d_mst_idx_s, h->d_temp};
@@ -559,20 +633,10 @@ void vg_cluster_destroy(vg_cluster* h) {
     delete h;
 }
 
-/* Exact core distances + exact MST of the mutual reachability graph.  SYNCHRONOUS on `stream` (one small
- * device->host counter read per Boruvka round).
- *   d_points [n,stride] f32 (x,y,z first);  k = min_samples (<= 15): core = distance to the k-th nearest OTHER point
- *   d_core2  [n] f64 squared core distances, ORIGINAL point order (may be NULL)
- *   d_mst_lo/hi [n-1] int32 original point ids (lo < hi), d_mst_w2 [n-1] f64 squared weights, sorted ascending by
- *   weight (equal weights in unspecified order: vg_hdbscan_tree_host callers sort ties by (lo,hi)).
- *   h_rounds: number of Boruvka rounds (diagnostic, may be NULL). */
-int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
-                   int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream) {
-    if (!h || !d_points || n < 0 || stride < 3 || k < 1 || k >= CL_K) return VG_ERR_ARG;
-    if (n > h->max_points) return VG_ERR_CAPACITY;
-    if (h_rounds) *h_rounds = 0;
-    if (n < 2) return VG_OK;
-    hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+// bbox -> grid origin -> Morton codes -> radix sort -> sorted points + dense cell-start table
+static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride, int dim, hipStream_t st) {
     const int nb = vg_div_up(n, 256);
     ClGrid g0;
     memset(&g0, 0, sizeof(g0));
@@ -587,11 +651,98 @@ int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int 
         size_t tot = (size_t)CL_NCODES + 1;
         hipLaunchKernelGGL(k_cl_fill_int, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->d_cell_start, n, tot);
     }
-    hipLaunchKernelGGL(k_cl_gather, dim3(nb), dim3(256), 0, st, d_points, n, stride, h->d_perm, h->d_code_s, h->d_spts,
-                       h->d_cell_start);
+    hipLaunchKernelGGL(k_cl_gather, dim3(nb), dim3(256), 0, st, d_points, n, stride, dim, h->d_perm, h->d_code_s, h->d_spts,
+                       h->d_st, h->d_cell_start);
     tb = h->temp_bytes;
     VG_CHECK(rocprim::inclusive_scan(h->d_temp, tb, h->d_cell_start, h->d_cell_start, (size_t)(CL_NCODES + 1), MinOp(), st));
-    hipLaunchKernelGGL(k_cl_core, dim3(nb), dim3(256), 0, st, h->d_spts, n, h->d_grid, h->d_cell_start, k, h->d_core2);
+    VG_LAUNCH_CHECK();
+    h->grid_n = n;
+    return VG_OK;
+}
+
+template <int DIM>
+static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
+    hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                       h->d_cell_start, k, h->d_core2);
+}
+template <int DIM>
+static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
+    hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                       h->d_cell_start, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key,
+                       h->d_pt_b);
+}
+
+extern "C" {
+
+/* Builds the 0.4 m cell grid over a TARGET point set (x,y,z = first three columns) for vg_cluster_ball_count /
+ * vg_cluster_nearest.  The grid stays valid until the next vg_cluster_grid / vg_cluster_mst[_nd] on this handle. */
+int vg_cluster_grid(vg_cluster* h, const float* d_points, int n, int stride, void* stream) {
+    if (!h || n < 0 || stride < 3) return VG_ERR_ARG;
+    if (n > h->max_points) return VG_ERR_CAPACITY;
+    h->grid_n = 0;
+    if (n == 0) return VG_OK;
+    if (!d_points) return VG_ERR_ARG;
+    return cl_build_grid(h, d_points, n, stride, 3, (hipStream_t)stream);
+}
+
+/* d_counts[i] = min(cap, number of grid points t with d2(q_i, t) < r2), float32 d2 = fma(dz,dz,fma(dy,dy,dx*dx))
+ * (pcdet ball_query + the count of pointcloud_utils.py:74-107; a query point that is itself in the target set counts). */
+int vg_cluster_ball_count(vg_cluster* h, const float* d_query, int nq, int qstride, float r2, int cap, int32_t* d_counts,
+                          void* stream) {
+    if (!h || nq < 0 || qstride < 3 || !(r2 > 0.f) || cap < 0) return VG_ERR_ARG;
+    if (nq == 0) return VG_OK;
+    if (!d_query || !d_counts) return VG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->grid_n == 0) { VG_CHECK(hipMemsetAsync(d_counts, 0, 4 * (size_t)nq, st)); return VG_OK; }
+    const int reach = (int)ceil(sqrt((double)r2) / CL_CELL);
+    if (reach > 8) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_cl_ball_count, dim3(vg_div_up(nq, 256)), dim3(256), 0, st, d_query, nq, qstride, h->d_spts, h->d_grid,
+                       h->d_cell_start, r2, reach, cap, d_counts);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+/* nearest grid point with float32 d2 <= max_d2: d_idx = its index in the point array given to vg_cluster_grid (lowest
+ * index among equidistant points) and d_d2, or -1 / +inf (pointcloud_utils.py:496-513: knn K=1 + squared-distance gate). */
+int vg_cluster_nearest(vg_cluster* h, const float* d_query, int nq, int qstride, float max_d2, int32_t* d_idx, float* d_d2,
+                       void* stream) {
+    if (!h || nq < 0 || qstride < 3 || !(max_d2 > 0.f)) return VG_ERR_ARG;
+    if (nq == 0) return VG_OK;
+    if (!d_query || !d_idx || !d_d2) return VG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int reach = h->grid_n ? (int)ceil(sqrt((double)max_d2) / CL_CELL) : 0;
+    if (reach > 8) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_cl_nearest, dim3(vg_div_up(nq, 256)), dim3(256), 0, st, d_query, nq, qstride, h->d_spts, h->d_perm,
+                       h->d_grid, h->d_cell_start, max_d2, h->grid_n ? reach : -1, d_idx, d_d2);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+/* Exact core distances + exact MST of the mutual reachability graph.  SYNCHRONOUS on `stream` (one small
+ * device->host counter read per Boruvka round).
+ *   d_points [n,stride] f32; dim = 3, 4 or 5 leading columns form the clustering space (x,y,z first: the cell grid and
+ *   all pruning bounds use x,y,z only -- a lower bound of the dim-D distance; 5-D = the two-frame input of
+ *   zero_shot_detector.py:232-237: x,y,z,entropy,0.1*frame).  Distances: float64, summed left to right.
+ *   k = min_samples (<= 15): core = distance to the k-th nearest OTHER point
+ *   d_core2  [n] f64 squared core distances, ORIGINAL point order (may be NULL)
+ *   d_mst_lo/hi [n-1] int32 original point ids (lo < hi), d_mst_w2 [n-1] f64 squared weights, sorted ascending by
+ *   weight (equal weights in unspecified order: vg_hdbscan_tree_host callers sort ties by (lo,hi)).
+ *   h_rounds: number of Boruvka rounds (diagnostic, may be NULL). */
+int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, int dim, int k, double* d_core2,
+                      int32_t* d_mst_lo, int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream) {
+    if (!h || !d_points || n < 0 || dim < 3 || dim > 5 || stride < dim || k < 1 || k >= CL_K) return VG_ERR_ARG;
+    if (n > h->max_points) return VG_ERR_CAPACITY;
+    if (h_rounds) *h_rounds = 0;
+    if (n < 2) return VG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = vg_div_up(n, 256);
+    {
+        const int rc = cl_build_grid(h, d_points, n, stride, dim, st);
+        if (rc != VG_OK) return rc;
+    }
+    if (dim == 3) cl_launch_core<3>(h, n, k, st);
+    else if (dim == 4) cl_launch_core<4>(h, n, k, st);
+    else cl_launch_core<5>(h, n, k, st);
     if (d_core2) hipLaunchKernelGGL(k_cl_unsort_core, dim3(nb), dim3(256), 0, st, n, h->d_perm, h->d_core2, d_core2);
     VG_LAUNCH_CHECK();
     // ---- Boruvka ----
@@ -606,8 +757,9 @@ int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int 
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp);
         for (int l = 1; l < CL_PUR_LEVELS; ++l)
             hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp);
-        hipLaunchKernelGGL(k_cl_b_search, dim3(nb), dim3(256), 0, st, h->d_spts, n, h->d_grid, h->d_cell_start, h->d_cell_comp,
-                           h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_pt_b);
+        if (dim == 3) cl_launch_search<3>(h, n, st);
+        else if (dim == 4) cl_launch_search<4>(h, n, st);
+        else cl_launch_search<5>(h, n, st);
         hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_best_e);
         hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_e, h->d_pt_w, h->d_pt_key,
                            h->d_pt_b, h->d_sel_a, h->d_sel_b);
@@ -628,7 +780,7 @@ int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int 
     // ---- sort edges by weight ----
     const int m = n - 1;
     hipLaunchKernelGGL(k_cl_iota, dim3(vg_div_up(m, 256)), dim3(256), 0, st, m, h->d_mst_idx);
-    tb = h->temp_bytes;
+    size_t tb = h->temp_bytes;
     VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, (size_t)m, 0, 64, st));
     if (d_mst_lo && d_mst_hi)
         hipLaunchKernelGGL(k_cl_gather_edges, dim3(vg_div_up(m, 256)), dim3(256), 0, st, m, h->d_mst_idx_s, h->d_mst_a, h->d_mst_b,
@@ -636,6 +788,11 @@ int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int 
     if (d_mst_w2) VG_CHECK(hipMemcpyAsync(d_mst_w2, h->d_mst_w_s, 8 * (size_t)m, hipMemcpyDeviceToDevice, st));
     VG_LAUNCH_CHECK();
     return VG_OK;
+}
+
+int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
+                   int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream) {
+    return vg_cluster_mst_nd(h, d_points, n, stride, 3, k, d_core2, d_mst_lo, d_mst_hi, d_mst_w2, h_rounds, stream);
 }
 
 }  // extern "C"

@@ -369,6 +369,50 @@ __global__ __launch_bounds__(256) void k_cluster_box(const float* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// entropy (PP) score of a query frame from its neighbour counts; numpy's pairwise summation order
+// (n < 8: left to right; otherwise 8 running partial sums over blocks of 8, combined as a tree, then the tail).
+__device__ double vg_np_pairwise(const double* v, int n) {
+    if (n < 8) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += v[i];
+        return s;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += v[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += v[i];
+    return res;
+}
+
+__global__ void k_entropy_scores(const int* __restrict__ counts, int nf, int nq, int seek_row, double* __restrict__ H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    double c[128], t[128];
+    long long tot = 0;
+    for (int f = 0; f < nf; ++f) {
+        int v = counts[(size_t)f * nq + i];
+        if (f == seek_row) v -= 1;
+        c[f] = (double)v;
+        tot += v;
+    }
+    const double den = (double)tot + 1e-8;
+    for (int f = 0; f < nf; ++f) {
+        const double P = c[f] / den;
+        t[f] = -P * log(P + 1e-8);
+    }
+    H[i] = vg_np_pairwise(t, nf) / log((double)nf);
+}
+
+__global__ void k_subsample_keys(unsigned long long seed, unsigned long long tag, int n, long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (long long)(vg_mix64(seed * 0x100000001B3ull + (tag << 32) + (unsigned long long)i) >> 1);
+}
+
 extern "C" {
 
 int vg_ref_transform(const float* d_src, int n, int stride, const double* d_T4x4, float* d_dst, void* stream) {
@@ -413,6 +457,26 @@ int vg_cluster_boxes(const float* d_points, int stride, const int32_t* d_index, 
     if (!d_points || !d_index || !d_seg_off || !d_box7 || !d_aux3) return VG_ERR_ARG;
     hipLaunchKernelGGL(k_cluster_box, dim3(n_clusters), dim3(256), 0, (hipStream_t)stream, d_points, stride, d_index, d_seg_off,
                        d_box7, d_aux3);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+int vg_entropy_scores(const int32_t* d_counts, int n_frames, int nq, int seek_row, double* d_H, void* stream) {
+    if (nq < 0 || n_frames < 2 || n_frames > 128) return VG_ERR_ARG;
+    if (nq == 0) return VG_OK;
+    if (!d_counts || !d_H) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_entropy_scores, dim3(vg_div_up(nq, 128)), dim3(128), 0, (hipStream_t)stream, d_counts, n_frames, nq,
+                       seek_row, d_H);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+int vg_subsample_keys(uint64_t seed, uint64_t tag, int n, int64_t* d_keys, void* stream) {
+    if (n < 0) return VG_ERR_ARG;
+    if (n == 0) return VG_OK;
+    if (!d_keys) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_subsample_keys, dim3(vg_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, tag, n,
+                       (long long*)d_keys);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }

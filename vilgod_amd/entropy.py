@@ -1,0 +1,163 @@
+"""Entropy (PP) scores over a sliding window of frames and the two-frame clustering input -- SURVEY §8f row N1, the
+reference's DEFAULT configuration (tools/configs/preprocessing.yaml:57-68).
+
+Mirrors
+  ZeroShotDetector.calculate_entropy_scores   src/vilgod/zero_shot_detector.py:153-195
+  pointcloud_utils.count_neighbors / compute_ephe_score / calculate_entropy_scores   src/utils/pointcloud_utils.py:74-123
+  the n_frames > 1 branch of ZeroShotDetector.spatial_clustering   src/vilgod/zero_shot_detector.py:208-242
+  pointcloud_utils.knn_labels   src/utils/pointcloud_utils.py:505-513
+
+All neighbour searches run on the GPU through the cell grid of a `vilgod_amd.hdbscan.HDBSCAN` handle
+(csrc/cluster.hip: vg_cluster_grid / vg_cluster_ball_count / vg_cluster_nearest); the scores come from
+vg_entropy_scores, the random half-sample from vg_subsample_keys (counter-based; the reference draws from numpy's global
+Mersenne state, which no implementation can reproduce).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import lib, ptr, stream_ptr, check
+
+ENTROPY_KEEP = 0.9        # zero_shot_detector.py:186: only scores below 0.9 are stored
+MOVING = 0.6              # zero_shot_detector.py:224: entropy < 0.6 = moving point
+
+
+def window(fnr, length, n_neighbouring_frames):
+    """Frames in the reference's buffer when frame `fnr` is scored, and the query's position (`seek`) in it
+    (zero_shot_detector.py:165-181): the window starts at the query frame until it reaches the end of the sequence."""
+    n = min(n_neighbouring_frames, length)
+    start = min(fnr, max(length - n_neighbouring_frames, 0))
+    return list(range(start, start + n)), fnr - start
+
+
+class EntropyScorer:
+    def __init__(self, grid_model, n_neighbouring_frames=15, skip_frames=1, max_neighbor_point_dist=0.3,
+                 max_neighbor_points=1000, **unused):
+        self.grid_model = grid_model
+        self.n_neighbouring_frames = int(n_neighbouring_frames)
+        self.skip = int(skip_frames) + 1
+        r = np.float32(max_neighbor_point_dist)
+        self.r2 = np.float32(r * r)                     # ball_query: radius2 = radius * radius in float32
+        self.cap = int(max_neighbor_points)
+
+    def score_sequence(self, X_list):
+        """X_list: per frame CUDA float32 [n,>=3] (`points_ref_wo_ground`).  -> per frame float64 CUDA tensor [n] of
+        entropy scores.  Every frame's grid is built once and queried by all the frames whose window contains it."""
+        L = len(X_list)
+        wins = [window(f, L, self.n_neighbouring_frames) for f in range(L)]
+        used = [w[0][::self.skip] for w in wins]                     # pointcloud_utils.py:81 idx_list[::skip]
+        counts = [torch.zeros((len(u), X_list[f].shape[0]), dtype=torch.int32, device=X_list[f].device)
+                  for f, u in enumerate(used)]
+        users = [[] for _ in range(L)]
+        for f, u in enumerate(used):
+            for col, j in enumerate(u):
+                users[j].append((f, col))
+        for j in range(L):
+            if not users[j]:
+                continue
+            self.grid_model.grid(X_list[j])
+            for f, col in users[j]:
+                self.grid_model.ball_count(X_list[f], self.r2, self.cap, out=counts[f][col])
+        out = []
+        for f in range(L):
+            frames, seek = wins[f]
+            seek_row = used[f].index(frames[seek]) if frames[seek] in used[f] else -1
+            n = X_list[f].shape[0]
+            H = torch.empty(n, dtype=torch.float64, device=X_list[f].device)
+            if len(used[f]) < 2:
+                raise NotImplementedError('entropy scores need at least two neighbouring frames')
+            check(lib.vg_entropy_scores(ptr(counts[f]), len(used[f]), n, seek_row, ptr(H), stream_ptr()), 'vg_entropy_scores')
+            out.append(H)
+        return out
+
+    @staticmethod
+    def reduce(H):
+        """zero_shot_detector.py:186-187: keep scores < 0.9 -> (values float64, indices int64) on the host."""
+        keep = torch.nonzero(H < ENTROPY_KEEP).squeeze(1)
+        return H.index_select(0, keep).cpu().numpy(), keep.cpu().numpy()
+
+
+def full_scores(n, kept_scores, kept_idx, device=None):
+    """LidarFrame.entropy_scores (lidar_frame.py:111-118): float32 [n], 1.0 where nothing was stored."""
+    e = np.ones(n, np.float32)
+    e[kept_idx] = kept_scores
+    return e if device is None else torch.from_numpy(e).to(device)
+
+
+class TwoFrameClusterer:
+    """spatial_clustering with n_frames > 1 (zero_shot_detector.py:208-242)."""
+
+    def __init__(self, cluster_model, n_frames=2, seed=0, dist_threshold=0.2):
+        self.model = cluster_model
+        self.n_frames = int(n_frames)
+        self.seed = int(seed)
+        g = np.float32(dist_threshold)                      # `dists > 0.2` on float32 squared distances (float64 compare)
+        self.gate = float(np.nextafter(g, np.float32(0)) if np.float64(g) > dist_threshold else g)
+        self._cache = {}
+
+    def reset(self):
+        self._cache = {}
+
+    def frame_part(self, f, X, ent, n_used):
+        """Rows of frame f that enter the clustering input: [x, y, z, entropy] (CUDA float32 [m,4]).
+        X: CUDA float32 [n,>=3]; ent: CUDA float32 [n] (full entropy array)."""
+        key = (f, n_used)
+        if key in self._cache:
+            return self._cache[key]
+        n = X.shape[0]
+        dev = X.device
+        m = self.model
+        m.grid(X)
+        counts = m.ball_count(X, np.float32(0.2) * np.float32(0.2), 100)             # count_neighbors_inter_frame(points, 0.2)
+        moving = ent < MOVING
+        mi = torch.nonzero(moving).squeeze(1)
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        k = int(n / n_used)
+        if k > 0:
+            keys = torch.empty(n, dtype=torch.int64, device=dev)
+            check(lib.vg_subsample_keys(self.seed, int(f), n, ptr(keys), stream_ptr()), 'vg_subsample_keys')
+            mask[torch.sort(keys, stable=True).indices[:k]] = True
+        mask &= counts >= 2
+        mask[mi] = False
+        if mi.numel():
+            mp = X.index_select(0, mi).contiguous()
+            m.grid(mp)
+            others = m.ball_count(mp, np.float32(0.1), 4) - 1       # 3 nearest OTHER moving points with d2 < 0.1 (self always hits)
+            mask[mi] = others >= 2                                   # np.sum(dists < 0.1, axis=1) > 1
+        rows = torch.nonzero(mask).squeeze(1)
+        part = torch.cat([X.index_select(0, rows)[:, :3], ent.index_select(0, rows)[:, None]], dim=1)
+        self._cache = {kk: v for kk, v in self._cache.items() if kk[0] >= f - 1}
+        self._cache[key] = part
+        return part
+
+    def used_frames(self, fnr, length):
+        return list(range(min(fnr, length - self.n_frames), min(fnr + self.n_frames, length)))
+
+    def cluster_input(self, fnr, X_list, ent_list):
+        rng = self.used_frames(fnr, len(X_list))
+        parts = []
+        for rel, f in enumerate(rng):
+            p = self.frame_part(f, X_list[f], ent_list[f], len(rng))
+            t = torch.full((p.shape[0], 1), rel * 0.1, dtype=torch.float32, device=p.device)
+            parts.append(torch.cat([p, t], dim=1))
+        return torch.cat(parts, dim=0).contiguous()
+
+    def labels(self, fnr, X_list, ent_list):
+        """-> (labels int64 [n], probabilities float64 [n]) for the points of frame fnr (host)."""
+        if len(X_list) < self.n_frames:
+            raise ValueError('sequence shorter than n_frames')
+        seq = self.cluster_input(fnr, X_list, ent_list)
+        n = X_list[fnr].shape[0]
+        m = seq.shape[0]
+        if m < 2:
+            return np.full(n, -1, np.int64), np.zeros(n)
+        lo, hi, w2 = self.model.mst(seq, dim=5)
+        lab_seq, prob_seq, _ = self.model.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), m)
+        self.model.grid(seq)
+        idx, _ = self.model.nearest(X_list[fnr], self.gate)
+        idx = idx.cpu().numpy().astype(np.int64)
+        ok = idx >= 0
+        labels = np.where(ok, lab_seq[np.maximum(idx, 0)], -1).astype(np.int64)
+        probs = np.where(ok, prob_seq[np.maximum(idx, 0)], 0.0)
+        return labels, probs

@@ -62,6 +62,29 @@ def vote(class_ids, scores, class_names_sorted):
     return win, score
 
 
+def static_from_entropy(ent_full, index, seg_off, percentile=30, min_percentile_pp_score=0.5):
+    """`Detection.static = not filter_by_ephemeral_score(entropy[cluster_points_index], ...)` for every cluster
+    (lidar_frame.py:238-243; cluster_utils.py:62-64): static <=> np.percentile(scores, percentile) > min score.
+    np.percentile(method='linear') on a float32 array: virtual index t*(n-1), neighbours a <= b, float64
+    a + (b-a)*g for g < 0.5 else b - (b-a)*(1-g).  ent_full float32 [M]; packed cluster index / offsets.  -> bool [C]."""
+    C = len(seg_off) - 1
+    if C == 0:
+        return np.zeros(0, bool)
+    vals = np.asarray(ent_full, np.float32)[index]
+    seg_id = np.repeat(np.arange(C), np.diff(seg_off))
+    order = np.lexsort((vals, seg_id))
+    sv = vals[order].astype(np.float64)
+    n = np.diff(seg_off).astype(np.int64)
+    virt = (percentile / 100.0) * (n - 1)
+    lo = np.floor(virt).astype(np.int64)
+    g = virt - lo
+    hi = np.minimum(lo + 1, n - 1)
+    a, b = sv[seg_off[:-1] + lo], sv[seg_off[:-1] + hi]
+    d = b - a
+    q = np.where(g >= 0.5, b - d * (1 - g), a + d * g)
+    return q > min_percentile_pp_score
+
+
 class FrameState:
     def __init__(self, fnr, pose, ref_pose):
         self.fnr = fnr
@@ -72,6 +95,9 @@ class FrameState:
         self.ground_point_indices = None
         self.n_points = 0
         self.ground_plane_model_ref = None
+        self.entropy_scores = None                     # kept values (< 0.9), float64   (lidar_frame.py:256-258)
+        self.entropy_indices = None                    # their indices into points_ref_wo_ground
+        self.n_nonground = 0
         self.clear_detections()
 
     def clear_detections(self):
@@ -137,6 +163,9 @@ class FrameState:
         frame = {'_detections': [self.detection_dict(c) for c in range(self.n_detections)]}
         if self.ground_point_indices is not None:
             frame['_ground_point_indices'] = self.ground_point_indices
+        if self.entropy_scores is not None:
+            frame['_entropy_scores'] = self.entropy_scores
+            frame['_entropy_indices'] = self.entropy_indices
         frame['_gt_cluster_mapping'] = {}
         return frame
 
@@ -144,6 +173,9 @@ class FrameState:
         """lidar_frame.py:124-147 + objects.py:136-142: restore from a serialised frame dict."""
         if '_ground_point_indices' in data:
             self.ground_point_indices = np.asarray(data['_ground_point_indices'])
+        if data.get('_entropy_scores') is not None:
+            self.entropy_scores = np.asarray(data['_entropy_scores'])
+            self.entropy_indices = np.asarray(data['_entropy_indices'])
         dets = data.get('_detections')
         if not dets:
             return

@@ -48,11 +48,40 @@ class HDBSCAN:
             lib.vg_cluster_destroy(h)
             self._h = None
 
+    # ---- fixed-radius queries on the same cell grid -----------------------------------
+    def grid(self, T, stream=None):
+        """Build the handle's cell grid over target points T (CUDA float32 [n,>=3]); valid until the next grid()/mst()."""
+        assert T.is_cuda and T.dtype == torch.float32 and (T.shape[0] == 0 or T.stride(1) == 1)
+        check(lib.vg_cluster_grid(self._h, ptr(T), T.shape[0], T.stride(0) if T.shape[0] else 3, stream_ptr(stream)),
+              'vg_cluster_grid')
+        self._grid_ref = T                      # the kernels read the handle's own sorted copy; kept for clarity only
+
+    def ball_count(self, Q, r2, cap, out=None, stream=None):
+        """-> int32 [nq]: min(cap, #{grid points with float32 d2 < r2}) per query row of Q (CUDA float32 [nq,>=3])."""
+        assert Q.is_cuda and Q.dtype == torch.float32 and (Q.shape[0] == 0 or Q.stride(1) == 1)
+        nq = Q.shape[0]
+        if out is None:
+            out = torch.empty(nq, dtype=torch.int32, device=Q.device)
+        check(lib.vg_cluster_ball_count(self._h, ptr(Q), nq, Q.stride(0) if nq else 3, float(np.float32(r2)), int(cap), ptr(out),
+                                        stream_ptr(stream)), 'vg_cluster_ball_count')
+        return out
+
+    def nearest(self, Q, max_d2, stream=None):
+        """-> (idx int32 [nq] row of the grid's point array or -1, d2 float32 [nq]) of the nearest grid point with
+        float32 d2 <= max_d2."""
+        assert Q.is_cuda and Q.dtype == torch.float32 and (Q.shape[0] == 0 or Q.stride(1) == 1)
+        nq = Q.shape[0]
+        idx = torch.empty(nq, dtype=torch.int32, device=Q.device)
+        d2 = torch.empty(nq, dtype=torch.float32, device=Q.device)
+        check(lib.vg_cluster_nearest(self._h, ptr(Q), nq, Q.stride(0) if nq else 3, float(np.float32(max_d2)), ptr(idx), ptr(d2),
+                                     stream_ptr(stream)), 'vg_cluster_nearest')
+        return idx, d2
+
     # ---- GPU stage ---------------------------------------------------------------------------------
-    def mst(self, X, want_core=False, stream=None):
-        """X: CUDA float32 [n,>=3].  -> (lo int32[n-1], hi int32[n-1], w2 float64[n-1]) CUDA, sorted by w2
-        (+ squared core distances in input order)."""
-        assert X.is_cuda and X.dtype == torch.float32 and X.stride(1) == 1
+    def mst(self, X, want_core=False, stream=None, dim=3):
+        """X: CUDA float32 [n,>=dim]; the first `dim` (3..5) columns are the clustering space.
+        -> (lo int32[n-1], hi int32[n-1], w2 float64[n-1]) CUDA, sorted by w2 (+ squared core distances in input order)."""
+        assert X.is_cuda and X.dtype == torch.float32 and X.stride(1) == 1 and 3 <= dim <= 5 and X.shape[1] >= dim
         n = X.shape[0]
         m = max(n - 1, 0)
         dev = X.device
@@ -61,8 +90,8 @@ class HDBSCAN:
         w2 = torch.empty(m, dtype=torch.float64, device=dev)
         core2 = torch.empty(n, dtype=torch.float64, device=dev) if want_core else None
         rounds = ctypes.c_int32(0)
-        check(lib.vg_cluster_mst(self._h, ptr(X), n, X.stride(0), self.min_samples, ptr(core2), ptr(lo), ptr(hi), ptr(w2),
-                                 ctypes.byref(rounds), stream_ptr(stream)), 'vg_cluster_mst')
+        check(lib.vg_cluster_mst_nd(self._h, ptr(X), n, X.stride(0), int(dim), self.min_samples, ptr(core2), ptr(lo), ptr(hi),
+                                    ptr(w2), ctypes.byref(rounds), stream_ptr(stream)), 'vg_cluster_mst_nd')
         self.n_rounds_ = rounds.value
         return (lo, hi, w2, core2) if want_core else (lo, hi, w2)
 
@@ -77,17 +106,25 @@ class HDBSCAN:
                                        p(labels), p(probs), ctypes.byref(nc)), 'vg_hdbscan_tree_host')
         return labels, probs, nc.value
 
-    def fit(self, X):
+    def fit(self, X, dim=None):
+        """numpy input: every column is a clustering coordinate, like the library (3 = `points_ref_wo_ground[..., :3]`,
+        zero_shot_detector.py:246-248; 5 = the two-frame `points_seq`, :239-241).  CUDA tensor input (fused pipeline):
+        point rows, the first `dim` (default 3) columns are used."""
         if isinstance(X, np.ndarray):
-            Xd = torch.from_numpy(np.ascontiguousarray(X[:, :3], dtype=np.float32)).to(self.device)
+            if dim is None:
+                dim = X.shape[1]
+            if not 3 <= dim <= 5:
+                raise NotImplementedError('3 to 5 clustering coordinates (x, y, z first)')
+            Xd = torch.from_numpy(np.ascontiguousarray(X[:, :dim], dtype=np.float32)).to(self.device)
         else:
             Xd = X if (X.dtype == torch.float32 and X.stride(1) == 1) else X.float().contiguous()
+            dim = 3 if dim is None else dim
         n = Xd.shape[0]
         if n < 2:
             self.labels_ = np.full(n, -1, np.int64)
             self.probabilities_ = np.zeros(n)
             return self
-        lo, hi, w2 = self.mst(Xd)
+        lo, hi, w2 = self.mst(Xd, dim=dim)
         labels, probs, _ = self.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), n)
         self.labels_ = labels.astype(np.int64)
         self.probabilities_ = probs

@@ -20,7 +20,7 @@ import torch
 from scipy.spatial.transform import Rotation
 
 from ._lib import lib, ptr, stream_ptr, check
-from .frame_state import FrameState, pack_clusters, vote
+from .frame_state import FrameState, pack_clusters, vote, static_from_entropy
 from . import patchworkpp as gpw
 from .hdbscan import HDBSCAN
 from .projection import RealisticProjection, VIEWS_4, VIEWS_6
@@ -267,6 +267,22 @@ class PseudoLabelPipeline:
         return out
 
     # ---------------------------------------------------------------------------------------------
+    def prepare(self, points, pose, ref_pose, fnr=0, state=None, mask=None):
+        """[A] + [B1]: ground mask, reference-frame transform, non-ground gather.
+        -> (FrameState, points_ref, points_ref_wo_ground, ground indices), all CUDA."""
+        fs = state if state is not None else FrameState(fnr, pose, ref_pose)
+        d_pts = self.upload(points)
+        fs.n_points = d_pts.shape[0]
+        if mask is None:
+            mask = self.ground(d_pts)
+        d_ref = self.to_ref(d_pts, fs.transform_to_ref)
+        ng = torch.nonzero(mask == 0).squeeze(1)
+        gidx = torch.nonzero(mask).squeeze(1)
+        d_X = d_ref.index_select(0, ng).contiguous()
+        fs.ground_point_indices = gidx.cpu().numpy()
+        fs.n_nonground = d_X.shape[0]
+        return fs, d_ref, d_X, gidx
+
     def process_frame(self, points, pose, ref_pose, fnr=0, state=None, timing=False, mask=None):
         """One frame through [A]-[F].  points: (N,>=4) float32 numpy/CUDA [x,y,z,intensity,...].
         Returns (FrameState, result dict {'boxes_lidar','name','score','moving'})."""
@@ -279,23 +295,60 @@ class PseudoLabelPipeline:
             return time.perf_counter()
 
         t0 = time.perf_counter()
-        fs = state if state is not None else FrameState(fnr, pose, ref_pose)
-        d_pts = self.upload(points)
-        fs.n_points = d_pts.shape[0]
         if mask is None:
+            d_pts = self.upload(points)
             mask = self.ground(d_pts)
-        t0 = tick('ground', t0)
-        d_ref = self.to_ref(d_pts, fs.transform_to_ref)
-        ng = torch.nonzero(mask == 0).squeeze(1)
-        gidx = torch.nonzero(mask).squeeze(1)
-        d_X = d_ref.index_select(0, ng).contiguous()
-        fs.ground_point_indices = gidx.cpu().numpy()
+            t0 = tick('ground', t0)
+            points = d_pts
+        else:
+            t['ground'] = 0.0
+        fs, d_ref, d_X, gidx = self.prepare(points, pose, ref_pose, fnr=fnr, state=state, mask=mask)
         t0 = tick('to_ref', t0)
         labels, probs = self.cluster(d_X)
         t0 = tick('cluster', t0)
+        return self.label(fs, d_ref, d_X, gidx, labels, probs, t=t, t0=t0, tick=tick)
+
+    def process_sequence(self, frames, poses, ref_pose, entropy_args=None, n_frames=2, seed=0, first_fnr=0):
+        """The reference's DEFAULT stage order over a whole sequence (preprocessing.yaml:50-68):
+        mask_ground_points -> calculate_entropy_scores (sliding window over the neighbouring frames) ->
+        spatial_clustering with n_frames frames (5-D HDBSCAN + nearest-label transfer) -> filters / classification /
+        boxes per frame as in `process_frame`.  `Detection.static` comes from the clusters' entropy percentile.
+        Returns [(FrameState, result dict)] in frame order."""
+        from .entropy import EntropyScorer, TwoFrameClusterer, full_scores
+        self.new_sequence()
+        prepared = []
+        for i, pts in enumerate(frames):
+            prepared.append(self.prepare(pts, poses[i], ref_pose, fnr=first_fnr + i))
+        X_list = [p[2] for p in prepared]
+        scorer = EntropyScorer(self.cluster_model, **(entropy_args or {}))
+        H_list = scorer.score_sequence(X_list)
+        ent_list = []
+        for (fs, _, d_X, _), H in zip(prepared, H_list):
+            fs.entropy_scores, fs.entropy_indices = scorer.reduce(H)
+            ent_list.append(full_scores(d_X.shape[0], fs.entropy_scores, fs.entropy_indices, device=self.device))
+        two = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed) if n_frames > 1 else None
+        out = []
+        for i, (fs, d_ref, d_X, gidx) in enumerate(prepared):
+            if two is not None and len(frames) >= n_frames:
+                labels, probs = two.labels(i, X_list, ent_list)
+            else:
+                labels, probs = self.cluster(d_X)
+            out.append(self.label(fs, d_ref, d_X, gidx, labels, probs, entropy=ent_list[i].cpu().numpy()))
+        return out
+
+    def label(self, fs, d_ref, d_X, gidx, labels, probs, entropy=None, t=None, t0=None, tick=None):
+        """Everything after clustering: detections, static flags, filters, classification, boxes, results."""
+        t = {} if t is None else t
+        if tick is None:
+            tick = lambda name, t0: time.perf_counter()
+            t0 = time.perf_counter()
         ids, index, seg = pack_clusters(labels, probs, self.prob_threshold)
         fs.set_clusters(ids, index, seg)
         C = len(ids)
+        if entropy is not None and C:
+            ecfg = _get(_get(self.cfg, 'clustering'), 'entropy_score_filter', None)
+            fs.static = static_from_entropy(entropy, index, seg, percentile=float(_get(ecfg, 'percentile', 30) if ecfg else 30),
+                                            min_percentile_pp_score=float(_get(ecfg, 'min_percentile_pp_score', 0.5) if ecfg else 0.5))
         result = {'boxes_lidar': np.zeros((0, 7)), 'name': np.array([]), 'score': np.array([]), 'moving': np.array([])}
         if C == 0:
             self.timings = t

@@ -138,3 +138,56 @@ def make_poses(n_frames, step=0.5, seed=0):
         y += step * s
         yaw += yaw_rate
     return poses
+
+
+def make_sequence(seed=0, n_frames=6, n_points=20_000, n_objects=12, moving_frac=0.35, ground_frac=0.45,
+                  clutter_frac=0.03, step=0.5):
+    """A sequence over ONE world: static objects stay put, a fraction moves along its heading (0.3-1.2 m per frame),
+    the ego vehicle follows `make_poses`.  Every frame re-samples the surfaces (a LiDAR never hits the same spot
+    twice), so static structure keeps a similar neighbour count from frame to frame (entropy score near 1) and
+    moving objects do not (low score) -- the signal `calculate_entropy_scores` measures.
+    -> (list of (n_points,5) float32 frames in the VEHICLE frame, list of 4x4 poses)."""
+    rng = np.random.default_rng(seed + 7919)
+    poses = make_poses(n_frames, step=step, seed=seed)
+    freq = np.array([t[2] for t in OBJECT_TYPES])
+    kinds = rng.choice(len(OBJECT_TYPES), size=n_objects, p=freq / freq.sum())
+    rr = rng.uniform(5, 45, size=n_objects)
+    tt = rng.uniform(0, 2 * np.pi, size=n_objects)
+    yaw = rng.uniform(0, 2 * np.pi, size=n_objects)
+    centers = np.stack([rr * np.cos(tt), rr * np.sin(tt)], 1)              # world
+    movable = np.array([OBJECT_TYPES[k][0] in ('car', 'pedestrian', 'cyclist', 'truck') for k in kinds])
+    moving = movable & (rng.uniform(size=n_objects) < moving_frac / max(movable.mean(), 1e-9))
+    speed = np.where(moving, rng.uniform(0.3, 1.2, size=n_objects), 0.0)
+    n_ground = int(n_points * ground_frac)
+    n_clutter = int(n_points * clutter_frac)
+    n_obj_pts = n_points - n_ground - n_clutter
+    clutter_w = np.stack([rng.uniform(-60, 60, n_clutter), rng.uniform(-60, 60, n_clutter), rng.uniform(0.3, 4, n_clutter)], 1)
+    rings = np.geomspace(2.5, 75.0, 64)
+    frames = []
+    for f in range(n_frames):
+        T = poses[f]
+        Ti = np.linalg.inv(T)
+        ego_yaw = np.arctan2(T[1, 0], T[0, 0])
+        ring_of = rng.integers(0, 64, size=n_ground)
+        r = rings[ring_of] * (1 + rng.normal(0, 0.002, size=n_ground))
+        th = rng.uniform(0, 2 * np.pi, size=n_ground)
+        ground = np.stack([r * np.cos(th), r * np.sin(th), rng.normal(0, 0.03, size=n_ground)], 1)
+        cw = centers + (speed * f)[:, None] * np.stack([np.cos(yaw), np.sin(yaw)], 1)
+        ce = (np.c_[cw, np.zeros(n_objects), np.ones(n_objects)] @ Ti.T)[:, :2]
+        dist2 = np.maximum((ce ** 2).sum(1), 9.0)
+        weights = np.array([(OBJECT_TYPES[k][1][0] + OBJECT_TYPES[k][1][1]) * OBJECT_TYPES[k][1][2] for k in kinds]) / dist2
+        cnt = np.maximum(40, np.floor(weights / weights.sum() * n_obj_pts)).astype(int)
+        while cnt.sum() > n_obj_pts:
+            cnt[np.argmax(cnt)] -= min(cnt.sum() - n_obj_pts, cnt.max() - 40)
+        cnt[np.argmax(cnt)] += n_obj_pts - cnt.sum()
+        objs = [_box_surface_points(rng, int(cnt[i]), (ce[i, 0], ce[i, 1], OBJECT_TYPES[k][1][2] / 2 + 0.02),
+                                    OBJECT_TYPES[k][1], yaw[i] - ego_yaw) for i, k in enumerate(kinds)]
+        cl = (np.c_[clutter_w[:, :2], np.zeros(n_clutter), np.ones(n_clutter)] @ Ti.T)[:, :2]
+        clutter = np.c_[cl + rng.normal(0, 0.01, size=cl.shape), clutter_w[:, 2]]
+        xyz = np.concatenate([ground] + objs + [clutter])
+        xyz = xyz[rng.permutation(len(xyz))]
+        pts = np.zeros((len(xyz), 5), dtype=np.float32)
+        pts[:, :3] = xyz
+        pts[:, 3] = rng.uniform(0, 1, size=len(xyz))
+        frames.append(pts)
+    return frames, poses
