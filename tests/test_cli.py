@@ -16,8 +16,14 @@ OVR = ['dataset.SYNTHETIC.frames_per_sequence=4', 'dataset.SYNTHETIC.points_per_
        'device.max_points=24000', 'paths.clip_model=/nonexistent']
 
 
-def _load(root, seq='synthetic_train_0000'):
-    stages = 'mask_ground_points_spatial_clustering_filter_detections_classification_fit_bounding_boxes_simple_evaluate_sequence'
+DEFAULT_STAGES = ['mask_ground_points', 'calculate_entropy_scores', 'spatial_clustering', 'filter_detections', 'track_clusters',
+                  'classification', 'fit_bounding_boxes_simple', 'propagate_labels', 'evaluate_sequence']      # reference default
+SINGLE_STAGES = ['mask_ground_points', 'spatial_clustering', 'filter_detections', 'classification', 'fit_bounding_boxes_simple',
+                 'evaluate_sequence']
+
+
+def _load(root, seq='synthetic_train_0000', stage_list=DEFAULT_STAGES):
+    stages = '_'.join(stage_list)
     with open(f'{root}/preprocessed_data/results/vilgod_mi355x/{stages}/{seq}.pkl', 'rb') as f:
         res = pickle.load(f)
     with open(f'{root}/preprocessed_data/results/vilgod_mi355x/{stages}/{seq}_indices.pkl', 'rb') as f:
@@ -41,21 +47,29 @@ def test_cli_single_process_and_resume(cuda, tmp_path):
         assert len(fr['name']) == len(fr['score']) == len(fr['moving']) == len(fr['boxes_lidar'])
         assert set(fr['name']) <= {'Vehicle', 'Pedestrian', 'Cyclist'}
     key = 'clip_a_point_representation_of_a'
+    n_moving = 0
     for st in state:
-        assert set(st) >= {'_detections', '_ground_point_indices', '_gt_cluster_mapping'}
+        assert set(st) >= {'_detections', '_ground_point_indices', '_entropy_scores', '_entropy_indices', '_gt_cluster_mapping'}
+        assert len(st['_entropy_scores']) == len(st['_entropy_indices']) and np.all(st['_entropy_scores'] < 0.9)
+        n_moving += sum(not d['static'] for d in st['_detections'])
         for d in st['_detections']:
             assert {'cluster_id', 'valid', 'static', 'gt_assigned', 'cluster_points_index', 'tid'} <= set(d)
             if d['valid']:
                 assert len(d['_bounding_box']) == 7 and key in d['object_class'] and len(d['object_class_predictions'][key]) == 4
     assert sum(len(fr['name']) for fr in out) > 0
+    assert n_moving > 0                                   # the synthetic world has moving objects: some clusters are not static
     # second run: every stage finds its output in the sequence pickle and skips (zero_shot_detector.py resume logic)
-    os.remove(f'{root}/preprocessed_data/results/vilgod_mi355x/' + '_'.join(
-        ['mask_ground_points', 'spatial_clustering', 'filter_detections', 'classification', 'fit_bounding_boxes_simple',
-         'evaluate_sequence']) + '/synthetic_train_0000.pkl')
+    os.remove(f'{root}/preprocessed_data/results/vilgod_mi355x/' + '_'.join(DEFAULT_STAGES) + '/synthetic_train_0000.pkl')
     res2 = preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}', 'pipeline.6.args.force=False'] + OVR)
     out2, _, _ = _load(root)
     for a, b in zip(out, out2):
         assert np.array_equal(a['name'], b['name']) and np.allclose(a['boxes_lidar'], b['boxes_lidar'])
+    # the single-frame preset (no entropy stage, n_frames=1) on independent frames
+    root3 = str(tmp_path / 'd3')
+    preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root3}', 'pipeline_active=[' + ','.join(SINGLE_STAGES) + ']',
+                          'pipeline.2.args.n_frames=1', 'dataset.SYNTHETIC.coherent=False'] + OVR)
+    out3, idx3, state3 = _load(root3, stage_list=SINGLE_STAGES)
+    assert len(out3) == 4 and '_entropy_scores' not in state3[0] and sum(len(fr['name']) for fr in out3) > 0
 
 
 @pytest.mark.gpu
@@ -80,6 +94,8 @@ def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
         assert np.array_equal(x['boxes_lidar'], y['boxes_lidar']) and np.array_equal(x['score'], y['score'])
     for x, y in zip(sa, sb):
         assert np.array_equal(x['_ground_point_indices'], y['_ground_point_indices'])
+        assert np.array_equal(x['_entropy_indices'], y['_entropy_indices']) and np.array_equal(x['_entropy_scores'], y['_entropy_scores'])
         assert len(x['_detections']) == len(y['_detections'])
         for d, e in zip(x['_detections'], y['_detections']):
             assert np.array_equal(d['cluster_points_index'], e['cluster_points_index']) and d['valid'] == e['valid']
+            assert d['static'] == e['static']

@@ -70,3 +70,40 @@ def test_pipeline_fp16_full_size_frame_runs(cuda):
         assert fs.n_detections > 20 and fs.valid.sum() > 10
         assert 0.35 < len(fs.ground_point_indices) / 150_000 < 0.6
         assert np.isfinite(res['boxes_lidar']).all() and (res['score'] > 0).all()
+
+
+@pytest.mark.gpu
+def test_sequence_pipeline_matches_oracle(cuda):
+    """SURVEY 8f N1, the reference's default stage order on a short coherent sequence: ground -> entropy scores ->
+    two-frame clustering + label transfer -> filters -> classification -> boxes; GPU pipeline vs the chained oracle.
+    Exact: ground set, kept entropy indices, cluster membership, static flags, valid flags; names as in the 1-frame test."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline, default_preprocessor_cfg
+    from oracle.pipeline_oracle import OraclePipeline
+    cfg = default_preprocessor_cfg()
+    frames, poses = synthetic.make_sequence(seed=2, n_frames=4, n_points=12_000, n_objects=8)
+    pipe = PseudoLabelPipeline(cfg, device=cuda, vit_dtype='f32', max_points=25_000, clip_model_path='/nonexistent')
+    ent_args = dict(n_neighbouring_frames=3, skip_frames=0)
+    got = pipe.process_sequence(frames, poses, poses[0], entropy_args=ent_args, n_frames=2, seed=0)
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    text = cw.synthetic_text_features(0, 24, 512)
+    orc = OraclePipeline(wd, text, cfg['clip']['class_list'], cfg['clip']['class_mapping'])
+    want = orc.process_sequence(frames, poses, poses[0], n_neighbouring_frames=3, skip_frames=0, n_frames=2, seed=0)
+    n_static = n_moving = 0
+    for (fs, res), o in zip(got, want):
+        assert np.array_equal(np.sort(fs.ground_point_indices), o['ground_idx'])
+        assert np.array_equal(fs.entropy_indices, o['entropy_indices'])
+        assert np.allclose(fs.entropy_scores, o['entropy_scores'], rtol=0, atol=1e-12)
+        assert [int(c) for c in fs.cluster_ids] == [c for c, _ in o['dets']]
+        for c, (_, idx) in enumerate(o['dets']):
+            assert np.array_equal(fs.cluster_index(c), idx)
+        assert np.array_equal(fs.static, o['static'])
+        assert np.array_equal(fs.valid, o['valid'])
+        n_static += int(fs.static.sum()); n_moving += int((~fs.static).sum())
+        rows = np.flatnonzero(fs.valid)
+        if len(rows):
+            e = fs.cls[pipe.cls_key]
+            agree = sum(str(e['name'][r]) == n for r, n in zip(rows, o['names']))
+            assert agree >= len(rows) - 1
+        ser = fs.serialize
+        assert list(ser)[:4] == ['_detections', '_ground_point_indices', '_entropy_scores', '_entropy_indices']
+    assert n_static > 0 and n_moving > 0

@@ -26,6 +26,10 @@ class SyntheticDataset:
         self.objects_per_frame = int(_get(syn, 'objects_per_frame', 60))
         self.step = float(_get(syn, 'step', 0.5))
         self.seed = int(_get(syn, 'seed', 0))
+        # coherent: one world per sequence (static scene + moving objects + ego motion) -- what the entropy scores and
+        # the two-frame clustering need; False: independent frames (`synthetic.make_frame`)
+        self.coherent = bool(_get(syn, 'coherent', True))
+        self._frames = None
         self.start_sequence, self.end_sequence = int(start_sequence), int(end_sequence)
         self.sequence_name = None
         self.sequence_infos = []
@@ -48,12 +52,18 @@ class SyntheticDataset:
             self.sequence_infos = [{'pose': p, 'frame_id': f'{self.sequence_name}_{i:03d}'} for i, p in enumerate(poses)]
             base = sid * self.frames_per_sequence
             self.sequence_indices = list(range(base, base + self.frames_per_sequence))
+            self._frames = None
             yield self.sequence_name
 
     def get_lidar_points(self, fnr):
         """(N,5) float32 [x,y,z,intensity,elongation] in the vehicle frame."""
-        return synthetic.make_frame(self.seed + self._seq_id * 100_003 + fnr, self.points_per_frame,
-                                    n_objects=self.objects_per_frame)
+        if not self.coherent:
+            return synthetic.make_frame(self.seed + self._seq_id * 100_003 + fnr, self.points_per_frame,
+                                        n_objects=self.objects_per_frame)
+        if self._frames is None:
+            self._frames, _ = synthetic.make_sequence(self.seed + self._seq_id, self.frames_per_sequence, self.points_per_frame,
+                                                      n_objects=self.objects_per_frame, step=self.step)
+        return self._frames[fnr]
 
     def get_annos(self, fnr):
         return {'gt_names': np.array([]), 'moving': np.array([], dtype=bool), 'gt_boxes_lidar': np.zeros((0, 7))}

@@ -41,26 +41,35 @@ class EntropyScorer:
         self.r2 = np.float32(r * r)                     # ball_query: radius2 = radius * radius in float32
         self.cap = int(max_neighbor_points)
 
-    def score_sequence(self, X_list):
-        """X_list: per frame CUDA float32 [n,>=3] (`points_ref_wo_ground`).  -> per frame float64 CUDA tensor [n] of
-        entropy scores.  Every frame's grid is built once and queried by all the frames whose window contains it."""
+    def frames_needed(self, queries, length):
+        """Frames whose points must be resident to score the `queries`."""
+        need = set()
+        for f in queries:
+            need.update(window(f, length, self.n_neighbouring_frames)[0][::self.skip])
+            need.add(f)
+        return sorted(need)
+
+    def score_sequence(self, X_list, queries=None):
+        """X_list: per frame CUDA float32 [n,>=3] (`points_ref_wo_ground`; entries of frames that are not needed may be
+        None).  -> {fnr: float64 CUDA tensor [n] of entropy scores} for the `queries` (default: every frame; then a
+        list).  Every frame's grid is built once and queried by all the frames whose window contains it."""
         L = len(X_list)
-        wins = [window(f, L, self.n_neighbouring_frames) for f in range(L)]
-        used = [w[0][::self.skip] for w in wins]                     # pointcloud_utils.py:81 idx_list[::skip]
-        counts = [torch.zeros((len(u), X_list[f].shape[0]), dtype=torch.int32, device=X_list[f].device)
-                  for f, u in enumerate(used)]
-        users = [[] for _ in range(L)]
-        for f, u in enumerate(used):
-            for col, j in enumerate(u):
-                users[j].append((f, col))
-        for j in range(L):
-            if not users[j]:
-                continue
+        as_list = queries is None
+        queries = list(range(L)) if queries is None else sorted(queries)
+        wins = {f: window(f, L, self.n_neighbouring_frames) for f in queries}
+        used = {f: wins[f][0][::self.skip] for f in queries}         # pointcloud_utils.py:81 idx_list[::skip]
+        counts = {f: torch.zeros((len(used[f]), X_list[f].shape[0]), dtype=torch.int32, device=X_list[f].device)
+                  for f in queries}
+        users = {}
+        for f in queries:
+            for col, j in enumerate(used[f]):
+                users.setdefault(j, []).append((f, col))
+        for j in sorted(users):
             self.grid_model.grid(X_list[j])
             for f, col in users[j]:
                 self.grid_model.ball_count(X_list[f], self.r2, self.cap, out=counts[f][col])
-        out = []
-        for f in range(L):
+        out = {}
+        for f in queries:
             frames, seek = wins[f]
             seek_row = used[f].index(frames[seek]) if frames[seek] in used[f] else -1
             n = X_list[f].shape[0]
@@ -68,8 +77,8 @@ class EntropyScorer:
             if len(used[f]) < 2:
                 raise NotImplementedError('entropy scores need at least two neighbouring frames')
             check(lib.vg_entropy_scores(ptr(counts[f]), len(used[f]), n, seek_row, ptr(H), stream_ptr()), 'vg_entropy_scores')
-            out.append(H)
-        return out
+            out[f] = H
+        return [out[f] for f in range(L)] if as_list else out
 
     @staticmethod
     def reduce(H):

@@ -5,14 +5,15 @@ Same contract (SURVEY §8b "Stage dispatch"): `process()` walks `cfg.pipeline_ac
 `cfg.pipeline` and calls `getattr(self, name)(**args)`; unknown names only warn (zero_shot_detector.py:62-68).
 Stage names, keyword arguments, skip-if-already-done rules and the two pickle families are the reference's:
   mask_ground_points(min_range, z_offset)                          :129-151
-  spatial_clustering(force, n_frames)            (n_frames = 1)     :197-259
+  calculate_entropy_scores(n_neighbouring_frames, skip_frames, ...) :153-195
+  spatial_clustering(force, n_frames)            (n_frames >= 1)    :197-259
   filter_detections(force)                                          :261-297
   classification(image_size, key, aggregation, valid_only, ...)     :329-420
   fit_bounding_boxes_simple(method, force, valid_only, ...)         :422-462 (static branch)
   evaluate_sequence(modes, classification_key, ...)                 :826-857
   sync_lidar_frames(mode)                                           :105-123
-`calculate_entropy_scores`, `track_clusters`, `propagate_labels` and the 2-frame clustering branch are the
-"next" rows N1/N2 of SURVEY §8f: accepted by name, skipped with a warning.
+SURVEY §8f row N1 (entropy scores, two-frame clustering -- the shipped default) is built; the N2 stages
+`track_clusters` and `propagate_labels` are accepted by name and skipped with a warning.
 
 Execution differs on purpose: per-frame device data (points, ref-frame points, non-ground subset, cluster lists)
 stays resident in HBM across stages (a 199-frame Waymo segment is ~0.6 GB), every stage calls the HIP kernels
@@ -52,6 +53,7 @@ class ZeroShotDetector:
         self.lidar_frame_list = []
         self._dev = {}                                   # fnr -> dict of device tensors kept across stages
         self._scores = {}                                # fnr -> [n_crops, K] class probabilities
+        self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
         self.init_lidar_frames()
         try:
             self.sync_lidar_frames(mode='load')
@@ -137,20 +139,99 @@ class ZeroShotDetector:
             fs.ground_point_indices = torch.nonzero(mask).squeeze(1).cpu().numpy()
         self.sync_lidar_frames()
 
+    def _entropy_full(self, fnr):
+        """LidarFrame.entropy_scores (lidar_frame.py:111-118) on the device, or None before calculate_entropy_scores."""
+        d = self._dev.setdefault(fnr, {})
+        if 'ent' not in d:
+            kept = self._ent.get(fnr)
+            if kept is None:
+                fs = self.lidar_frame_list[fnr]
+                kept = (fs.entropy_scores, fs.entropy_indices) if fs.entropy_scores is not None else None
+            if kept is None:
+                return None
+            from .entropy import full_scores
+            n = self._ref_and_nonground(fnr)[1].shape[0]
+            d['ent'] = full_scores(n, kept[0], kept[1], device=self.pipe.device)
+        return d['ent']
+
+    def calculate_entropy_scores(self, n_neighbouring_frames, **kwargs):
+        """zero_shot_detector.py:153-195.  Every rank scores its own frames plus the neighbours its two-frame
+        clustering will read; the sliding 15-frame buffer of the reference becomes "each frame's grid is built once
+        and queried by every frame whose window contains it"."""
+        from .entropy import EntropyScorer, TwoFrameClusterer
+        if all(f.entropy_scores is not None for f in self.lidar_frame_list) and not kwargs.get('force', False):
+            return
+        if any(f.ground_point_indices is None for f in self.lidar_frame_list):
+            raise RuntimeError('calculate_entropy_scores needs mask_ground_points first (points_ref_wo_ground)')
+        include_ground = kwargs.get('include_ground_points', False)
+        scorer = EntropyScorer(self.pipe.cluster_model, n_neighbouring_frames=n_neighbouring_frames,
+                               **{k: v for k, v in kwargs.items() if k in ('skip_frames', 'max_neighbor_point_dist', 'max_neighbor_points')})
+        cl = [t for t in self.cfg.pipeline if t['name'] == 'spatial_clustering']
+        n_frames = (cl[0]['args'] or {}).get('n_frames', 1) if cl else 1
+        queries = set(self.my_frames)
+        if n_frames > 1 and self.lenght >= n_frames:
+            two = TwoFrameClusterer(self.pipe.cluster_model, n_frames=n_frames)
+            for f in self.my_frames:
+                queries.update(two.used_frames(f, self.lenght))
+        X_list = [None] * self.lenght
+        for f in scorer.frames_needed(queries, self.lenght):
+            ref, X = self._ref_and_nonground(f)
+            X_list[f] = ref if include_ground else X
+        if include_ground:
+            raise NotImplementedError('include_ground_points: scores would index points_ref, which nothing downstream reads')
+        H = scorer.score_sequence(X_list, queries=queries)
+        mine = set(self.my_frames)
+        for f, h in H.items():
+            kept = scorer.reduce(h)
+            self._ent[f] = kept
+            if f in mine:
+                self.lidar_frame_list[f].entropy_scores, self.lidar_frame_list[f].entropy_indices = kept
+            self._dev.get(f, {}).pop('ent', None)
+        for f in range(self.lenght):                      # halo frames: keep X only where clustering will read it
+            if f not in queries:
+                self._dev.pop(f, None)
+        self.sync_lidar_frames()
+
     def spatial_clustering(self, **kwargs):
+        """zero_shot_detector.py:197-256: n_frames == 1 clusters points_ref_wo_ground[..., :3]; n_frames > 1 (the shipped
+        default, preprocessing.yaml:68) clusters the entropy-guided 5-D union of n_frames frames and transfers the labels
+        to the frame's points by nearest neighbour.  Either way `Detection.static` comes from the entropy scores when
+        they exist (lidar_frame.py:238-243)."""
+        from .entropy import TwoFrameClusterer
+        from .frame_state import static_from_entropy
         n_frames = kwargs.get('n_frames', 1)
-        if n_frames > 1:
-            self.logger.warning('spatial_clustering: n_frames > 1 (entropy-guided multi-frame clustering, SURVEY §8f N1) '
-                                'is not built yet -- using the single-frame branch (zero_shot_detector.py:245-250)')
         force = kwargs.get('force', False)
+        two = None
+        if n_frames > 1:
+            if self.lenght < n_frames:
+                raise RuntimeError(f'spatial_clustering: n_frames={n_frames} but the sequence has {self.lenght} frames')
+            dev = self.cfg.get('device', {}) if hasattr(self.cfg, 'get') else {}
+            two = TwoFrameClusterer(self.pipe.cluster_model, n_frames=n_frames, seed=int(dev.get('subsample_seed', 0)))
+        ecfg = self.cfg.preprocessor.clustering.get('entropy_score_filter', None) \
+            if hasattr(self.cfg.preprocessor.clustering, 'get') else None
         updated = False
         for fnr in self.my_frames:
             fs = self.lidar_frame_list[fnr]
             if fs.ground_point_indices is None or (fs.n_detections > 0 and not force):
                 continue
             _, X = self._ref_and_nonground(fnr)
-            labels, probs = self.pipe.cluster(X)
+            if two is not None:
+                X_list, ent_list = [None] * self.lenght, [None] * self.lenght
+                for f in two.used_frames(fnr, self.lenght):
+                    X_list[f] = self._ref_and_nonground(f)[1]
+                    ent_list[f] = self._entropy_full(f)
+                    if ent_list[f] is None:
+                        raise RuntimeError('spatial_clustering with n_frames > 1 reads the entropy scores: activate '
+                                           'calculate_entropy_scores first (preprocessing.yaml:50)')
+                labels, probs = two.labels(fnr, X_list, ent_list)
+            else:
+                labels, probs = self.pipe.cluster(X)
             fs.set_clusters(*pack_clusters(labels, probs, self.pipe.prob_threshold))     # lidar_frame.py:154-248
+            ent = self._entropy_full(fnr)
+            if ent is not None and fs.n_detections:
+                fs.static = static_from_entropy(ent.cpu().numpy(), fs.index, fs.seg_off,
+                                                percentile=float(ecfg['percentile']) if ecfg else 30.0,
+                                                min_percentile_pp_score=float(ecfg['min_percentile_pp_score']) if ecfg else 0.5)
             updated = True
         if updated:
             self.sync_lidar_frames()
@@ -262,10 +343,7 @@ class ZeroShotDetector:
                     pickle.dump([f.serialize for f in self.lidar_frame_list], fp)
         self.detection_3d_result_list = [local[f] for f in sorted(local)]
 
-    # ---- SURVEY §8f "next" rows: accepted, not built ----------------------------------------------------------
-    def calculate_entropy_scores(self, **kwargs):
-        self.logger.warning('calculate_entropy_scores (PP-score, SURVEY §8f N1) is not built yet -- skipped')
-
+    # ---- SURVEY §8f "next" row N2: accepted, not built ----------------------------------------------------------
     def track_clusters(self, **kwargs):
         self.logger.warning('track_clusters (SURVEY §8f N2) is not built yet -- skipped')
 
