@@ -652,44 +652,66 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #define AT_KLD 72      // K rows: 64 + 8 halves
 #define AT_VLD 232     // V^T rows: 224 + 8 halves
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T,
-                                                       int W, int heads, int ld) {
+                                                       int W, int heads, int ld, int n_items) {
     __shared__ __attribute__((aligned(16))) f16 Ks[AT_MAXT * AT_KLD];
     __shared__ __attribute__((aligned(16))) f16 Vt[64 * AT_VLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int crop = blockIdx.x / heads, head = blockIdx.x - crop * heads;
-    const size_t row0 = (size_t)crop * T;
-    const f16* qbase = qkv + row0 * ld + head * 64;
-    const f16* kbase = qbase + W;
-    const f16* vbase = qbase + 2 * W;
-
-    // this lane's Q fragments first: their latency hides behind the K/V staging below
     const int r31 = lane & 31, hh = lane >> 5;
     const int q0 = wave * 32;
     const int q = q0 + r31;
-    f16x8 qf[4];
+    const int nkb = (T + 31) / 32;
+    static_assert(AT_MAXT * 8 == 4 * 448, "staging split");
+    // PERSISTENT workgroups (182 VGPRs and 62 KB of LDS allow one 7-wave workgroup per CU, so nothing else would hide
+    // an item's load latency): item = (crop, head); the NEXT item's Q / K / V rows are fetched into registers while
+    // the current item is computed.  All eight 16-byte K/V loads of a thread go out back to back, branch-free
+    // (clamped row, zeroed by select when written to LDS).
+    f16x8 qf[4], qn[4];
+    uint4 kreg[4];
+    f16x8 vreg[4];
+    auto fetch = [&](int item) {
+        const int crop = item / heads, head = item - crop * heads;
+        const f16* qbase = qkv + (size_t)crop * T * ld + head * 64;
+        const f16* kbase = qbase + W;
+        const f16* vbase = qbase + 2 * W;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        qf[s] = (q < T) ? *(const f16x8*)(qbase + (size_t)q * ld + s * 16 + hh * 8) : z;
-    }
+        for (int s = 0; s < 4; ++s) qn[s] = *(const f16x8*)(qbase + (size_t)(q < T ? q : T - 1) * ld + s * 16 + hh * 8);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = tid + it * 448, key = c >> 3, part = c & 7;
+            kreg[it] = *(const uint4*)(kbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = tid + it * 448, part = c / AT_MAXT, key = c - part * AT_MAXT;
+            vreg[it] = *(const f16x8*)(vbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
+        }
+    };
+    int item = blockIdx.x;
+    if (item < n_items) fetch(item);
+    for (; item < n_items; item += gridDim.x) {
+    const int crop = item / heads, head = item - crop * heads;
+    const size_t row0 = (size_t)crop * T;
     // K -> LDS rows (zero beyond T)
-    for (int c = tid; c < AT_MAXT * 8; c += 448) {
-        int key = c >> 3, part = c & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < T) v = *(const uint4*)(kbase + (size_t)key * ld + part * 8);
-        *(uint4*)(Ks + key * AT_KLD + part * 8) = v;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 448, key = c >> 3, part = c & 7;
+        *(uint4*)(Ks + key * AT_KLD + part * 8) = key < T ? kreg[it] : make_uint4(0, 0, 0, 0);
     }
     // V -> LDS transposed (zero beyond T); consecutive lanes take consecutive keys
-    for (int c = tid; c < AT_MAXT * 8; c += 448) {
-        int part = c / AT_MAXT, key = c - part * AT_MAXT;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < T) v = *(const f16x8*)(vbase + (size_t)key * ld + part * 8);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 448, part = c / AT_MAXT, key = c - part * AT_MAXT;
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const f16x8 v = key < T ? vreg[it] : z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
     __syncthreads();
-    if (q0 >= T) return;
-    const int nkb = (T + 31) / 32;
+    if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);      // in flight during the compute below
+    if (q0 < T) {
+
 
     f32x16 sacc[7];
 #pragma unroll
@@ -704,28 +726,38 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
             }
         }
     }
-    // softmax over keys (scores scaled by 1/8 = dh^-0.5, model.py via nn.MultiheadAttention)
+    // softmax over keys (scores scaled by 1/8 = dh^-0.5, model.py via nn.MultiheadAttention).  Only the last key block
+    // can hold keys >= T; blocks beyond it were never computed (zeros) and are skipped below.
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < 7; ++kb)
+    for (int kb = 0; kb < 7; ++kb) {
+        if (kb == nkb - 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float v = (key < T) ? sacc[kb][r] : -INFINITY;
-            sacc[kb][r] = v;
-            mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= T) sacc[kb][r] = -INFINITY;
+            }
         }
+        if (kb < nkb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float c2 = 0.125f * 1.4426950408889634f;
+    const float mc = -mx * c2;
     float sum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 7; ++kb)
+    for (int kb = 0; kb < 7; ++kb) {
+        if (kb < nkb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = exp2f((sacc[kb][r] - mx) * c2);
-            sacc[kb][r] = p;
-            sum += p;
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, mc));      // raw v_exp_f32: exp2(-inf) = 0
+                sacc[kb][r] = p;
+                sum += p;
+            }
         }
+    }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 
@@ -764,6 +796,9 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
                 for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
                 *(f16x4*)(o + dt * 32 + 8 * g + 4 * hh) = h4;
             }
+    }
+    }
+    __syncthreads();      // every wave is done with this item's K / V^T before the next item overwrites them
     }
 }
 
@@ -1120,7 +1155,11 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld);
         if (rc) return rc;
         if (v->dtype == 1) {
-            hipLaunchKernelGGL(k_attention_f16, dim3(n_crops * H), dim3(448), 0, st, (const f16*)qkv, (f16*)h, T, W, H, qkv_ld);
+            {
+                const int items = n_crops * H;
+                hipLaunchKernelGGL(k_attention_f16, dim3(items < 256 ? items : 256), dim3(448), 0, st, (const f16*)qkv, (f16*)h, T, W, H,
+                                   qkv_ld, items);
+            }
         } else {
             size_t lds = ((size_t)T * 65 + (size_t)T * 64 + 4 * (size_t)T) * sizeof(float);
             static bool attr = false;
