@@ -172,7 +172,7 @@ int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, const double*
                          int32_t* h_n_clusters);
 
 /* GPU half of the clustering: exact k-NN core distances and THE minimum spanning tree of the mutual
- * reachability graph under the strict edge order (w2, min id, max id) (unique -> identical to the CPU oracle's). */
+ * reachability graph under the strict edge order (w2, pair d2, min id, max id) (unique -> identical to the CPU oracle's). */
 typedef struct vg_cluster vg_cluster;
 int vg_cluster_create(vg_cluster** out, int max_points);
 void vg_cluster_destroy(vg_cluster* h);

@@ -23,7 +23,7 @@ Healy 2017) with the tree semantics of the scikit-learn port whose sources are r
 PARITY PIN: `sklearn_fit` (the scikit-learn implementation itself) is the stand-in for the absent library;
 tests/test_cluster.py checks `fit` against it (same partition after canonical relabel, same noise set,
 probabilities within 1e-9) on seeded scenes.  Equal-weight MST edges (ties) are resolved here by
-(weight, min index, max index); the libraries leave tie order unspecified.
+(weight, pair distance, min index, max index); the libraries leave tie order unspecified.
 """
 import numpy as np
 from scipy.spatial import cKDTree
@@ -60,13 +60,17 @@ def core_distances_sq(X, k=MIN_CLUSTER_SIZE):
 
 def mst_prim(X, core2):
     """THE minimum spanning tree of the mutual-reachability graph under the strict total edge order
-    (w2, min(a,b), max(a,b)) -- unique, so any exact algorithm using the same order (the GPU's Boruvka)
-    returns the same edge set.  O(n^2) Prim; squared weights."""
+    (w2, d2, min(a,b), max(a,b)) -- mutual-reachability weight, then the plain squared distance of the pair, then the
+    ids -- unique, so any exact algorithm using the same order (the GPU's Boruvka) returns the same edge set.
+    (Equal weights are the rule, not the exception: w = core[a] for every neighbour inside a's core ball.  The
+    libraries leave their order unspecified; preferring the SHORTER pair lets a nearest-neighbour search stop at the
+    nearest qualifying point instead of scanning the whole ball for the smallest id.)  O(n^2) Prim; squared weights."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     n = len(X)
     ids = np.arange(n)
     in_tree = np.zeros(n, bool)
     best = np.full(n, np.inf)
+    bd2 = np.full(n, np.inf)
     blo = np.full(n, n, np.int64)
     bhi = np.full(n, n, np.int64)
     src = np.zeros(n, np.int64)
@@ -79,11 +83,13 @@ def mst_prim(X, core2):
         d2 = _d2(d)
         w = np.maximum(np.maximum(d2, core2), core2[cur])
         lo, hi = np.minimum(ids, cur), np.maximum(ids, cur)
-        upd = ~in_tree & ((w < best) | ((w == best) & ((lo < blo) | ((lo == blo) & (hi < bhi)))))
-        best[upd], blo[upd], bhi[upd], src[upd] = w[upd], lo[upd], hi[upd], cur
+        tie_w = w == best
+        tie_d = tie_w & (d2 == bd2)
+        upd = ~in_tree & ((w < best) | (tie_w & (d2 < bd2)) | (tie_d & ((lo < blo) | ((lo == blo) & (hi < bhi)))))
+        best[upd], bd2[upd], blo[upd], bhi[upd], src[upd] = w[upd], d2[upd], lo[upd], hi[upd], cur
         cand = np.where(in_tree, np.inf, best)
         tie = np.flatnonzero(cand == cand.min())
-        nxt = int(tie[np.lexsort((bhi[tie], blo[tie]))[0]]) if len(tie) > 1 else int(tie[0])
+        nxt = int(tie[np.lexsort((bhi[tie], blo[tie], bd2[tie]))[0]]) if len(tie) > 1 else int(tie[0])
         edges[e] = (src[nxt], nxt)
         w2[e] = cand[nxt]
         in_tree[nxt] = True

@@ -6,7 +6,8 @@ scikit-learn implementation of the same algorithm:
   * mutual-reachability MST weights: bit-identical multiset to scikit-learn's (`_single_linkage_tree_`)
   * tree stages: identical labels/probabilities to scikit-learn's own `tree_to_labels` on the same linkage
   * end to end: adjusted Rand index >= 0.99 and >= 99 % agreement on the noise set (equal-weight MST edges are
-    ordered arbitrarily by both libraries; the oracle and the GPU use the strict order (w2, lo, hi))
+    ordered arbitrarily by both libraries; the oracle and the GPU use the strict order (w2, pair d2, lo, hi) for the MST;
+    the linkage stage orders equal-weight MST edges by (w2, lo, hi))
 Product side on CPU: the host hierarchy stage (csrc/hdbscan_tree.cpp) == the oracle's, exactly.
 GPU: see the gpu-marked tests below (exact equality with the oracle: labels, probabilities, MST).
 """

@@ -13,7 +13,7 @@
 //                         query's component are skipped through per-round purity tables (levels 0..3), and
 //                         per-component upper bounds published with atomicMin prune the rest of the component;
 //                         edges are ordered by the STRICT total order
-//                         (w2, min id, max id) so the tree is unique and equals the oracle's
+//                         (w2, pair d2, min id, max id) so the tree is unique and equals the oracle's
 //        radix sort of the n-1 edges by weight
 // The sequential hierarchy stage (K2d) is csrc/hdbscan_tree.cpp on the host.
 //
@@ -34,7 +34,7 @@
 #define CL_LB 6                       // interleaved bits per axis
 #define CL_NCODES (1 << 24)           // 9 + 9 + 6 bits
 #define CL_LMAX 6                     // coarsest Morton-contiguous level (25.6 m cubes): 8 x 8 x 1 roots
-#define CL_PUR_LEVELS 4               // purity tables for levels 0..3 (0.4 .. 3.2 m)
+#define CL_PUR_LEVELS 4               // purity tables for levels 0..3 (0.4 .. 3.2 m); levels 4..6 were measured: no gain
 #define CL_LEAF 48                    // nodes with at most this many points are scanned instead of subdivided
 #define CL_STACK 64
 #define CL_K 16                       // neighbours kept (k-th other point = entry k, entry 0 is the point itself)
@@ -58,7 +58,7 @@ struct vg_cluster {
     int *d_comp, *d_parent, *d_parent2;   // Boruvka components (sorted index space)
     unsigned long long *d_best_w, *d_best_e;
     int *d_sel_a, *d_sel_b;
-    unsigned long long *d_pt_w, *d_pt_key;
+    unsigned long long *d_pt_w, *d_pt_key, *d_pt_d, *d_best_d;   // pt_d / best_d: squared pair distance (tie-break after w)
     int* d_pt_b;
     int* d_counter;                       // [0] number of MST edges emitted
     int *d_mst_a, *d_mst_b;               // original ids
@@ -289,10 +289,12 @@ __global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ cou
 }
 
 __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned long long* __restrict__ best_w,
-                                  unsigned long long* __restrict__ best_e, int* __restrict__ sel_a) {
+                                  unsigned long long* __restrict__ best_d, unsigned long long* __restrict__ best_e,
+                                  int* __restrict__ sel_a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     best_w[i] = CL_NONE;
+    best_d[i] = ~0ull;
     best_e[i] = ~0ull;
     sel_a[i] = -1;
 }
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      const double* __restrict__ core2, const int* __restrict__ comp,
                                                      unsigned long long* __restrict__ best_w,
                                                      unsigned long long* __restrict__ pt_w,
+                                                     unsigned long long* __restrict__ pt_d,
                                                      unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b) {
     __shared__ unsigned int stack[CL_STACK * 256];
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +365,12 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     const int oa = perm[a];
     int cx, cy, cz;
     cl_cell_of(g, qx, qy, qz, cx, cy, cz);
+    // edges are ordered by (w, d2, original ids): mutual-reachability weight, then the pair's own squared distance.
+    // w = core_a for EVERY neighbour inside a's core ball whose core distance is not larger, so ties on w are the
+    // rule; breaking them by d2 lets the traversal stop at the nearest such neighbour (nodes farther than bd2 cannot
+    // win a tie) instead of scanning the whole ball for the smallest id.
     double bw = INFINITY;          // best weight found by this point
+    double bd2 = INFINITY;         // ... and that edge's squared pair distance
     double cbest = INFINITY;       // best weight published for the whole component (refreshed now and then)
     unsigned long long bkey = ~0ull;
     int bb = -1;
@@ -380,8 +388,9 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             int l, x, y, z;
             cl_unpack(st[(--sp) * 256], l, x, y, z);
             // every edge into this node weighs at least lb; it must be able to tie or beat both bounds (ALU only)
-            const double lb = fmax(core_a, cl_box_d2(g, qx, qy, qz, l, x, y, z));
-            if (lb > bw || lb > cbest) continue;
+            const double nd2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
+            const double lb = fmax(core_a, nd2);
+            if (lb > bw || lb > cbest || (lb == bw && nd2 > bd2)) continue;
             const unsigned int c0 = cl_code(x << l, y << l, z << l);
             const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
             if (j0 == j1) continue;
@@ -393,9 +402,9 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                     const double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
                     if (d2 > bw) continue;
                     const double w = fmax(fmax(d2, core_a), core2[j]);
-                    if (w > bw) continue;
+                    if (w > bw || (w == bw && d2 > bd2)) continue;
                     const unsigned long long key = cl_edge_key(oa, perm[j]);
-                    if (w < bw || key < bkey) { bw = w; bkey = key; bb = j; improved = true; }
+                    if (w < bw || d2 < bd2 || key < bkey) { bw = w; bd2 = d2; bkey = key; bb = j; improved = true; }
                 }
                 if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
                 since_refresh = 64;     // force a refresh below
@@ -412,45 +421,57 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             for (int c = 7; c >= 0; --c) {
                 const int ch = c ^ near;
                 const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
-                const double clb = fmax(core_a, cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz));
-                if (clb > bw || clb > cbest) continue;
+                const double cd2 = cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz);
+                const double clb = fmax(core_a, cd2);
+                if (clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) continue;
                 if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, nx, ny, nz);
             }
         }
     }
     if (bb >= 0 && bw <= cbest) {
         pt_w[a] = (unsigned long long)__double_as_longlong(bw);
+        pt_d[a] = (unsigned long long)__double_as_longlong(bd2);
         pt_key[a] = bkey;
         pt_b[a] = bb;
     } else {
         pt_w[a] = CL_NONE;
+        pt_d[a] = ~0ull;
         pt_key[a] = ~0ull;
         pt_b[a] = -1;
     }
 }
 
+// per component: smallest w (atomicMin in the search), then smallest d2 among those, then smallest id key among those
+__global__ void k_cl_b_select_d(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
+                                const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_d,
+                                unsigned long long* __restrict__ best_d) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int c = comp[a];
+    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c]) atomicMin(&best_d[c], pt_d[a]);
+}
 __global__ void k_cl_b_select(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
-                              const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_key,
+                              const unsigned long long* __restrict__ best_d, const unsigned long long* __restrict__ pt_w,
+                              const unsigned long long* __restrict__ pt_d, const unsigned long long* __restrict__ pt_key,
                               unsigned long long* __restrict__ best_e) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
-    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c]) atomicMin(&best_e[c], pt_key[a]);
+    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c] && pt_d[a] == best_d[c]) atomicMin(&best_e[c], pt_key[a]);
 }
-
 __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
-                            const unsigned long long* __restrict__ best_e, const unsigned long long* __restrict__ pt_w,
+                            const unsigned long long* __restrict__ best_d, const unsigned long long* __restrict__ best_e,
+                            const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_d,
                             const unsigned long long* __restrict__ pt_key, const int* __restrict__ pt_b,
                             int* __restrict__ sel_a, int* __restrict__ sel_b) {
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
-    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c] && pt_key[a] == best_e[c]) {
+    if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c] && pt_d[a] == best_d[c] && pt_key[a] == best_e[c]) {
         sel_a[c] = a;
         sel_b[c] = pt_b[a];
     }
 }
-
 __global__ void k_cl_b_link(int n, const int* __restrict__ comp, const int* __restrict__ sel_a,
                             const int* __restrict__ sel_b, int* __restrict__ parent) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,7 +613,11 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_spts, sizeof(float4) * n));
     VG_CHECK(hipMalloc(&h->d_st, 4 * n));
     VG_CHECK(hipMalloc(&h->d_cell_start, 4 * (size_t)(CL_NCODES + 1)));
-    VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * (size_t)(CL_NCODES + (CL_NCODES >> 3) + (CL_NCODES >> 6) + (CL_NCODES >> 9))));
+    {
+        size_t tot = 0;
+        for (int l = 0; l < CL_PUR_LEVELS; ++l) tot += (size_t)CL_NCODES >> (3 * l);
+        VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * tot));
+    }
     VG_CHECK(hipMalloc(&h->d_core2, 8 * n));
     VG_CHECK(hipMalloc(&h->d_comp, 4 * n));
     VG_CHECK(hipMalloc(&h->d_parent, 4 * n));
@@ -603,6 +628,8 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_sel_b, 4 * n));
     VG_CHECK(hipMalloc(&h->d_pt_w, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_key, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_pt_d, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_best_d, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_b, 4 * n));
     VG_CHECK(hipMalloc(&h->d_counter, 64));
     VG_CHECK(hipMalloc(&h->d_mst_a, 4 * n));
@@ -626,7 +653,7 @@ void vg_cluster_destroy(vg_cluster* h) {
     if (!h) return;
     void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
-                    h->d_pt_w, h->d_pt_key, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
+                    h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
                     h->d_mst_idx, h->d_mst_idx_s, h->d_temp};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(h->h_counter);
@@ -668,8 +695,8 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
     hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key,
-                       h->d_pt_b);
+                       h->d_cell_start, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                       h->d_pt_key, h->d_pt_b);
 }
 
 extern "C" {
@@ -753,16 +780,18 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
             fprintf(stderr, "[vilgod_hip] vg_cluster_mst: Boruvka did not converge (%d of %d edges)\n", edges, n - 1);
             return VG_ERR_HIP;
         }
-        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_e, h->d_sel_a);
+        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp);
         for (int l = 1; l < CL_PUR_LEVELS; ++l)
             hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp);
         if (dim == 3) cl_launch_search<3>(h, n, st);
         else if (dim == 4) cl_launch_search<4>(h, n, st);
         else cl_launch_search<5>(h, n, st);
-        hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_key, h->d_best_e);
-        hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_e, h->d_pt_w, h->d_pt_key,
-                           h->d_pt_b, h->d_sel_a, h->d_sel_b);
+        hipLaunchKernelGGL(k_cl_b_select_d, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_best_d);
+        hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_pt_w, h->d_pt_d,
+                           h->d_pt_key, h->d_best_e);
+        hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_pt_w,
+                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b);
         hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent);
         hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent, h->d_sel_a, h->d_sel_b, h->d_best_w,
                            h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w);
