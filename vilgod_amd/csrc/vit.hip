@@ -451,18 +451,28 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp(const f16* __restrict__ 
             }
             __syncthreads();
             const int j = tid & 63, rr = tid >> 6;
-#pragma unroll 4
-            for (int pass = 0; pass < 16; ++pass) {
-                const int m = pass * 8 + rr;
-                float4 v = *(const float4*)(smem + m * 1024 + j * 16);
-                const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+#pragma unroll
+            for (int p8 = 0; p8 < 2; ++p8) {
+                // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
+                float4 x4[8];
                 if (EPI == EPI_BIAS_RESID) {
-                    float* p = resid + off;
-                    const float4 x4 = *(const float4*)p;
-                    v.x += x4.x; v.y += x4.y; v.z += x4.z; v.w += x4.w;
-                    *(float4*)p = v;
-                } else {
-                    *(float4*)((float*)Cout + off) = v;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int m = (p8 * 8 + q) * 8 + rr;
+                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = (p8 * 8 + q) * 8 + rr;
+                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
+                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+                    if (EPI == EPI_BIAS_RESID) {
+                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
+                        *(float4*)(resid + off) = v;
+                    } else {
+                        *(float4*)((float*)Cout + off) = v;
+                    }
                 }
             }
         }
@@ -930,7 +940,7 @@ struct vg_vit {
     int prof_on = 0, prof_n = 0;
     hipEvent_t prof_ev[2 * VG_PROF_MAX];
     double prof_flops[VG_PROF_MAX];
-    int prof_kind[VG_PROF_MAX];      // 0 = k_gemm_f16 / k_gemm_f32, 1 = k_gemm_f16_pp
+    int prof_kind[VG_PROF_MAX];      // 0 = k_gemm_f16 / k_gemm_f32, 1 = k_gemm_f16_pp16
     bool prof_init = false;
     std::map<std::string, void*> w;        // device pointers (f32 or f16 depending on role)
     std::map<std::string, size_t> numel;
@@ -953,6 +963,196 @@ static int gemm_chunk_tiles(int N, int K) {
     int nchunks = (ntn + cw_max - 1) / cw_max;
     while (ntn % nchunks) ++nchunks;
     return ntn / nchunks;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same ping-pong schedule on v_mfma_f32_16x16x32_f16 (one MFMA spans the whole 32-wide K-step of a 16 x 16 block:
+// 32 MFMAs of 16 cycles per wave and K-step instead of 16 of 32).  MI355X_MICROARCH.md "DVFS give-back" item 7: on
+// random operands the 16x16x32 form holds a higher clock at equal cycles per FLOP.
+//   A operand (weight rows): lane l -> row l & 15, 16-byte K chunk l >> 4;  B operand (activation rows): the same.
+//   D: column (activation row m) = l & 15, rows (features n) = 4 (l >> 4) + r  -> a lane owns 4 consecutive n of one m.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int EPI, int STAGES>
+__global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict__ X, const f16* __restrict__ Wt,
+                                                          const float* __restrict__ bias, void* __restrict__ Cout,
+                                                          float* __restrict__ resid, int M, int N, int K, int ldc, int cw) {
+    constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;       // 16 x 16 blocks per wave tile (128 m x 64 n)
+    constexpr int STAGE_BYTES = (BM + BN) * 64, W_OFF = BM * 64;
+    constexpr int D = STAGES - 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntm = M / BM;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = ntm * cw;
+    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int grp = wave >> 2, wn = wave & 3;
+
+    const int l2 = lane >> 2, pslot = lane & 3;
+    const int R0 = wave * 32 + l2, R1 = R0 + 16;
+    const f16* xs0 = X + (size_t)(m0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
+    const f16* xs1 = X + (size_t)(m0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
+    const f16* ws0 = Wt + (size_t)(n0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
+    const f16* ws1 = Wt + (size_t)(n0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
+    char* const dma_base = smem + wave * 2048;
+    auto issue = [&](int tile) {
+        char* sb_ = dma_base + (tile % STAGES) * STAGE_BYTES;
+        __builtin_amdgcn_global_load_lds((glb_void*)(xs0 + (size_t)tile * GK), (lds_void*)sb_, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(xs1 + (size_t)tile * GK), (lds_void*)(sb_ + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(ws0 + (size_t)tile * GK), (lds_void*)(sb_ + W_OFF), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(ws1 + (size_t)tile * GK), (lds_void*)(sb_ + W_OFF + 1024), 16, 0, 0);
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r15 = lane & 15, q4 = lane >> 4;
+    const int po = (q4 ^ ((r15 >> 2) & 3)) * 16;
+    const int xrow = (grp * 128 + r15) * 64 + po, wrow = W_OFF + (wn * 64 + r15) * 64 + po;
+    const int nk = K / GK;
+#define PP_BAR()                                  \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    __builtin_amdgcn_sched_barrier(0);
+#define PP_WAIT(newer)                                                                       \
+    do {                                                                                     \
+        const int nw_ = (newer);                                                             \
+        if (nw_ >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory"); \
+        else if (nw_ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
+        else if (nw_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+    } while (0)
+#pragma unroll
+    for (int q = 0; q < D; ++q) issue(q);
+    PP_WAIT(D - 1);
+    PP_BAR()
+    if (grp == 1) { PP_BAR() }
+    f16x8 fa[TN], fb[TM];
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const f16x8*)(sb + wrow + ni * 1024);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const f16x8*)(sb + xrow + mi * 1024);
+        if (kt + D < nk) issue(kt + D);
+        if (kt + 1 < nk) {
+            const int newest = (kt + D < nk - 1) ? kt + D : nk - 1;
+            PP_WAIT(newest - (kt + 1));
+        }
+        PP_BAR()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR()
+    }
+    if (grp == 0) { PP_BAR() }
+#undef PP_BAR
+#undef PP_WAIT
+    // ---- epilogue: the same chunk-XOR-swizzled LDS image as k_gemm_f16_pp ----
+    __syncthreads();
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int nloc = wn * 64 + ni * 16 + 4 * q4;
+            const float4 b4 = *(const float4*)(bias + n0 + nloc);
+            const int ch = nloc >> 3, hf = (nloc >> 2) & 1;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int m = grp * 128 + mi * 16 + r15;
+                float v[4] = {acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w};
+                f16x4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+                    h4[e] = (f16)x;
+                }
+                *(f16x4*)(smem + m * 512 + ((ch ^ (m & 31)) << 4) + hf * 8) = h4;
+            }
+        }
+        __syncthreads();
+        const int j = tid & 31, rr = tid >> 5;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int m = pass * 16 + rr;
+            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
+            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (grp == half) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int nloc = wn * 64 + ni * 16 + 4 * q4;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
+                    const int ch = nloc >> 2;
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int m = mi * 16 + r15;
+                        *(float4*)(smem + m * 1024 + ((ch ^ (m & 31)) << 4)) =
+                            make_float4(acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w);
+                    }
+                }
+            }
+            __syncthreads();
+            const int j = tid & 63, rr = tid >> 6;
+#pragma unroll
+            for (int p8 = 0; p8 < 2; ++p8) {
+                // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
+                float4 x4[8];
+                if (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int m = (p8 * 8 + q) * 8 + rr;
+                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = (p8 * 8 + q) * 8 + rr;
+                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
+                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+                    if (EPI == EPI_BIAS_RESID) {
+                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
+                        *(float4*)(resid + off) = v;
+                    } else {
+                        *(float4*)((float*)Cout + off) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int STAGES>
+static int launch_gemm_pp16(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
+                            hipStream_t st) {
+    if (M % 256 || N % 256 || K % GK || K / GK < STAGES) return VG_ERR_ARG;
+    auto kern = k_gemm_f16_pp16<EPI, STAGES>;
+    const int lds = STAGES * 32768;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ntn = N / 256;
+    int cwt = (int)(2400000L / (256L * K * 2));
+    if (cwt < 1) cwt = 1;
+    if (cwt > ntn) cwt = ntn;
+    while (ntn % cwt) --cwt;
+    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
+                       ldc, cwt);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
 }
 
 template <int EPI, int STAGES, bool TRACE, int PH = 2>
@@ -982,10 +1182,8 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                        int N, int K, hipStream_t st, int ldc = 0) {
     if (ldc == 0) ldc = N;
     vg_vit* v = const_cast<vg_vit*>(cv);
-    // f16 ViT shapes (N % 256 == 0, K >= 128) with a streaming epilogue take the ping-pong kernel.  The residual
-    // epilogue (fp32 read-modify-write of the stream, HBM bound) stays on k_gemm_f16, whose two workgroups per CU
-    // overlap one block's epilogue traffic with the other's MFMAs; so do the remaining legal shapes.
-    const bool use_pp = v->dtype == 1 && EPI != EPI_BIAS_RESID && N % 256 == 0 && K / GK >= 4 && !getenv("VG_GEMM_V4");
+    // f16 ViT shapes (N % 256 == 0, K >= 128) take the ping-pong kernel; k_gemm_f16 serves the remaining legal shapes.
+    const bool use_pp = v->dtype == 1 && N % 256 == 0 && K / GK >= 4 && !getenv("VG_GEMM_V4");
     const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
     if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
     struct Closer {
@@ -1000,7 +1198,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
     } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K, use_pp ? 1 : 0};
     if (v->dtype == 1) {
         if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
-        if (use_pp) return launch_gemm_pp<EPI, 4, false, 1>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr);
+        if (use_pp) return launch_gemm_pp16<EPI, 4>(X, Wt, bias, C, resid, M, N, K, ldc, st);
         int nwg = (M / GBM) * (N / GBN);
         static bool attr_set = false;
         if (!attr_set) {
@@ -1206,6 +1404,7 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
         case 21: return launch_gemm_pp<EPI_BIAS, 5, false>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
         case 22: return launch_gemm_pp<EPI_BIAS, 4, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
         case 23: return launch_gemm_pp<EPI_BIAS, 5, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
+        case 30: return launch_gemm_pp16<EPI_BIAS, 4>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
         default: return VG_ERR_ARG; }
 #undef VG_VAR
     VG_LAUNCH_CHECK();
@@ -1256,7 +1455,7 @@ int vg_vit_profile(vg_vit* v, int on) {
 }
 
 /* synchronises, then returns the number of GEMM launches sampled, their summed duration (ms) and algorithmic FLOPs;
- * kind -1: every projection GEMM, 0: k_gemm_f16 (residual epilogue), 1: k_gemm_f16_pp */
+ * kind -1: every projection GEMM, 0: k_gemm_f16 / k_gemm_f32, 1: k_gemm_f16_pp16 */
 int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h_ms, double* h_flops) {
     if (!v || !h_launches || !h_ms || !h_flops) return VG_ERR_ARG;
     *h_launches = 0; *h_ms = 0; *h_flops = 0;
