@@ -13,7 +13,7 @@ the only collective is ONE all-gather of the per-crop score matrices after the K
 Inputs are resident in HBM before the timed region starts.
 
 The JSON line also carries
-  roofline      the dominant kernel (ViT projection GEMM, k_gemm_f16_pp16): algorithmic FLOPs / launch duration, measured
+  roofline      the dominant kernel (ViT projection GEMM, k_gemm_f16_pp64): algorithmic FLOPs / launch duration, measured
                 live with HIP event pairs on the launch stream (csrc/vit.hip vg_vit_profile), vs the dense fp16
                 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md
   cpu_baseline  the CPU oracle (oracle/pipeline_oracle.py, kind "port": the reference cannot travel to the GPU box)
@@ -195,14 +195,14 @@ def main():
                 'weights': pipe.clip.weights_source, 'parallelism': f'frame-sharded x{world}', 'frames_in_flight_per_gpu': inflight,
             },
             'roofline': {
-                'kernel': 'k_gemm_f16_pp16 (every ViT projection GEMM: in_proj, out_proj, c_fc, c_proj, patch embedding)',
+                'kernel': 'k_gemm_f16_pp64 (every ViT projection GEMM: in_proj, out_proj, c_fc, c_proj, patch embedding)',
                 'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)',
-                'method': 'HIP event pairs on the launch stream around every k_gemm_f16_pp16 launch, sequential pass (1 frame in flight) of the same frames right after the timed region',
+                'method': 'HIP event pairs on the launch stream around every k_gemm_f16_pp64 launch, sequential pass (1 frame in flight) of the same frames right after the timed region',
                 'launches': launches, 'avg_launch_us': round(1000.0 * gemm_ms / max(launches, 1), 2),
                 'algorithmic_flops_per_launch': round(gemm_flops / max(launches, 1)),
                 'gemm_ms_per_frame': round(gemm_ms / max(min(4, args.steps), 1), 3),
-                'all_projection_gemms': {'kernels': 'k_gemm_f16_pp16 (+ k_gemm_f16 for shapes it does not take: none in ViT-B/16)', 'launches': all_launches,
+                'all_projection_gemms': {'kernels': 'k_gemm_f16_pp64 (+ k_gemm_f16_pp16 / k_gemm_f16 for shapes it does not take: none in ViT-B/16)', 'launches': all_launches,
                                          'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
                                          'ms_per_frame': round(all_ms / max(min(4, args.steps), 1), 3)},
             },

@@ -59,7 +59,7 @@ class VitEncoder:
 
     def profile_read(self, kind=-1):
         """-> (launches, total ms, total algorithmic FLOPs) of the projection GEMMs since profile(True);
-        kind 1: k_gemm_f16_pp16 launches only, 0: the fallback kernels only, -1: all."""
+        kind 1: k_gemm_f16_pp64 launches only, 0: the fallback kernels only, -1: all."""
         n, ms, fl = ctypes.c_int32(0), ctypes.c_double(0), ctypes.c_double(0)
         check(lib.vg_vit_profile_read_kind(self._h, int(kind), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)),
               'vg_vit_profile_read_kind')

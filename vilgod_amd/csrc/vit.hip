@@ -940,7 +940,7 @@ struct vg_vit {
     int prof_on = 0, prof_n = 0;
     hipEvent_t prof_ev[2 * VG_PROF_MAX];
     double prof_flops[VG_PROF_MAX];
-    int prof_kind[VG_PROF_MAX];      // 0 = k_gemm_f16 / k_gemm_f32, 1 = k_gemm_f16_pp16
+    int prof_kind[VG_PROF_MAX];      // 0 = k_gemm_f16 / k_gemm_f32, 1 = k_gemm_f16_pp64 / pp16
     bool prof_init = false;
     std::map<std::string, void*> w;        // device pointers (f32 or f16 depending on role)
     std::map<std::string, size_t> numel;
@@ -1133,6 +1133,239 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K-step 64 (128-byte rows).  Measured with tools/micro/dma_rate.hip: LDS-DMA from L2-resident data streams at
+// 39 B/clk/CU when a piece covers 16 rows x 64 B and at 64 B/clk/CU (the L1 peak) when it covers 8 rows x 128 B -- a
+// 256 x 256 x 32 K-step needs 32 B/clk/CU at full MFMA rate, so 64-byte row segments leave the LOAD segment the
+// longer one of the ping-pong pair.  Here a phase is one 64-wide K-tile (two k32 sub-steps, 64 MFMAs per wave):
+//   LDS (all 160 KB): X ring 2 x 32 KB + W ring 3 x 32 KB; a row is 128 B, 16-byte chunk c of row r sits at c ^ ((r>>1)&7).
+//   Group g reads X rows [128 g, +128) only -> it refills them itself (K-tile j+1 in LOAD_j, its slot was last read
+//   in the group's own MMA_{j-1}).  W rows are read by both groups; group 1, which runs one barrier behind, is the
+//   last reader of a W slot: W of K-tile j+2 goes into the slot of K-tile j-1, half by group 1 in its LOAD_j and half
+//   by group 0 in its LOAD_{j+1} (3-deep ring -> at least one interval of lead).
+//   The second k32 sub-step's fragments are read during the first sub-step's MFMAs into the registers those have
+//   just consumed.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that ends its MMA segment.
+template <int EPI, bool TRACE = false>
+__global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
+                                                          const float* __restrict__ bias, void* __restrict__ Cout,
+                                                          float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
+                                                          long long* __restrict__ trace = nullptr) {
+    constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;
+    constexpr int XBUF = 32768, WBASE = 2 * XBUF, WBUF = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntm = M / BM;
+    const int grp = wave >> 2, wn = wave & 3;
+    long long tr_entry = 0, tr_load = 0, tr_bar = 0, tr_mma = 0, tr_wait = 0, tr_t0 = 0, tr_w0 = 0, tr_main = 0;
+    if (TRACE) tr_entry = clock64();
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = ntm * cw;
+    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // DMA pieces: 8 rows x 128 B; lane -> row l >> 3, chunk slot l & 7 (source chunk = slot ^ ((row >> 1) & 7))
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int xr = grp * 128 + wn * 32 + prow;                         // + 8 i, i = 0..3
+    auto issue_x = [&](int kt) {                                       // this group's X half of K-tile kt
+        char* d = smem + (kt & 1) * XBUF + (grp * 128 + wn * 32) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = xr + 8 * i;
+            const f16* sp = X + (size_t)(m0 + r) * K + (size_t)kt * 64 + (pslot ^ ((r >> 1) & 7)) * 8;
+            __builtin_amdgcn_global_load_lds((glb_void*)sp, (lds_void*)(d + i * 1024), 16, 0, 0);
+        }
+    };
+    // W rows [128 h, +128) of K-tile kt, four pieces per wave.  Half 0 is issued by group 1 in LOAD_{kt-2}, half 1 by
+    // group 0 in LOAD_{kt-1} (both after the slot's last reader, group 1's MMA_{kt-3}, has passed its barrier), which
+    // balances the DMA work: 8 pieces per wave and phase in either group.
+    auto issue_w = [&](int kt, int h) {
+        char* d = smem + WBASE + (kt % 3) * WBUF + (h * 128 + wn * 32) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = h * 128 + wn * 32 + prow + 8 * i;
+            const f16* sp = Wt + (size_t)(n0 + r) * K + (size_t)kt * 64 + (pslot ^ ((r >> 1) & 7)) * 8;
+            __builtin_amdgcn_global_load_lds((glb_void*)sp, (lds_void*)(d + i * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r15 = lane & 15, q4 = lane >> 4;
+    const int swz = (r15 >> 1) & 7;
+    const int xo0 = (grp * 128 + r15) * 128 + ((q4 ^ swz) << 4), xo1 = (grp * 128 + r15) * 128 + (((4 + q4) ^ swz) << 4);
+    const int wo0 = (wn * 64 + r15) * 128 + ((q4 ^ swz) << 4), wo1 = (wn * 64 + r15) * 128 + (((4 + q4) ^ swz) << 4);
+    const int np = K / 64;                         // host guarantees K % 64 == 0 and np >= 2
+#define PP_BAR()                                  \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    __builtin_amdgcn_sched_barrier(0);
+    issue_x(0);
+    if (grp == 1) { issue_w(0, 0); issue_w(1, 0); } else issue_w(0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR()
+    if (grp == 1) { PP_BAR() }
+    f16x8 fa[TN], fa2[TN], fb[TM];
+    if (TRACE) { tr_t0 = clock64(); tr_w0 = wall_clock64(); }
+    for (int j = 0; j < np; ++j) {
+        const char* xb = smem + (j & 1) * XBUF;
+        const char* wb = smem + WBASE + (j % 3) * WBUF;
+        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+        if (TRACE) c0 = clock64();
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const f16x8*)(wb + wo0 + ni * 2048);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const f16x8*)(xb + xo0 + mi * 2048);
+        if (j + 1 < np) issue_x(j + 1);
+        if (grp == 1) { if (j + 2 < np) issue_w(j + 2, 0); }
+        else if (j + 1 < np) issue_w(j + 1, 1);
+        if (TRACE) c1 = clock64();
+        PP_BAR()
+        if (TRACE) c2 = clock64();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) fa2[ni] = *(const f16x8*)(wb + wo1 + ni * 2048);
+        // the second k32 sub-step's x fragments go into the registers the first sub-step has consumed, TWO MFMA groups
+        // later (a ds_read into a register that in-flight MFMAs still read stalls the issue: 1370 instead of 1024 cycles)
+        __builtin_amdgcn_sched_barrier(0);      // pin the issue order: left alone, hipcc sinks every reload next to its consumer
+                                                // and waits lgkmcnt(0) there (4 exposed LDS latencies per segment)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+            if (mi >= 2) fb[mi - 2] = *(const f16x8*)(xb + xo1 + (mi - 2) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa2[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+            if (mi < 2) fb[TM - 2 + mi] = *(const f16x8*)(xb + xo1 + (TM - 2 + mi) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (TRACE) c3 = clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my pieces issued in this phase have landed
+        if (TRACE) c4 = clock64();
+        PP_BAR()
+        if (TRACE) { const long long c5 = clock64(); tr_load += c1 - c0; tr_bar += (c2 - c1) + (c5 - c4); tr_mma += c3 - c2; tr_wait += c4 - c3; }
+    }
+    if (TRACE) tr_main += clock64() - tr_t0;
+    if (grp == 0) { PP_BAR() }
+#undef PP_BAR
+    // ---- epilogue: the same chunk-XOR-swizzled LDS image as k_gemm_f16_pp ----
+    __syncthreads();
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int nloc = wn * 64 + ni * 16 + 4 * q4;
+            const float4 b4 = *(const float4*)(bias + n0 + nloc);
+            const int ch = nloc >> 3, hf = (nloc >> 2) & 1;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int m = grp * 128 + mi * 16 + r15;
+                float v[4] = {acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w};
+                f16x4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+                    h4[e] = (f16)x;
+                }
+                *(f16x4*)(smem + m * 512 + ((ch ^ (m & 31)) << 4) + hf * 8) = h4;
+            }
+        }
+        __syncthreads();
+        const int j = tid & 31, rr = tid >> 5;
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) {
+            const int m = pass * 16 + rr;
+            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
+            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (grp == half) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int nloc = wn * 64 + ni * 16 + 4 * q4;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
+                    const int ch = nloc >> 2;
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi) {
+                        const int m = mi * 16 + r15;
+                        *(float4*)(smem + m * 1024 + ((ch ^ (m & 31)) << 4)) =
+                            make_float4(acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w);
+                    }
+                }
+            }
+            __syncthreads();
+            const int j = tid & 63, rr = tid >> 6;
+#pragma unroll
+            for (int p8 = 0; p8 < 2; ++p8) {
+                // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
+                float4 x4[8];
+                if (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int m = (p8 * 8 + q) * 8 + rr;
+                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = (p8 * 8 + q) * 8 + rr;
+                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
+                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+                    if (EPI == EPI_BIAS_RESID) {
+                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
+                        *(float4*)(resid + off) = v;
+                    } else {
+                        *(float4*)((float*)Cout + off) = v;
+                    }
+                }
+            }
+        }
+    }
+    if (TRACE && lane == 0 && trace) {
+        long long* o = trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        const long long t2 = clock64();
+        o[0] = tr_main; o[1] = tr_wait; o[2] = tr_bar; o[3] = (t2 - tr_entry) - tr_main; o[4] = tr_load; o[5] = tr_mma; o[6] = wave;
+        o[7] = wall_clock64() - tr_w0;
+    }
+}
+
+
+template <int EPI, bool TRACE = false>
+static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
+                            hipStream_t st, long long* trace = nullptr) {
+    if (M % 256 || N % 256 || K % 64 || K / 64 < 2) return VG_ERR_ARG;
+    auto kern = k_gemm_f16_pp64<EPI, TRACE>;
+    const int lds = 5 * 32768;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int ntn = N / 256;
+    int cwt = (int)(2400000L / (256L * K * 2));
+    if (cwt < 1) cwt = 1;
+    if (cwt > ntn) cwt = ntn;
+    while (ntn % cwt) --cwt;
+    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
+                       ldc, cwt, trace);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+
 template <int EPI, int STAGES>
 static int launch_gemm_pp16(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st) {
@@ -1198,7 +1431,11 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
     } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K, use_pp ? 1 : 0};
     if (v->dtype == 1) {
         if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
-        if (use_pp) return launch_gemm_pp16<EPI, 4>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+        if (use_pp) {
+            // K-step 64 / 128-byte rows when K allows it (every ViT-B/16 projection), else the K-step-32 kernel
+            if (K % 64 == 0 && K / 64 >= 2 && !getenv("VG_GEMM_PP16")) return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+            return launch_gemm_pp16<EPI, 4>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+        }
         int nwg = (M / GBM) * (N / GBN);
         static bool attr_set = false;
         if (!attr_set) {
@@ -1405,6 +1642,7 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
         case 22: return launch_gemm_pp<EPI_BIAS, 4, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
         case 23: return launch_gemm_pp<EPI_BIAS, 5, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
         case 30: return launch_gemm_pp16<EPI_BIAS, 4>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
+        case 32: return launch_gemm_pp64<EPI_BIAS>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
         default: return VG_ERR_ARG; }
 #undef VG_VAR
     VG_LAUNCH_CHECK();
@@ -1419,6 +1657,7 @@ int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bia
         case 21: return launch_gemm_pp<EPI_BIAS, 5, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 22: return launch_gemm_pp<EPI_BIAS, 4, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 23: return launch_gemm_pp<EPI_BIAS, 5, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        case 32: return launch_gemm_pp64<EPI_BIAS, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         default: return VG_ERR_ARG; }
     VG_LAUNCH_CHECK();
     return VG_OK;
@@ -1455,7 +1694,7 @@ int vg_vit_profile(vg_vit* v, int on) {
 }
 
 /* synchronises, then returns the number of GEMM launches sampled, their summed duration (ms) and algorithmic FLOPs;
- * kind -1: every projection GEMM, 0: k_gemm_f16 / k_gemm_f32, 1: k_gemm_f16_pp16 */
+ * kind -1: every projection GEMM, 0: k_gemm_f16 / k_gemm_f32, 1: k_gemm_f16_pp64 (pp16 when K % 64 != 0) */
 int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h_ms, double* h_flops) {
     if (!v || !h_launches || !h_ms || !h_flops) return VG_ERR_ARG;
     *h_launches = 0; *h_ms = 0; *h_flops = 0;
