@@ -67,9 +67,11 @@ class patchworkpp:
     # -- zero-copy path -----------------------------------------------------------------------------
     def estimate_mask(self, points, z_offset=0.0, out=None, stream=None):
         """points: CUDA float32 [N,>=4] (x,y,z,intensity,...) -> CUDA uint8 [N], 1 = ground."""
-        assert points.is_cuda and points.dtype == torch.float32 and points.stride(1) == 1
         n = points.shape[0]
+        assert points.is_cuda and points.dtype == torch.float32 and (n == 0 or points.stride(1) == 1)
         mask = out if out is not None else torch.empty(n, dtype=torch.uint8, device=points.device)
+        if n == 0:                      # an empty scan: no ground, and the adaptive state is left untouched
+            return mask
         check(lib.vg_ground_estimate(self._h, ptr(points), n, points.stride(0), float(z_offset), ptr(mask),
                                      stream_ptr(stream)), 'vg_ground_estimate')
         return mask

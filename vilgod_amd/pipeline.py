@@ -181,6 +181,8 @@ class PseudoLabelPipeline:
     def to_ref(self, d_points, transform_to_ref):
         T = torch.from_numpy(np.ascontiguousarray(transform_to_ref, dtype=np.float64)).to(self.device)
         out = torch.empty_like(d_points)
+        if d_points.shape[0] == 0:
+            return out
         check(lib.vg_ref_transform(ptr(d_points), d_points.shape[0], d_points.stride(0), ptr(T), ptr(out), stream_ptr()),
               'vg_ref_transform')
         return out
