@@ -54,6 +54,7 @@ struct vg_cluster {
     int grid_n;                           // points in the grid currently built (vg_cluster_grid / vg_cluster_mst_nd)
     int* d_cell_start;                    // [CL_NCODES+1] reversed min-scan layout, see cl_cell_start()
     int* d_cell_comp;                     // purity tables, levels 0..3 back to back: component id if pure, else -1
+    unsigned int* d_cell_e;               // same layout: (min, max) of the 4th coordinate in the node as two fp16 (dim >= 4)
     double* d_core2;                      // [n] sorted order
     int *d_comp, *d_parent, *d_parent2;   // Boruvka components (sorted index space)
     unsigned long long *d_best_w, *d_best_e;
@@ -219,9 +220,72 @@ __device__ __forceinline__ double cl_box_d2(const ClGrid& g, double qx, double q
     return d2;
 }
 
+__device__ __forceinline__ size_t cl_pur_off_fwd(int l) {   // offset of level l inside the per-node tables (= cl_pur_off)
+    size_t o = 0;
+    for (int i = 0; i < l; ++i) o += (size_t)CL_NCODES >> (3 * i);
+    return o;
+}
+// ---- range of the 4th clustering coordinate per octree node (levels 0..CL_PUR_LEVELS-1), for the 4-/5-D searches -----
+// The grid prunes on x,y,z only; in the two-frame input the 4th coordinate (entropy score, 0..1) often separates a
+// point from ALL its spatial neighbours, so the xyz bound alone lets the search wander through thousands of points that
+// are close in space and far in 5-D.  Packed as two fp16: min rounded DOWN (low half), max rounded UP (high half).
+__device__ __forceinline__ unsigned int cl_pack_e(float mn, float mx) {
+    __half hmn = __float2half_rd(mn), hmx = __float2half_ru(mx);
+    return (unsigned int)__half_as_ushort(hmn) | ((unsigned int)__half_as_ushort(hmx) << 16);
+}
+__device__ __forceinline__ void cl_unpack_e(unsigned int v, float& mn, float& mx) {
+    mn = __half2float(__ushort_as_half((unsigned short)(v & 0xFFFFu)));
+    mx = __half2float(__ushort_as_half((unsigned short)(v >> 16)));
+}
+// squared gap between qe and the node's [min, max] range (0 inside), shaved by 2^-30 so that rounding cannot lift the
+// sum above the true minimum
+__device__ __forceinline__ double cl_e_gap2(unsigned int packed, double qe) {
+    float mn, mx;
+    cl_unpack_e(packed, mn, mx);
+    double d = 0.0;
+    if (qe < (double)mn) d = (double)mn - qe;
+    else if (qe > (double)mx) d = qe - (double)mx;
+    d *= (1.0 - 9.313225746154785e-10);
+    return d * d;
+}
+__global__ void k_cl_e_leaf(int n, const unsigned int* __restrict__ code_s, const float4* __restrict__ spts,
+                            unsigned int* __restrict__ cell_e) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int c = code_s[i];
+    if (i > 0 && code_s[i - 1] == c) return;
+    float mn = spts[i].w, mx = mn;
+    for (int j = i + 1; j < n && code_s[j] == c; ++j) {
+        const float e = spts[j].w;
+        mn = fminf(mn, e);
+        mx = fmaxf(mx, e);
+    }
+    cell_e[c] = cl_pack_e(mn, mx);
+}
+__global__ void k_cl_e_up(int n, int l, const unsigned int* __restrict__ code_s, const int* __restrict__ cs,
+                          unsigned int* __restrict__ cell_e) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int key = code_s[i] >> (3 * l);
+    if (i > 0 && (code_s[i - 1] >> (3 * l)) == key) return;
+    const unsigned int* below = cell_e + cl_pur_off_fwd(l - 1);
+    float mn = INFINITY, mx = -INFINITY;
+    for (unsigned int ch = 0; ch < 8; ++ch) {
+        const unsigned int ck = key * 8 + ch;
+        const unsigned int c0 = ck << (3 * (l - 1));
+        if (cl_start(cs, c0) == cl_start(cs, c0 + (1u << (3 * (l - 1))))) continue;   // empty child: entry not written
+        float a, b;
+        cl_unpack_e(below[ck], a, b);
+        mn = fminf(mn, a);
+        mx = fmaxf(mx, b);
+    }
+    cell_e[cl_pur_off_fwd(l) + key] = cl_pack_e(mn, mx);
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
-                                                 const ClGrid* __restrict__ gp, const int* __restrict__ cs, int k,
+                                                 const ClGrid* __restrict__ gp, const int* __restrict__ cs,
+                                                 const unsigned int* __restrict__ cell_e, int k,
                                                  double* __restrict__ core2) {
     __shared__ unsigned int stack[CL_STACK * 256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,10 +312,12 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
         while (sp > 0) {
             int l, x, y, z;
             cl_unpack(st[(--sp) * 256], l, x, y, z);
-            if (cl_box_d2(g, qx, qy, qz, l, x, y, z) >= h[k]) continue;     // cannot lower the k-th distance (ALU only)
+            const double nb2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
+            if (nb2 >= h[k]) continue;                                       // cannot lower the k-th distance (ALU only)
             const unsigned int c0 = cl_code(x << l, y << l, z << l);
             const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
             if (j0 == j1) continue;
+            if (DIM >= 4 && l < CL_PUR_LEVELS && nb2 + cl_e_gap2(cell_e[cl_pur_off_fwd(l) + (c0 >> (3 * l))], qe) >= h[k]) continue;
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 for (int j = j0; j < j1; ++j) {
                     double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
@@ -282,10 +348,25 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
 // Boruvka
 #define CL_NONE 0xFFFFFFFFFFFFFFFFull   // 'no candidate' (sorts after every weight, +inf included)
 
-__global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter) {
+__global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter, int* __restrict__ pt_b) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) comp[i] = i;
+    if (i < n) { comp[i] = i; pt_b[i] = -1; }
     if (i == 0) counter[0] = 0;
+}
+
+// A point's candidate of the previous round stays its minimum foreign edge as long as the other end is still foreign
+// (components only grow): keep it, and publish its weight as the component's bound BEFORE the searches start, so the
+// points that do have to search again (their candidate was absorbed) prune against a tight bound from the first node on.
+// Without this every late round -- few, large components -- started all its traversals unbounded (3-4 ms per round).
+__global__ void k_cl_b_seed(int n, const int* __restrict__ comp, int* __restrict__ pt_b,
+                            const unsigned long long* __restrict__ pt_w, unsigned long long* __restrict__ best_w) {
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const int b = pt_b[a];
+    if (b < 0) return;
+    const int c = comp[a];
+    if (comp[b] == c) pt_b[a] = -1;                 // absorbed: search again
+    else atomicMin(&best_w[c], pt_w[a]);
 }
 
 __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned long long* __restrict__ best_w,
@@ -347,7 +428,8 @@ __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
 template <int DIM>
 __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                      const ClGrid* __restrict__ gp, const int* __restrict__ cs,
-                                                     const int* __restrict__ cell_comp, const int* __restrict__ perm,
+                                                     const int* __restrict__ cell_comp, const unsigned int* __restrict__ cell_e,
+                                                     const int* __restrict__ perm,
                                                      const double* __restrict__ core2, const int* __restrict__ comp,
                                                      unsigned long long* __restrict__ best_w,
                                                      unsigned long long* __restrict__ pt_w,
@@ -360,6 +442,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     const ClGrid g = *gp;
     const float4 qf = spts[a];
     const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[a] : 0.0;
+    if (pt_b[a] >= 0) return;                        // candidate of an earlier round still valid (k_cl_b_seed)
     const int ca = comp[a];
     const double core_a = core2[a];
     const int oa = perm[a];
@@ -395,6 +478,11 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
             if (j0 == j1) continue;
             if (l < CL_PUR_LEVELS && cell_comp[cl_pur_off(l) + (c0 >> (3 * l))] == ca) continue;   // all ours
+            if (DIM >= 4 && l < CL_PUR_LEVELS) {
+                const double ed2 = nd2 + cl_e_gap2(cell_e[cl_pur_off(l) + (c0 >> (3 * l))], qe);
+                const double elb = fmax(core_a, ed2);
+                if (elb > bw || elb > cbest || (elb == bw && ed2 > bd2)) continue;
+            }
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 bool improved = false;
                 for (int j = j0; j < j1; ++j) {
@@ -541,6 +629,24 @@ __device__ __forceinline__ float cl_d2_f32(float qx, float qy, float qz, const f
 }
 
 // counts[i] = min(cap, #{ target j : d2(q_i, t_j) < r2 })  -- pointcloud_utils.py:74-107 (ball_query + count_nonzero)
+// squared distance (float, slightly UNDER-estimated) from q to cell (x,y,z) of the grid: a cell is skipped only when even
+// this lower bound exceeds the radius.  Border cells extend to infinity outwards (points beyond the grid are clamped into them).
+__device__ __forceinline__ float cl_cell_d2_lb(const ClGrid& g, float qx, float qy, float qz, int x, int y, int z) {
+    const float q[3] = {qx, qy, qz};
+    const double o[3] = {g.ox, g.oy, g.oz};
+    const int c[3] = {x, y, z}, nb[3] = {CL_NX, CL_NY, CL_NZ};
+    float d2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = (float)(o[a] + (double)c[a] * CL_CELL), hi = (float)(o[a] + (double)(c[a] + 1) * CL_CELL);
+        float d = 0.f;
+        if (q[a] < lo && c[a] > 0) d = lo - q[a];
+        else if (q[a] > hi && c[a] < nb[a] - 1) d = q[a] - hi;
+        d2 += d * d;
+    }
+    return d2 * 0.9999f - 1e-6f;
+}
+
 __global__ __launch_bounds__(256) void k_cl_ball_count(const float* __restrict__ q, int nq, int qstride,
                                                        const float4* __restrict__ spts, const ClGrid* __restrict__ gp,
                                                        const int* __restrict__ cs, float r2, int reach, int cap,
@@ -555,6 +661,7 @@ __global__ __launch_bounds__(256) void k_cl_ball_count(const float* __restrict__
     for (int z = max(cz - reach, 0); z <= min(cz + reach, CL_NZ - 1); ++z)
         for (int y = max(cy - reach, 0); y <= min(cy + reach, CL_NY - 1); ++y)
             for (int x = max(cx - reach, 0); x <= min(cx + reach, CL_NX - 1); ++x) {
+                if (cl_cell_d2_lb(g, qx, qy, qz, x, y, z) >= r2) continue;          // no point of this cell can be inside
                 const unsigned int c = cl_code(x, y, z);
                 const int j0 = cl_start(cs, c), j1 = cl_start(cs, c + 1u);
                 for (int j = j0; j < j1; ++j) cnt += cl_d2_f32(qx, qy, qz, spts[j]) < r2 ? 1 : 0;
@@ -576,17 +683,24 @@ __global__ __launch_bounds__(256) void k_cl_nearest(const float* __restrict__ q,
     cl_cell_of(g, qx, qy, qz, cx, cy, cz);
     float best = INFINITY;
     int bi = -1;
+    auto scan = [&](int x, int y, int z) {
+        const unsigned int c = cl_code(x, y, z);
+        const int j0 = cl_start(cs, c), j1 = cl_start(cs, c + 1u);
+        for (int j = j0; j < j1; ++j) {
+            const float d2 = cl_d2_f32(qx, qy, qz, spts[j]);
+            if (d2 > r2max) continue;
+            const int o = perm[j];
+            if (d2 < best || (d2 == best && o < bi)) { best = d2; bi = o; }
+        }
+    };
+    if (reach >= 0) scan(cx, cy, cz);                 // the own cell first: its hit prunes most of the others
     for (int z = max(cz - reach, 0); z <= min(cz + reach, CL_NZ - 1); ++z)
         for (int y = max(cy - reach, 0); y <= min(cy + reach, CL_NY - 1); ++y)
             for (int x = max(cx - reach, 0); x <= min(cx + reach, CL_NX - 1); ++x) {
-                const unsigned int c = cl_code(x, y, z);
-                const int j0 = cl_start(cs, c), j1 = cl_start(cs, c + 1u);
-                for (int j = j0; j < j1; ++j) {
-                    const float d2 = cl_d2_f32(qx, qy, qz, spts[j]);
-                    if (d2 > r2max) continue;
-                    const int o = perm[j];
-                    if (d2 < best || (d2 == best && o < bi)) { best = d2; bi = o; }
-                }
+                if (x == cx && y == cy && z == cz) continue;
+                const float lb = cl_cell_d2_lb(g, qx, qy, qz, x, y, z);
+                if (lb > r2max || lb > best) continue;        // equal distances still compete on the index: strict >
+                scan(x, y, z);
             }
     idx[i] = bi;
     d2out[i] = best;
@@ -617,6 +731,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
         size_t tot = 0;
         for (int l = 0; l < CL_PUR_LEVELS; ++l) tot += (size_t)CL_NCODES >> (3 * l);
         VG_CHECK(hipMalloc(&h->d_cell_comp, 4 * tot));
+        VG_CHECK(hipMalloc(&h->d_cell_e, 4 * tot));
     }
     VG_CHECK(hipMalloc(&h->d_core2, 8 * n));
     VG_CHECK(hipMalloc(&h->d_comp, 4 * n));
@@ -651,7 +766,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
 
 void vg_cluster_destroy(vg_cluster* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp,
+    void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp, h->d_cell_e,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
                     h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
                     h->d_mst_idx, h->d_mst_idx_s, h->d_temp};
@@ -690,12 +805,12 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
 template <int DIM>
 static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
     hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, k, h->d_core2);
+                       h->d_cell_start, h->d_cell_e, k, h->d_core2);
 }
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
     hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                       h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
                        h->d_pt_key, h->d_pt_b);
 }
 
@@ -767,13 +882,18 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         const int rc = cl_build_grid(h, d_points, n, stride, dim, st);
         if (rc != VG_OK) return rc;
     }
+    if (dim >= 4) {
+        hipLaunchKernelGGL(k_cl_e_leaf, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_spts, h->d_cell_e);
+        for (int l = 1; l < CL_PUR_LEVELS; ++l)
+            hipLaunchKernelGGL(k_cl_e_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_e);
+    }
     if (dim == 3) cl_launch_core<3>(h, n, k, st);
     else if (dim == 4) cl_launch_core<4>(h, n, k, st);
     else cl_launch_core<5>(h, n, k, st);
     if (d_core2) hipLaunchKernelGGL(k_cl_unsort_core, dim3(nb), dim3(256), 0, st, n, h->d_perm, h->d_core2, d_core2);
     VG_LAUNCH_CHECK();
     // ---- Boruvka ----
-    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter);
+    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b);
     int rounds = 0, edges = 0;
     while (edges < n - 1) {
         if (++rounds > 64) {
@@ -781,6 +901,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
             return VG_ERR_HIP;
         }
         hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a);
+        if (rounds > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp);
         for (int l = 1; l < CL_PUR_LEVELS; ++l)
             hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp);
