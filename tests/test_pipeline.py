@@ -107,3 +107,9 @@ def test_sequence_pipeline_matches_oracle(cuda):
         ser = fs.serialize
         assert list(ser)[:4] == ['_detections', '_ground_point_indices', '_entropy_scores', '_entropy_indices']
     assert n_static > 0 and n_moving > 0
+    # frames in flight (worker streams + shared, precomputed clustering rows) give the same states
+    got2 = pipe.process_sequence(frames, poses, poses[0], entropy_args=ent_args, n_frames=2, seed=0, n_workers=2)
+    for (fa, ra), (fb, rb) in zip(got, got2):
+        assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off)
+        assert np.array_equal(fa.valid, fb.valid) and np.array_equal(fa.static, fb.static)
+        assert np.array_equal(ra['name'], rb['name']) and np.allclose(ra['boxes_lidar'], rb['boxes_lidar'])

@@ -38,3 +38,12 @@ for rep in range(2):
           f'ground+to_ref {ms(t0, t1):.2f}  entropy {ms(t1, t2):.2f}  reduce {ms(t2, t3):.2f}  two-frame clustering {ms(t3, t4):.2f}  '
           f'filter+classify+boxes {ms(t4, t5):.2f}  total {ms(t0, t5):.2f}  -> {1000.0 / ms(t0, t5):.1f} frames/s; '
           f'labels/frame {sum(len(o[1]["name"]) for o in out) / n_frames:.1f}, moving clusters/frame {sum(int((~o[0].static).sum()) for o in out) / n_frames:.1f}')
+
+# ---- the same through PseudoLabelPipeline.process_sequence, sequential and with frames in flight ----
+for nw in (1, 3):
+    pipe.process_sequence(d_frames[:4], poses[:4], poses[0], n_workers=nw)          # warm-up (worker handles)
+    sync(); t0 = time.perf_counter()
+    out = pipe.process_sequence(d_frames, poses, poses[0], n_workers=nw)
+    sync(); t1 = time.perf_counter()
+    print(f'process_sequence n_workers={nw}: {1000.0 * (t1 - t0) / n_frames:.2f} ms per frame -> {n_frames / (t1 - t0):.1f} frames/s, '
+          f'labels/frame {sum(len(o[1]["name"]) for o in out) / n_frames:.1f}')

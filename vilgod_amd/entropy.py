@@ -97,8 +97,9 @@ def full_scores(n, kept_scores, kept_idx, device=None):
 class TwoFrameClusterer:
     """spatial_clustering with n_frames > 1 (zero_shot_detector.py:208-242)."""
 
-    def __init__(self, cluster_model, n_frames=2, seed=0, dist_threshold=0.2):
+    def __init__(self, cluster_model, n_frames=2, seed=0, dist_threshold=0.2, parts=None):
         self.model = cluster_model
+        self._parts = parts                                  # precomputed frame parts (read-only), see precompute_parts
         self.n_frames = int(n_frames)
         self.seed = int(seed)
         g = np.float32(dist_threshold)                      # `dists > 0.2` on float32 squared distances (float64 compare)
@@ -108,10 +109,19 @@ class TwoFrameClusterer:
     def reset(self):
         self._cache = {}
 
+    def precompute_parts(self, X_list, ent_list):
+        """Every frame's clustering rows once, up front (a frame enters the input of two consecutive query frames): the
+        returned dict can be handed to other TwoFrameClusterer instances (worker threads) through `parts=`."""
+        L = len(X_list)
+        n_used = min(self.n_frames, L)
+        return {(f, n_used): self.frame_part(f, X_list[f], ent_list[f], n_used) for f in range(L)}
+
     def frame_part(self, f, X, ent, n_used):
         """Rows of frame f that enter the clustering input: [x, y, z, entropy] (CUDA float32 [m,4]).
         X: CUDA float32 [n,>=3]; ent: CUDA float32 [n] (full entropy array)."""
         key = (f, n_used)
+        if self._parts is not None and key in self._parts:
+            return self._parts[key]
         if key in self._cache:
             return self._cache[key]
         n = X.shape[0]
@@ -136,7 +146,8 @@ class TwoFrameClusterer:
             mask[mi] = others >= 2                                   # np.sum(dists < 0.1, axis=1) > 1
         rows = torch.nonzero(mask).squeeze(1)
         part = torch.cat([X.index_select(0, rows)[:, :3], ent.index_select(0, rows)[:, None]], dim=1)
-        self._cache = {kk: v for kk, v in self._cache.items() if kk[0] >= f - 1}
+        if self._parts is None:
+            self._cache = {kk: v for kk, v in self._cache.items() if kk[0] >= f - 1}
         self._cache[key] = part
         return part
 

@@ -310,7 +310,7 @@ class PseudoLabelPipeline:
         t0 = tick('cluster', t0)
         return self.label(fs, d_ref, d_X, gidx, labels, probs, t=t, t0=t0, tick=tick)
 
-    def process_sequence(self, frames, poses, ref_pose, entropy_args=None, n_frames=2, seed=0, first_fnr=0):
+    def process_sequence(self, frames, poses, ref_pose, entropy_args=None, n_frames=2, seed=0, first_fnr=0, n_workers=1):
         """The reference's DEFAULT stage order over a whole sequence (preprocessing.yaml:50-68):
         mask_ground_points -> calculate_entropy_scores (sliding window over the neighbouring frames) ->
         spatial_clustering with n_frames frames (5-D HDBSCAN + nearest-label transfer) -> filters / classification /
@@ -328,15 +328,39 @@ class PseudoLabelPipeline:
         for (fs, _, d_X, _), H in zip(prepared, H_list):
             fs.entropy_scores, fs.entropy_indices = scorer.reduce(H)
             ent_list.append(full_scores(d_X.shape[0], fs.entropy_scores, fs.entropy_indices, device=self.device))
-        two = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed) if n_frames > 1 else None
-        out = []
-        for i, (fs, d_ref, d_X, gidx) in enumerate(prepared):
-            if two is not None and len(frames) >= n_frames:
-                labels, probs = two.labels(i, X_list, ent_list)
-            else:
-                labels, probs = self.cluster(d_X)
-            out.append(self.label(fs, d_ref, d_X, gidx, labels, probs, entropy=ent_list[i].cpu().numpy()))
-        return out
+        use_two = n_frames > 1 and len(frames) >= n_frames
+        ent_host = [e.cpu().numpy() for e in ent_list]
+        if n_workers <= 1:
+            two = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed) if use_two else None
+            out = []
+            for i, (fs, d_ref, d_X, gidx) in enumerate(prepared):
+                labels, probs = two.labels(i, X_list, ent_list) if use_two else self.cluster(d_X)
+                out.append(self.label(fs, d_ref, d_X, gidx, labels, probs, entropy=ent_host[i]))
+            return out
+        # several frames in flight: ground / entropy / the per-frame clustering rows are sequence-level work on the caller's
+        # stream; clustering + label transfer + filters + classification + boxes of a frame run on a worker stream
+        from concurrent.futures import ThreadPoolExecutor
+        if self._workers is None or len(self._workers) < n_workers:
+            self._workers = [self._clone_for_worker() for _ in range(n_workers)]
+            self._pool = ThreadPoolExecutor(max_workers=n_workers)
+        parts = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed).precompute_parts(X_list, ent_list) if use_two else None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+
+        def run(worker, i):
+            fs, d_ref, d_X, gidx = prepared[i]
+            with torch.cuda.stream(worker.stream):
+                worker.stream.wait_event(ev)
+                if use_two:
+                    labels, probs = TwoFrameClusterer(worker.cluster_model, n_frames=n_frames, seed=seed, parts=parts).labels(i, X_list, ent_list)
+                else:
+                    labels, probs = worker.cluster(d_X)
+                r = worker.label(fs, d_ref, d_X, gidx, labels, probs, entropy=ent_host[i])
+                worker.stream.synchronize()
+            return r
+
+        futures = [self._pool.submit(run, self._workers[i % n_workers], i) for i in range(len(prepared))]
+        return [f.result() for f in futures]
 
     def label(self, fs, d_ref, d_X, gidx, labels, probs, entropy=None, t=None, t0=None, tick=None):
         """Everything after clustering: detections, static flags, filters, classification, boxes, results."""
