@@ -20,6 +20,8 @@
 // All distances are float64 with d2 = (dx*dx + dy*dy) + dz*dz on exactly converted float32 coordinates
 // (what the library computes after its float64 conversion); compiled with -ffp-contract=off.
 #include <string.h>
+#include <vector>
+#include <algorithm>
 #include <cstring>
 #include <math.h>
 #include <algorithm>
@@ -60,6 +62,7 @@ struct vg_cluster {
     unsigned long long *d_best_w, *d_best_e;
     int *d_sel_a, *d_sel_b;
     unsigned long long *d_pt_w, *d_pt_key, *d_pt_d, *d_best_d;   // pt_d / best_d: squared pair distance (tie-break after w)
+    double* d_pt_lb;                      // per point: a lower bound of the weight of ANY edge leaving its component (grows over the rounds)
     int* d_pt_b;
     int* d_counter;                       // [0] number of MST edges emitted
     int *d_mst_a, *d_mst_b;               // original ids
@@ -68,6 +71,7 @@ struct vg_cluster {
     void* d_temp;
     size_t temp_bytes;
     int* h_counter;                       // pinned
+    int* d_dbg;                           // VG_CLUSTER_DEBUG=1: points scanned per thread in the last search round
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -348,9 +352,10 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
 // Boruvka
 #define CL_NONE 0xFFFFFFFFFFFFFFFFull   // 'no candidate' (sorts after every weight, +inf included)
 
-__global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter, int* __restrict__ pt_b) {
+__global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter, int* __restrict__ pt_b,
+                            double* __restrict__ pt_lb) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { comp[i] = i; pt_b[i] = -1; }
+    if (i < n) { comp[i] = i; pt_b[i] = -1; pt_lb[i] = 0.0; }
     if (i == 0) counter[0] = 0;
 }
 
@@ -434,10 +439,13 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      unsigned long long* __restrict__ best_w,
                                                      unsigned long long* __restrict__ pt_w,
                                                      unsigned long long* __restrict__ pt_d,
-                                                     unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b) {
+                                                     unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b,
+                                                     double* __restrict__ pt_lb, int* __restrict__ dbg_scan) {
     __shared__ unsigned int stack[CL_STACK * 256];
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
+    int scanned = 0;
+    if (dbg_scan) dbg_scan[a] = 0;
     unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[a];
@@ -445,6 +453,18 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     if (pt_b[a] >= 0) return;                        // candidate of an earlier round still valid (k_cl_b_seed)
     const int ca = comp[a];
     const double core_a = core2[a];
+    // Every edge that leaves a's component from a weighs at least lb_a: its mutual-reachability weight is >= core_a, and
+    // >= the bound carried over from earlier rounds (a's own minimum foreign edge then, or the winning weight of its
+    // component when a was pruned) -- the foreign set only shrinks.  A point whose bound already exceeds the component's
+    // published best cannot supply the component's edge: interior points of large components drop out at once.
+    const double lb_a = fmax(core_a, pt_lb[a]);
+    {
+        const unsigned long long cb0 = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cb0 != CL_NONE && lb_a > __longlong_as_double((long long)cb0)) {
+            pt_w[a] = CL_NONE; pt_d[a] = ~0ull; pt_key[a] = ~0ull; pt_b[a] = -1;
+            return;
+        }
+    }
     const int oa = perm[a];
     int cx, cy, cz;
     cl_cell_of(g, qx, qy, qz, cx, cy, cz);
@@ -472,7 +492,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             cl_unpack(st[(--sp) * 256], l, x, y, z);
             // every edge into this node weighs at least lb; it must be able to tie or beat both bounds (ALU only)
             const double nd2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
-            const double lb = fmax(core_a, nd2);
+            const double lb = fmax(lb_a, nd2);
             if (lb > bw || lb > cbest || (lb == bw && nd2 > bd2)) continue;
             const unsigned int c0 = cl_code(x << l, y << l, z << l);
             const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
@@ -480,11 +500,12 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             if (l < CL_PUR_LEVELS && cell_comp[cl_pur_off(l) + (c0 >> (3 * l))] == ca) continue;   // all ours
             if (DIM >= 4 && l < CL_PUR_LEVELS) {
                 const double ed2 = nd2 + cl_e_gap2(cell_e[cl_pur_off(l) + (c0 >> (3 * l))], qe);
-                const double elb = fmax(core_a, ed2);
+                const double elb = fmax(lb_a, ed2);
                 if (elb > bw || elb > cbest || (elb == bw && ed2 > bd2)) continue;
             }
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 bool improved = false;
+                scanned += j1 - j0;
                 for (int j = j0; j < j1; ++j) {
                     if (comp[j] == ca) continue;
                     const double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
@@ -501,6 +522,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                 const unsigned long long cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
                 since_refresh = 0;
+                if (lb_a > cbest) { sp = 0; rr = nrx * nry; break; }      // this point can no longer win: stop
             }
             if (l == 0 || j1 - j0 <= CL_LEAF) continue;
             const int l1 = l - 1;
@@ -510,18 +532,21 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                 const int ch = c ^ near;
                 const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
                 const double cd2 = cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz);
-                const double clb = fmax(core_a, cd2);
+                const double clb = fmax(lb_a, cd2);
                 if (clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) continue;
                 if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, nx, ny, nz);
             }
         }
     }
+    if (dbg_scan) dbg_scan[a] = scanned;
     if (bb >= 0 && bw <= cbest) {
         pt_w[a] = (unsigned long long)__double_as_longlong(bw);
         pt_d[a] = (unsigned long long)__double_as_longlong(bd2);
         pt_key[a] = bkey;
         pt_b[a] = bb;
+        pt_lb[a] = bw;                       // a's true minimum foreign edge: a lower bound from now on
     } else {
+        if (cbest < INFINITY && cbest > pt_lb[a]) pt_lb[a] = cbest;      // everything a left unexplored weighs more than this
         pt_w[a] = CL_NONE;
         pt_d[a] = ~0ull;
         pt_key[a] = ~0ull;
@@ -744,6 +769,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_pt_w, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_key, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_d, 8 * n));
+    VG_CHECK(hipMalloc(&h->d_pt_lb, 8 * n));
     VG_CHECK(hipMalloc(&h->d_best_d, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_b, 4 * n));
     VG_CHECK(hipMalloc(&h->d_counter, 64));
@@ -754,6 +780,8 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_mst_idx, 4 * n));
     VG_CHECK(hipMalloc(&h->d_mst_idx_s, 4 * n));
     VG_CHECK(hipHostMalloc((void**)&h->h_counter, 64));
+    h->d_dbg = nullptr;
+    if (getenv("VG_CLUSTER_DEBUG")) VG_CHECK(hipMalloc(&h->d_dbg, 4 * n));
     size_t t1 = 0, t2 = 0, t3 = 0;
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t1, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, n, 0, 24));
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t2, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, n, 0, 64));
@@ -768,7 +796,7 @@ void vg_cluster_destroy(vg_cluster* h) {
     if (!h) return;
     void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp, h->d_cell_e,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
-                    h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
+                    h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_pt_lb, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
                     h->d_mst_idx, h->d_mst_idx_s, h->d_temp};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(h->h_counter);
@@ -811,7 +839,7 @@ template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
     hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                        h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                       h->d_pt_key, h->d_pt_b);
+                       h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg);
 }
 
 extern "C" {
@@ -893,7 +921,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
     if (d_core2) hipLaunchKernelGGL(k_cl_unsort_core, dim3(nb), dim3(256), 0, st, n, h->d_perm, h->d_core2, d_core2);
     VG_LAUNCH_CHECK();
     // ---- Boruvka ----
-    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b);
+    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b, h->d_pt_lb);
     int rounds = 0, edges = 0;
     while (edges < n - 1) {
         if (++rounds > 64) {
@@ -920,6 +948,15 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         VG_CHECK(hipMemcpyAsync(h->h_counter, h->d_counter, 4, hipMemcpyDeviceToHost, st));
         VG_CHECK(hipStreamSynchronize(st));
         int e = h->h_counter[0];
+        if (h->d_dbg) {
+            std::vector<int> sc(n);
+            (void)hipMemcpy(sc.data(), h->d_dbg, 4 * (size_t)n, hipMemcpyDeviceToHost);
+            std::sort(sc.begin(), sc.end());
+            long long tot = 0; int active = 0;
+            for (int v : sc) { tot += v; active += v > 0; }
+            fprintf(stderr, "[cluster dbg] round %d: edges %d -> %d, searching threads %d, scanned points: total %lld, median %d, p99 %d, p99.9 %d, max %d\n",
+                    rounds, edges, e, active, tot, sc[n / 2], sc[(size_t)n * 99 / 100], sc[(size_t)n * 999 / 1000], sc[n - 1]);
+        }
         if (e == edges) {
             fprintf(stderr, "[vilgod_hip] vg_cluster_mst: no progress in round %d (%d of %d edges)\n", rounds, e, n - 1);
             return VG_ERR_HIP;
