@@ -92,8 +92,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
-                                device_id=torch.device(f'cuda:{local_rank}'))
+        backend = os.environ.get('VILGOD_DIST_BACKEND', 'nccl')       # 'gloo' only for the 2-ranks-on-one-GPU self test
+        kw = {'device_id': torch.device(f'cuda:{local_rank}')} if backend == 'nccl' else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     dev = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(dev)
 
@@ -142,19 +143,25 @@ def main():
     # the one collective of the path: all-gather of the per-crop score matrices (padded to a common length)
     scores = torch.cat(score_mats) if score_mats else torch.zeros((0, 24), device=dev)
     if dist is not None:
-        n_loc = torch.tensor([scores.shape[0]], device=dev, dtype=torch.int64)
+        cdev = 'cpu' if dist.get_backend() == 'gloo' else dev
+        n_loc = torch.tensor([scores.shape[0]], device=cdev, dtype=torch.int64)
         n_all = [torch.zeros_like(n_loc) for _ in range(world)]
         dist.all_gather(n_all, n_loc)
         mx = int(max(int(x.item()) for x in n_all))
         pad = torch.zeros((mx, scores.shape[1]), device=dev, dtype=scores.dtype)
         pad[:scores.shape[0]] = scores
         gathered = torch.empty((world * mx, scores.shape[1]), device=dev, dtype=scores.dtype)
-        dist.all_gather_into_tensor(gathered, pad)
+        if dist.get_backend() == 'gloo':                  # host-staged in the self test; RCCL gathers device tensors directly
+            parts = [torch.empty_like(pad.cpu()) for _ in range(world)]
+            dist.all_gather(parts, pad.cpu())
+            gathered = torch.cat(parts).to(dev)
+        else:
+            dist.all_gather_into_tensor(gathered, pad)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device='cpu' if (dist is not None and dist.get_backend() == 'gloo') else dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

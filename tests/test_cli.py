@@ -99,3 +99,24 @@ def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
         for d, e in zip(x['_detections'], y['_detections']):
             assert np.array_equal(d['cluster_points_index'], e['cluster_points_index']) and d['valid'] == e['valid']
             assert d['static'] == e['static']
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(cuda):
+    """bench.py's N > 1 path (barriers, padded all-gather of the score matrices, max-over-ranks timing, one JSON line from
+    rank 0) with two processes sharing the single GPU of the test box over gloo; the driver's multi-GPU runs use RCCL."""
+    import json
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--points', '30000',
+           '--objects', '12', '--no-cpu-baseline', '--no-sequence-pass']
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(k), LOCAL_RANK='0'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:] + e[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['value'] > 0 and d['unit'] == 'frames/s'
+    assert d['value'] == pytest.approx(2 * 3 / (d['ms_per_step'] * 3 / 1000.0), rel=1e-3)       # whole-job frames / max-rank time
+    assert 0 < d['roofline']['frac'] < 1 and 'cpu_baseline' not in d
