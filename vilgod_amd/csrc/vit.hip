@@ -1343,6 +1343,17 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 }
 
 
+// Column tiles (256 wide) per L2 chunk of the tile order for the 256 x 256 kernels.  Measured at M = 64512 (sweep with
+// VG_GEMM_CW): sharing one activation row-tile between ALL column tiles that run together wins as long as there are at most
+// 9 of them (in_proj 9: 278 vs 292 us; c_proj 3, K = 3072: 302 vs 345 us although its 4.7 MB of weights exceed one XCD's L2 --
+// with single-column chunks the 396 MB of hidden activations stream from HBM three times); c_fc (12) is best with 4.
+static int gemm_chunk_tiles_256(int ntn) {
+    if (ntn <= 9) return ntn;
+    int cw = 4;
+    while (ntn % cw) --cw;
+    return cw;
+}
+
 template <int EPI, bool TRACE = false>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr) {
@@ -1355,10 +1366,8 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
         attr_set = true;
     }
     const int ntn = N / 256;
-    int cwt = (int)(2400000L / (256L * K * 2));
-    if (cwt < 1) cwt = 1;
-    if (cwt > ntn) cwt = ntn;
-    while (ntn % cwt) --cwt;
+    int cwt = gemm_chunk_tiles_256(ntn);
+    if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep
     hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
                        ldc, cwt, trace);
     VG_LAUNCH_CHECK();
@@ -1378,10 +1387,7 @@ static int launch_gemm_pp16(const void* X, const void* Wt, const float* bias, vo
         attr_set = true;
     }
     const int ntn = N / 256;
-    int cwt = (int)(2400000L / (256L * K * 2));
-    if (cwt < 1) cwt = 1;
-    if (cwt > ntn) cwt = ntn;
-    while (ntn % cwt) --cwt;
+    int cwt = gemm_chunk_tiles_256(ntn);
     hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
                        ldc, cwt);
     VG_LAUNCH_CHECK();
@@ -1400,10 +1406,7 @@ static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void
         attr_set = true;
     }
     const int ntn = N / 256;
-    int cwt = (int)(2400000L / (256L * K * 2));
-    if (cwt < 1) cwt = 1;
-    if (cwt > ntn) cwt = ntn;
-    while (ntn % cwt) --cwt;
+    int cwt = gemm_chunk_tiles_256(ntn);
     hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
                        ldc, cwt, trace);
     VG_LAUNCH_CHECK();
