@@ -323,12 +323,20 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             if (j0 == j1) continue;
             if (DIM >= 4 && l < CL_PUR_LEVELS && nb2 + cl_e_gap2(cell_e[cl_pur_off_fwd(l) + (c0 >> (3 * l))], qe) >= h[k]) continue;
             if (l == 0 || j1 - j0 <= CL_LEAF) {
-                for (int j = j0; j < j1; ++j) {
-                    double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
-                    if (d2 < h[CL_K - 1]) {
+                for (int jb = j0; jb < j1; jb += 4) {                       // four independent loads per trip
+                    float4 pj[4];
 #pragma unroll
-                        for (int u = 0; u < CL_K; ++u)
-                            if (d2 < h[u]) { double tmp = h[u]; h[u] = d2; d2 = tmp; }
+                    for (int u = 0; u < 4; ++u) pj[u] = spts[jb + u < j1 ? jb + u : j1 - 1];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int j = jb + v;
+                        if (j >= j1) continue;
+                        double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, pj[v], stt, j);
+                        if (d2 < h[CL_K - 1]) {
+#pragma unroll
+                            for (int u = 0; u < CL_K; ++u)
+                                if (d2 < h[u]) { double tmp = h[u]; h[u] = d2; d2 = tmp; }
+                        }
                     }
                 }
                 continue;
@@ -337,8 +345,17 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             const int l1 = l - 1;
             const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
             const int near = ox | (oy << 1) | (oz << 2);
+            // the 8 children are consecutive Morton ranges: their 9 boundaries are loaded together (independent loads), so
+            // empty octants -- most of them in LiDAR data -- are never pushed and never cost a pop with two dependent loads
+            int bnd[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) bnd[c] = cl_start(cs, c0 + ((unsigned int)c << (3 * l1)));
+            unsigned int occupied = 0;                    // bit c: child c holds points (static indices only: no scratch)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) occupied |= (bnd[c] != bnd[c + 1]) ? (1u << c) : 0u;
             for (int c = 7; c >= 0; --c) {
                 const int ch = c ^ near;
+                if (!((occupied >> ch) & 1u)) continue;
                 const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
                 if (cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz) >= h[k]) continue;
                 if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, nx, ny, nz);
@@ -506,14 +523,28 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 bool improved = false;
                 scanned += j1 - j0;
-                for (int j = j0; j < j1; ++j) {
-                    if (comp[j] == ca) continue;
-                    const double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
-                    if (d2 > bw) continue;
-                    const double w = fmax(fmax(d2, core_a), core2[j]);
-                    if (w > bw || (w == bw && d2 > bd2)) continue;
-                    const unsigned long long key = cl_edge_key(oa, perm[j]);
-                    if (w < bw || d2 < bd2 || key < bkey) { bw = w; bd2 = d2; bkey = key; bb = j; improved = true; }
+                // eight points per trip: their component ids and coordinates are loaded together (independent loads in
+                // flight), the slowest lane of a wave sets the kernel time and a one-point-per-trip loop is pure latency
+                for (int jb = j0; jb < j1; jb += 8) {
+                    int cj[8];
+                    float4 pj[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = jb + u < j1 ? jb + u : j1 - 1;
+                        cj[u] = comp[j];
+                        pj[u] = spts[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = jb + u;
+                        if (j >= j1 || cj[u] == ca) continue;
+                        const double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, pj[u], stt, j);
+                        if (d2 > bw) continue;
+                        const double w = fmax(fmax(d2, core_a), core2[j]);
+                        if (w > bw || (w == bw && d2 > bd2)) continue;
+                        const unsigned long long key = cl_edge_key(oa, perm[j]);
+                        if (w < bw || d2 < bd2 || key < bkey) { bw = w; bd2 = d2; bkey = key; bb = j; improved = true; }
+                    }
                 }
                 if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
                 since_refresh = 64;     // force a refresh below
@@ -528,8 +559,15 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             const int l1 = l - 1;
             const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
             const int near = ox | (oy << 1) | (oz << 2);
+            int bnd[9];                                  // boundaries of the 8 child ranges, loaded together (see k_cl_core)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) bnd[c] = cl_start(cs, c0 + ((unsigned int)c << (3 * l1)));
+            unsigned int occupied = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) occupied |= (bnd[c] != bnd[c + 1]) ? (1u << c) : 0u;
             for (int c = 7; c >= 0; --c) {
                 const int ch = c ^ near;
+                if (!((occupied >> ch) & 1u)) continue;
                 const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
                 const double cd2 = cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz);
                 const double clb = fmax(lb_a, cd2);
