@@ -38,8 +38,14 @@ def test_cli_single_process_and_resume(cuda, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import preprocess_data
     root = str(tmp_path / 'd1')
-    res = preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}'] + OVR)
+    res = preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}', 'export_pseudo_labels=True'] + OVR)
     out, idx, state = _load(root)
+    from vilgod_amd import export
+    import glob
+    npz = glob.glob(f'{root}/**/pseudo_labels_*/synthetic_train_0000.npz', recursive=True)
+    assert len(npz) == 1
+    lab = export.read_npz(npz[0])
+    assert len(lab) == 4 and [len(a['annos']['name']) for a in lab] == [len(fr['name']) for fr in out]
     assert len(out) == 4 and idx == [0, 1, 2, 3] and len(state) == 4
     for fr in out:
         assert set(fr) == {'boxes_lidar', 'name', 'score', 'moving'}

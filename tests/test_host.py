@@ -99,3 +99,26 @@ def test_two_rank_gather_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f'rank {r} ok' in o
+
+
+def test_pseudo_label_exporter_roundtrip(tmp_path):
+    """N3 exporter: result dicts -> OpenPCDet infos-style pickle + NPZ and back (empty frames included)."""
+    import pickle
+    import numpy as np
+    from vilgod_amd import export
+    rng = np.random.default_rng(0)
+    results = []
+    for n in (3, 0, 5):
+        results.append({'boxes_lidar': rng.normal(size=(n, 7)), 'name': np.array(['Vehicle', 'Pedestrian', 'Cyclist', 'Vehicle', 'Sign'][:n]),
+                        'score': rng.uniform(0.2, 1.0, size=n), 'moving': np.zeros(n, bool)})
+    pkl, npz = export.write_sequence(tmp_path, 'seq0', results, ['a', 'b', 'c'], [10, 11, 12], score_thresh=0.0,
+                                     class_names=['Vehicle', 'Pedestrian', 'Cyclist'])
+    infos = pickle.load(open(pkl, 'rb'))
+    assert [i['frame_id'] for i in infos] == ['a', 'b', 'c'] and [i['sample_idx'] for i in infos] == [10, 11, 12]
+    assert [len(i['annos']['name']) for i in infos] == [3, 0, 4]                  # 'Sign' is not a training class
+    assert infos[0]['annos']['gt_boxes_lidar'].dtype == np.float32 and infos[0]['annos']['gt_boxes_lidar'].shape == (3, 7)
+    back = export.read_npz(npz)
+    for a, b in zip(infos, back):
+        assert a['frame_id'] == b['frame_id'] and np.array_equal(a['annos']['name'], b['annos']['name'])
+        assert np.array_equal(a['annos']['gt_boxes_lidar'], b['annos']['gt_boxes_lidar'])
+        assert np.array_equal(a['annos']['score'], b['annos']['score'])

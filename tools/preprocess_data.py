@@ -93,6 +93,12 @@ def main(argv=None):
                 pickle.dump(zsd.detection_3d_result_list, f)
             with open(indices_file, 'wb') as f:
                 pickle.dump(dataset.sequence_indices, f)
+            if cfg.get('export_pseudo_labels', False):
+                # OpenPCDet `infos`-style pickle + NPZ under paths.pseudo_label (an addition: upstream declares the path, never writes it)
+                from vilgod_amd import export
+                ids = [info.get('frame_id', f'{sequence_name}_{i:03d}') for i, info in enumerate(dataset.sequence_infos)]
+                export.write_sequence(cfg.paths.pseudo_label, sequence_name, zsd.detection_3d_result_list, ids,
+                                      dataset.sequence_indices, class_names=dataset.class_names)
         del zsd
         gc.collect()
         torch.cuda.empty_cache()
