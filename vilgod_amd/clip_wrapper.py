@@ -40,12 +40,21 @@ class VitEncoder:
                       f'vg_vit_set_weight({name})')
         self._ws = None
         self._ws_crops = 0
+        self._owner = None               # set on views: keeps the owning encoder (and its handle) alive
+
+    def view(self):
+        """A second encoder object on the SAME weights (the device weights are read-only during encode) with its own
+        workspace: what a worker stream needs.  The owner must not enable profiling while views encode concurrently."""
+        import copy
+        v = copy.copy(self)
+        v._ws, v._ws_crops, v._owner = None, 0, self
+        return v
 
     def __del__(self):
         h = getattr(self, '_h', None)
-        if h is not None and lib is not None:
+        if h is not None and lib is not None and getattr(self, '_owner', None) is None:
             lib.vg_vit_destroy(h)
-            self._h = None
+        self._h = None
 
     def _workspace(self, n):
         if self._ws is None or n > self._ws_crops:
@@ -135,6 +144,13 @@ class ClipWrapper:
             self.weights_source = f'synthetic(seed={synthetic_seed})'
         self.text_features = text.to(self.device).contiguous()
         self.encoder = VitEncoder(weights, dtype=dtype, device=self.device)
+
+    def view(self):
+        """The same model for another worker stream: shared weights and text features, own ViT workspace."""
+        import copy
+        v = copy.copy(self)
+        v.encoder = self.encoder.view()
+        return v
 
     def predict_probs(self, crops, stream=None):
         feat = self.encoder.encode(crops, stream)

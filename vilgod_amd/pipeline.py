@@ -103,7 +103,7 @@ class PseudoLabelPipeline:
         w.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **self._mcfg)
         w.projection = RealisticProjection(_get(self.cfg, 'lidar_image_projection'), device=self.device,
                                            views=VIEWS_4 if self._n_views == 4 else VIEWS_6)
-        w.clip = ClipWrapper(self._clip_cfg, self._clip_model_path, device=self.device, dtype=self.vit_dtype)
+        w.clip = self.clip.view()                # shared read-only weights, own workspace
         w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         w.timings = {}
         w.stream = torch.cuda.Stream(device=self.device)

@@ -23,6 +23,7 @@ parity with the sequential reference), the other stages run on the 
 `evaluate_sequence` all-gathers scores and per-frame results so that every rank holds the sequence result.
 """
 import pickle
+import time
 from pathlib import Path
 
 import numpy as np
@@ -54,6 +55,7 @@ class ZeroShotDetector:
         self._dev = {}                                   # fnr -> dict of device tensors kept across stages
         self._scores = {}                                # fnr -> [n_crops, K] class probabilities
         self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
+        self.n_workers = int(dev.get('frames_in_flight', 3))
         self.init_lidar_frames()
         try:
             self.sync_lidar_frames(mode='load')
@@ -99,6 +101,37 @@ class ZeroShotDetector:
         dev = self.pipe.device
         return torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32)).to(dev), torch.from_numpy(seg).to(dev)
 
+    def _for_frames(self, frames, body, prepare=None):
+        """Run `body(pipe, fnr)` for every frame -- sequentially on the caller's stream, or, with device.frames_in_flight > 1,
+        on worker threads that own a stream and their own handles (cluster buffers, ViT workspace): `prepare(fnr)` is then
+        called for all frames first on the caller's stream (device data the bodies share), followed by one event the workers
+        wait for.  Bodies of different frames touch different FrameState objects."""
+        frames = list(frames)
+        nw = min(self.n_workers, len(frames))
+        if prepare is not None:
+            for f in frames:
+                prepare(f)
+        if nw <= 1:
+            for f in frames:
+                body(self.pipe, f)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        p = self.pipe
+        if p._workers is None or len(p._workers) < nw:
+            p._workers = [p._clone_for_worker() for _ in range(nw)]
+            p._pool = ThreadPoolExecutor(max_workers=nw)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(p.device))
+
+        def run(worker, f):
+            with torch.cuda.stream(worker.stream):
+                worker.stream.wait_event(ev)
+                body(worker, f)
+                worker.stream.synchronize()
+
+        for fut in [p._pool.submit(run, p._workers[i % nw], f) for i, f in enumerate(frames)]:
+            fut.result()
+
     def sync_lidar_frames(self, mode='save'):
         path = self.sequence_data_dir_path / f'{self.name}{self.cfg.postfix.sequence_data}'
         if mode == 'save':
@@ -120,7 +153,10 @@ class ZeroShotDetector:
         available = [t['name'] for t in self.cfg.pipeline]
         for task_name in self.cfg.pipeline_active:
             if task_name in available and hasattr(self, task_name):
+                t0 = time.perf_counter()
                 getattr(self, task_name)(**self.cfg.pipeline[available.index(task_name)]['args'])
+                torch.cuda.synchronize()
+                self.logger.info(f'  stage {task_name}: {1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1):.2f} ms per frame')
             else:
                 self.logger.warning(f'{task_name} NOT FOUND!!!')
         self.logger.info(f'Finished processing sequence: {self.name}')
@@ -209,31 +245,37 @@ class ZeroShotDetector:
             two = TwoFrameClusterer(self.pipe.cluster_model, n_frames=n_frames, seed=int(dev.get('subsample_seed', 0)))
         ecfg = self.cfg.preprocessor.clustering.get('entropy_score_filter', None) \
             if hasattr(self.cfg.preprocessor.clustering, 'get') else None
-        updated = False
-        for fnr in self.my_frames:
+        todo = [f for f in self.my_frames if self.lidar_frame_list[f].ground_point_indices is not None
+                and (self.lidar_frame_list[f].n_detections == 0 or force)]
+        X_list, ent_list, parts = [None] * self.lenght, [None] * self.lenght, None
+        if two is not None:
+            need = sorted({g for f in todo for g in two.used_frames(f, self.lenght)})
+            for g in need:
+                X_list[g] = self._ref_and_nonground(g)[1]
+                ent_list[g] = self._entropy_full(g)
+                if ent_list[g] is None:
+                    raise RuntimeError('spatial_clustering with n_frames > 1 reads the entropy scores: activate '
+                                       'calculate_entropy_scores first (preprocessing.yaml:50)')
+            n_used = min(n_frames, self.lenght)
+            parts = {(g, n_used): two.frame_part(g, X_list[g], ent_list[g], n_used) for g in need}      # shared, read-only
+        seed = two.seed if two is not None else 0
+
+        def body(p, fnr):
             fs = self.lidar_frame_list[fnr]
-            if fs.ground_point_indices is None or (fs.n_detections > 0 and not force):
-                continue
-            _, X = self._ref_and_nonground(fnr)
+            X = self._dev[fnr]['X']
             if two is not None:
-                X_list, ent_list = [None] * self.lenght, [None] * self.lenght
-                for f in two.used_frames(fnr, self.lenght):
-                    X_list[f] = self._ref_and_nonground(f)[1]
-                    ent_list[f] = self._entropy_full(f)
-                    if ent_list[f] is None:
-                        raise RuntimeError('spatial_clustering with n_frames > 1 reads the entropy scores: activate '
-                                           'calculate_entropy_scores first (preprocessing.yaml:50)')
-                labels, probs = two.labels(fnr, X_list, ent_list)
+                labels, probs = TwoFrameClusterer(p.cluster_model, n_frames=n_frames, seed=seed, parts=parts).labels(fnr, X_list, ent_list)
             else:
-                labels, probs = self.pipe.cluster(X)
-            fs.set_clusters(*pack_clusters(labels, probs, self.pipe.prob_threshold))     # lidar_frame.py:154-248
-            ent = self._entropy_full(fnr)
+                labels, probs = p.cluster(X)
+            fs.set_clusters(*pack_clusters(labels, probs, p.prob_threshold))     # lidar_frame.py:154-248
+            ent = self._dev[fnr].get('ent')
             if ent is not None and fs.n_detections:
                 fs.static = static_from_entropy(ent.cpu().numpy(), fs.index, fs.seg_off,
                                                 percentile=float(ecfg['percentile']) if ecfg else 30.0,
                                                 min_percentile_pp_score=float(ecfg['min_percentile_pp_score']) if ecfg else 0.5)
-            updated = True
-        if updated:
+
+        self._for_frames(todo, body, prepare=lambda f: (self._ref_and_nonground(f), self._entropy_full(f)))
+        if todo:
             self.sync_lidar_frames()
 
     def filter_detections(self, **kwargs):
@@ -263,23 +305,26 @@ class ZeroShotDetector:
         V = p.projection.num_views
         names = np.array(p.mapped_names, dtype=object)
         fine_names = np.array(p.class_list, dtype=object)
-        for fnr in self.my_frames:
+        todo = [f for f in self.my_frames if self.lidar_frame_list[f].n_detections > 0
+                and (key not in self.lidar_frame_list[f].cls or force)]
+
+        def body(pw, fnr):
             fs = self.lidar_frame_list[fnr]
-            if fs.n_detections == 0 or (key in fs.cls and not force):
-                continue
             which = fs.valid.copy() if valid_only else np.ones(fs.n_detections, bool)
             rows = np.flatnonzero(which)
             if len(rows) == 0:
-                continue
-            _, X = self._ref_and_nonground(fnr)
+                return
+            X = self._dev[fnr]['X']
             d_index, d_seg = self._cluster_lists(fnr, rows)
-            probs, top1, score = p.classify(X, d_index, d_seg, fs.transform_to_ego)
+            probs, top1, score = pw.classify(X, d_index, d_seg, fs.transform_to_ego)
             self._scores[fnr] = probs
             fine = top1.cpu().numpy().reshape(len(rows), V)
             sc = score.cpu().numpy().reshape(len(rows), V).astype(np.float32)
             mapped = p.fine_to_mapped[fine]
             win, final = vote(mapped, sc, p.mapped_names)
             fs.set_classes(key, which, names[mapped], fine_names[fine], sc, names[win], final)
+
+        self._for_frames(todo, body, prepare=self._ref_and_nonground)
         self.sync_lidar_frames()
 
     def fit_bounding_boxes_simple(self, method, **kwargs):
