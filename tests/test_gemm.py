@@ -20,7 +20,8 @@ def _ref(X, W, bias, resid, epi):
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [1, 0])
 @pytest.mark.parametrize('epi', [0, 1, 2, 3])
-@pytest.mark.parametrize('shape', [(256, 128, 64), (512, 768, 768), (256, 2304, 768), (256, 768, 3072), (768, 128, 128), (512, 3072, 768), (256, 1536, 96)])
+@pytest.mark.parametrize('shape', [(256, 128, 64), (512, 768, 768), (256, 2304, 768), (256, 768, 3072), (768, 128, 128), (512, 3072, 768), (256, 1536, 96),
+                                   (512, 512, 160), (256, 256, 128)])     # K % 64 != 0 -> k_gemm_f16_pp16; two K-tiles -> the shortest pp64 loop
 def test_gemm_epilogues(cuda, dtype, epi, shape):
     from vilgod_amd._lib import lib, ptr, stream_ptr, check
     M, N, K = shape
