@@ -235,6 +235,43 @@ def make_entropy():
     print('entropy_golden.npz', sorted(out)[:6], '...')
 
 
+def make_text():
+    """D8: the reference's tokenizer (third_party/CLIP/clip/simple_tokenizer.py, with `ftfy.fix_text` stubbed to identity: the
+    prompts are ASCII) and the reference's CLIP.encode_text (clip/model.py) on a small seeded text tower
+    (clip_weights.synthetic_text_weights) -> tests/golden/text_golden.npz (token ids + text features)."""
+    import types
+    import importlib.util
+    import torch
+    from vilgod_amd import clip_weights as cw
+    from vilgod_amd.pipeline import default_preprocessor_cfg
+    sys.modules.setdefault('ftfy', types.SimpleNamespace(fix_text=lambda t: t))
+    spec = importlib.util.spec_from_file_location('_ref_simple_tokenizer', f'{refstubs.REF}/third_party/CLIP/clip/simple_tokenizer.py')
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    tk = st.SimpleTokenizer()
+    cfg = default_preprocessor_cfg()['clip']
+    prompts = [cfg['prompt_template'].format(c) for c in cfg['class_list']]
+    extra = ["A photo of a   Dog's toy, 3 cats & 2.5 birds!", 'hello-world_foo BAR', "it's we're they'll"]
+    texts = prompts + extra
+    tokens = np.zeros((len(texts), 77), np.int64)
+    for i, t in enumerate(texts):
+        ids = [tk.encoder['<|startoftext|>']] + tk.encode(t) + [tk.encoder['<|endoftext|>']]
+        tokens[i, :len(ids)] = ids
+    m = refstubs.load_clip_model_py()
+    width, layers, embed = 64, 2, 32
+    model = m.CLIP(embed_dim=embed, image_resolution=32, vision_layers=1, vision_width=64, vision_patch_size=16, context_length=77,
+                   vocab_size=49408, transformer_width=width, transformer_heads=1, transformer_layers=layers)
+    sd = cw.synthetic_text_weights(0, width=width, layers=layers, embed=embed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith('visual.') or k == 'logit_scale' for k in missing), (missing, unexpected)
+    model = model.float().eval()
+    with torch.no_grad():
+        feat = model.encode_text(torch.from_numpy(tokens)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'text_golden.npz'), texts=np.array(texts), tokens=tokens, features=feat,
+                        width=width, layers=layers, embed=embed)
+    print('text_golden.npz', tokens.shape, feat.shape, 'longest prompt', int((tokens > 0).sum(1).max()), 'tokens')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['render', 'vit']
     for w in which:

@@ -67,6 +67,25 @@ def synthetic_text_features(seed=0, n_classes=24, dim=512):
     return t / t.norm(dim=-1, keepdim=True)
 
 
+def synthetic_text_weights(seed=0, width=64, layers=2, embed=32, vocab=49408, ctx=77):
+    """Seeded state dict of a (small) CLIP text tower with the key names of third_party/CLIP/clip/model.py:288-300 -- test
+    vector generator for vilgod_amd/clip_text.py (the same tensors are loaded into the reference model when the golden
+    features are made)."""
+    g = _gen(seed + 104729)
+    n = lambda *shape, std=1.0: torch.from_numpy((g.standard_normal(shape, dtype=np.float32) * std).astype(np.float32))
+    sd = {'token_embedding.weight': n(vocab, width, std=0.02), 'positional_embedding': n(ctx, width, std=0.01),
+          'ln_final.weight': 1 + n(width, std=0.1), 'ln_final.bias': n(width, std=0.1), 'text_projection': n(width, embed, std=width ** -0.5)}
+    for i in range(layers):
+        p = f'transformer.resblocks.{i}.'
+        sd[p + 'ln_1.weight'], sd[p + 'ln_1.bias'] = 1 + n(width, std=0.1), n(width, std=0.1)
+        sd[p + 'ln_2.weight'], sd[p + 'ln_2.bias'] = 1 + n(width, std=0.1), n(width, std=0.1)
+        sd[p + 'attn.in_proj_weight'], sd[p + 'attn.in_proj_bias'] = n(3 * width, width, std=width ** -0.5), n(3 * width, std=0.02)
+        sd[p + 'attn.out_proj.weight'], sd[p + 'attn.out_proj.bias'] = n(width, width, std=width ** -0.5), n(width, std=0.02)
+        sd[p + 'mlp.c_fc.weight'], sd[p + 'mlp.c_fc.bias'] = n(4 * width, width, std=width ** -0.5), n(4 * width, std=0.02)
+        sd[p + 'mlp.c_proj.weight'], sd[p + 'mlp.c_proj.bias'] = n(width, 4 * width, std=(4 * width) ** -0.5), n(width, std=0.02)
+    return sd
+
+
 def load_state_dict(path):
     """Real checkpoint: accepts a TorchScript archive (the published ViT-B-16.pt) or a plain
     state_dict; returns the `visual.*` tensors as float32 with the prefix dropped."""

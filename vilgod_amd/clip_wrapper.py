@@ -133,10 +133,15 @@ class ClipWrapper:
             weights = clip_weights.load_state_dict(ckpt)
             tf_path = ckpt + '.text_features.npy'
             if not os.path.exists(tf_path):
-                raise FileNotFoundError(
-                    f'{tf_path}: normalised text features [n_classes,{weights["proj"].shape[1]}] for the prompts '
-                    f'"{self.template}" x class_list are computed once off-line (text tower is not on the hot path)')
-            text = torch.from_numpy(np.load(tf_path)).float()
+                # clip_utils.py:22-26: tokenise the prompts, encode_text, normalise -- once, with plain torch, then cached
+                from . import clip_text
+                prompts = [self.template.format(c) for c in class_list]
+                feats = clip_text.text_features(ckpt, prompts, bpe_path=os.environ.get('CLIP_BPE'))
+                try:
+                    np.save(tf_path, feats)
+                except OSError:
+                    pass                                    # read-only model directory: recompute next time
+            text = torch.from_numpy(np.load(tf_path) if os.path.exists(tf_path) else feats).float()
             self.weights_source = ckpt
         else:
             weights = clip_weights.synthetic_vit_weights(synthetic_seed, **clip_weights.VIT_B16)
