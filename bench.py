@@ -165,7 +165,7 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    # roofline of the dominant kernel: HIP event pairs around every k_gemm_f16 launch on its launch stream, over a
+    # roofline of the dominant kernel: HIP event pairs around every k_gemm_f16_pp64 launch on its launch stream, over a
     # SEQUENTIAL pass (1 frame in flight) of the same workload right after the timed region -- with several frames in
     # flight the pairs would also span other streams' kernels and stop measuring this kernel.
     launches = gemm_ms = gemm_flops = all_launches = all_ms = all_flops = 0

@@ -96,12 +96,13 @@ int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream);
 
-/* development aid: ablation variants of the f16 GEMM kernels (k_gemm_f16: 0 shipped, 1 no in-loop DMA, 2 DMA only,
- * 3 no epilogue; k_gemm_f16_pp: 22 shipped, 20 two phases per K-step, 21/23 five stages) */
+/* development aid: the f16 GEMM kernels by number, bias epilogue (k_gemm_f16: 0, ablations 1 no in-loop DMA, 2 DMA only,
+ * 3 no epilogue; k_gemm_f16_pp (32x32x16, K-step 32): 22, 20 two phases per K-step, 21/23 five stages; k_gemm_f16_pp16: 30;
+ * k_gemm_f16_pp64, the production kernel: 32) */
 int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
                     void* stream);
 
-/* development aid: k_gemm_f16_pp (var 20..23) with per-wave cycle stamps.  d_trace receives, per (workgroup, wave),
+/* development aid: k_gemm_f16_pp (var 20..23) and k_gemm_f16_pp64 (var 32) with per-wave cycle stamps.  d_trace receives, per (workgroup, wave),
  * eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, epilogue cycles, LOAD-segment
  * cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks. */
 int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,

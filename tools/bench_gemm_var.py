@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vilgod_amd._lib import lib, ptr, stream_ptr, check
 dev = torch.device('cuda:0')
 M = (int(os.environ.get("CROPS", "240")) * 197 + 255) // 256 * 256
-vars_ = [int(v) for v in (sys.argv[1:] or ['0', '5'])]
+vars_ = [int(v) for v in (sys.argv[1:] or ['0', '22', '30', '32'])]      # k_gemm_f16, _pp (32x32), _pp16, _pp64
 for N, K, ldc in [(2304, 768, 2560), (3072, 768, 3072), (768, 768, 768), (768, 3072, 768)]:
     X = (torch.randn(M, K, device=dev) * 0.5).half(); W = (torch.randn(N, K, device=dev) * 0.05).half()
     b = torch.randn(N, device=dev); C = torch.zeros(M, ldc, dtype=torch.float16, device=dev)
