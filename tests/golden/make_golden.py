@@ -272,6 +272,97 @@ def make_text():
     print('text_golden.npz', tokens.shape, feat.shape, 'longest prompt', int((tokens > 0).sum(1).max()), 'tokens')
 
 
+class _RefKalman:
+    """Stand-in for the absent `filterpy.kalman.KalmanFilter` so that the reference's Track class can run here: filterpy's
+    published predict/update (kalman_filter.py: x = Fx, P = FPF' + Q; y = z - Hx, S = HPH' + R, K = PH'S^-1, x += Ky,
+    P = (I-KH)P(I-KH)' + KRK').  Written independently of vilgod_amd/tracking.py."""
+
+    def __init__(self, dim_x, dim_z):
+        self.x = np.zeros((dim_x, 1)); self.P = np.eye(dim_x); self.Q = np.eye(dim_x); self.F = np.eye(dim_x)
+        self.H = np.zeros((dim_z, dim_x)); self.R = np.eye(dim_z); self._I = np.eye(dim_x)
+
+    def predict(self):
+        self.x = np.dot(self.F, self.x)
+        self.P = np.dot(np.dot(self.F, self.P), self.F.T) + self.Q
+
+    def update(self, z):
+        z = np.asarray(z)
+        y = z - np.dot(self.H, self.x)
+        PHT = np.dot(self.P, self.H.T)
+        S = np.dot(self.H, PHT) + self.R
+        K = np.dot(PHT, np.linalg.inv(S))
+        self.x = self.x + np.dot(K, y)
+        I_KH = self._I - np.dot(K, self.H)
+        self.P = np.dot(np.dot(I_KH, self.P), I_KH.T) + np.dot(np.dot(K, self.R), K.T)
+
+
+def _ref_q_discrete_white_noise(dim, dt=1., var=1., block_size=1, order_by_dim=True):
+    assert dim == 4 and block_size == 1
+    Q = [[(dt**6)/36, (dt**5)/12, (dt**4)/6, (dt**3)/6],
+         [(dt**5)/12, (dt**4)/4, (dt**3)/2, (dt**2)/2],
+         [(dt**4)/6, (dt**3)/2, dt**2, dt],
+         [(dt**3)/6, (dt**2)/2, dt, 1.]]
+    return np.array(Q) * var
+
+
+def track_scene():
+    """The seeded scene of the N2 goldens: a short coherent sequence, clustered per frame by the oracle."""
+    from vilgod_amd import synthetic
+    from oracle import hdbscan_oracle as ho, segment_oracle as so, neighbors_oracle as no
+    frames, poses = synthetic.make_sequence(seed=11, n_frames=18, n_points=5000, n_objects=9, moving_frac=0.6)
+    X, clusters = [], []
+    for f, p in zip(frames, poses):
+        pr = so.apply_transform(f, np.linalg.inv(poses[0]) @ p)
+        X.append(np.ascontiguousarray(pr[pr[:, 2] > 0.25]))
+    kept = no.entropy_scores_sequence(X, 5, 1)
+    ent = [no.full_scores(len(x), s, i) for x, (s, i) in zip(X, kept)]
+    for fnr, x in enumerate(X):
+        labels, probs = ho.fit(x[:, :3])
+        dets = so.generate_detections(labels, probs)
+        # drop some detections so that tracks see misses, predictions, re-acquisitions and ends
+        dets = [(c, i) for k, (c, i) in enumerate(dets) if ((fnr * 7 + k * 3) % 11 >= 2 or fnr < 2) and not (k == 1 and 6 <= fnr <= 11)]
+        clusters.append(dets)
+    return frames, poses, X, ent, clusters
+
+
+def make_track():
+    """N2: the reference's Tracker / Track / Detection classes (src/vilgod/tracker.py, src/dataclass/objects.py,
+    src/utils/tracking_utils.py) run unchanged on the seeded scene, with `filterpy` replaced by the stand-in above
+    -> tests/golden/track_golden.pkl (tracks as lists of (frame, prediction flag, source frame, source cluster id))."""
+    import pickle
+    refstubs.install()
+    sys.modules['filterpy.kalman'].KalmanFilter = _RefKalman
+    sys.modules['filterpy.common'].Q_discrete_white_noise = _ref_q_discrete_white_noise
+    from src.dataclass.objects import Detection
+    from src.vilgod.tracker import Tracker
+    from oracle import neighbors_oracle as no
+    frames, poses, X, ent, clusters = track_scene()
+    cfg = refstubs.AttrDict(mode='cluster_center', assignment=refstubs.AttrDict(method='assign_detections_greedy', max_distance=1.0),
+                            min_length=5, max_missed=3, min_distance_dynamic=2.0)
+    tracker = Tracker('seq', cfg)
+    dets_per_frame = []
+    for fnr, (x, dets) in enumerate(zip(X, clusters)):
+        objs = []
+        for cid, idx in dets:
+            d = Detection(cluster_id=cid, cluster_points=x[idx], cluster_points_index=idx)
+            d.static = not no.filter_by_ephemeral_score(ent[fnr][idx])
+            d._fnr, d._cid = fnr, cid
+            objs.append(d)
+        dets_per_frame.append(objs)
+        tracker.next(objs, fnr)
+    tracker.finish()
+    tracks = []
+    for t in tracker.tracks:
+        tracks.append(dict(frames=list(t.frame_indices), entries=[(bool(d.track_prediction), d._fnr, d._cid) for d in t.detections],
+                           kf_x=np.array(t.kf.x), kf_P=np.array(t.kf.P)))
+    out = dict(clusters=[[(int(c), np.asarray(i)) for c, i in dets] for dets in clusters],
+               static=[[bool(d.static) for d in objs] for objs in dets_per_frame], tracks=tracks)
+    with open(os.path.join(OUT, 'track_golden.pkl'), 'wb') as f:
+        pickle.dump(out, f)
+    print('track_golden.pkl', len(tracks), 'tracks, lengths', sorted(len(t['frames']) for t in tracks)[-8:],
+          'predictions', sum(e[0] for t in tracks for e in t['entries']))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['render', 'vit']
     for w in which:
