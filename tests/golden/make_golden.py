@@ -357,10 +357,86 @@ def make_track():
                            kf_x=np.array(t.kf.x), kf_P=np.array(t.kf.P)))
     out = dict(clusters=[[(int(c), np.asarray(i)) for c, i in dets] for dets in clusters],
                static=[[bool(d.static) for d in objs] for objs in dets_per_frame], tracks=tracks)
+
+    # ---- fit_bounding_boxes_simple, track branch (zero_shot_detector.py:422-684), run unbound on a stand-in `self` ----
+    import types
+    import torch
+    from src.vilgod import zero_shot_detector as zsd
+    T_ref = [np.linalg.inv(poses[0]) @ p for p in poses]
+    lfl = [types.SimpleNamespace(fnr=f, detections=dets_per_frame[f], transform_to_ego=np.linalg.inv(poses[f]) @ poses[0])
+           for f in range(len(X))]
+    class_names = ['Vehicle', 'Pedestrian', 'Cyclist']
+    self_ = types.SimpleNamespace(tracker=tracker, lidar_frame_list=lfl, dataset=types.SimpleNamespace(class_names=class_names),
+                                  reset_progress_bar=lambda *a, **k: None, progress_bar=types.SimpleNamespace(update=lambda *a, **k: None),
+                                  sync_lidar_frames=lambda: None)
+    zsd.ZeroShotDetector.fit_bounding_boxes_simple(self_, {'name': 'minimum_bounding_rectangle', 'args': {}}, force=True,
+                                                   valid_only=True, fg_only=False, classification_key='clip')
+    for t, rec in zip(tracker.tracks, tracks):
+        rec['boxes_fit'] = np.array([d.bounding_box for d in t.detections])
+        rec['static_track_fit'] = [d.static_track for d in t.detections]
+        rec['track_static_fit'] = bool(t.static)
+
+    # ---- propagate_labels (zero_shot_detector.py:686-824) on seeded per-detection classification results ----
+    rng = np.random.default_rng(5)
+    names_all = ['Vehicle', 'Pedestrian', 'Cyclist', 'Background', 'Sign']
+    cls_in = []
+    for f, objs in enumerate(dets_per_frame):
+        row = []
+        for d in objs:
+            h = float(d.cluster_points[:, 2].max() - d.cluster_points[:, 2].min())
+            base = 0 if h < 1.9 and len(d.cluster_points) > 150 else (1 if h >= 1.5 else 3)
+            name = names_all[base] if rng.uniform() < 0.7 else names_all[int(rng.integers(0, 5))]
+            score = np.float32(rng.uniform(0.2, 0.95))
+            d.add_object_entry('object_class', 'clip', name)
+            d.add_object_entry('object_class_score', 'clip', score)
+            row.append((name, float(score)))
+        cls_in.append(row)
+    out['cls_in'] = cls_in
+
+    def sat_iou3d(a, b):
+        """Stand-in for pcdet's boxes_iou3d_gpu: only `iou > 0` is ever tested upstream (zero_shot_detector.py:739), so the
+        values are 1.0 where the rotated BEV rectangles overlap (separating-axis test) and the z ranges overlap, else 0."""
+        a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+
+        def corners(bx):
+            c, s = np.cos(bx[6]), np.sin(bx[6])
+            dx, dy = bx[3] / 2, bx[4] / 2
+            loc = np.array([[dx, dy], [-dx, dy], [-dx, -dy], [dx, -dy]])
+            return loc @ np.array([[c, s], [-s, c]]) + bx[:2]
+
+        def overlap(p, q):
+            for poly in (p, q):
+                for i in range(4):
+                    e = poly[(i + 1) % 4] - poly[i]
+                    ax = np.array([-e[1], e[0]])
+                    pp, qq = p @ ax, q @ ax
+                    if pp.max() <= qq.min() or qq.max() <= pp.min():
+                        return False
+            return True
+
+        res = np.zeros((len(a), len(b)), np.float32)
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                zo = min(x[2] + x[5] / 2, y[2] + y[5] / 2) - max(x[2] - x[5] / 2, y[2] - y[5] / 2)
+                res[i, j] = 1.0 if zo > 0 and overlap(corners(x), corners(y)) else 0.0
+        return torch.from_numpy(res)
+
+    zsd.iou3d_nms_utils = types.SimpleNamespace(boxes_iou3d_gpu=sat_iou3d)
+    zsd.ZeroShotDetector.propagate_labels(self_, classification_key='clip')
+    for t, rec in zip(tracker.tracks, tracks):
+        rec['track_static'] = bool(t.static); rec['track_valid'] = bool(t.valid); rec['class_label'] = t.class_label
+        rec['corrected'] = bool(t.class_label_corrected); rec['corrected_by_size'] = bool(t.class_label_corrected_by_size)
+        rec['boxes_final'] = np.array([d.bounding_box for d in t.detections])
+        rec['static_track_final'] = [d.static_track for d in t.detections]
+    out['final'] = [[dict(valid=bool(d.valid), name=d.object_class['clip'], score=float(d.object_class_score['clip']),
+                          box=None if d.bounding_box is None else np.array(d.bounding_box), static_track=d.static_track)
+                     for d in objs] for objs in dets_per_frame]
     with open(os.path.join(OUT, 'track_golden.pkl'), 'wb') as f:
         pickle.dump(out, f)
     print('track_golden.pkl', len(tracks), 'tracks, lengths', sorted(len(t['frames']) for t in tracks)[-8:],
-          'predictions', sum(e[0] for t in tracks for e in t['entries']))
+          'predictions', sum(e[0] for t in tracks for e in t['entries']),
+          '| moving tracks after fit', sum(not t['track_static_fit'] for t in tracks), 'after propagate', sum(not t['track_static'] for t in tracks),
+          '| invalid tracks', sum(not t['track_valid'] for t in tracks), '| labels', [t['class_label'] for t in tracks])
 
 
 if __name__ == '__main__':

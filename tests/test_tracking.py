@@ -61,3 +61,74 @@ def test_greedy_assignment_properties():
     assert np.array_equal(near[m[:, 0]], dist < 1.0) and not near[[i for i in range(7) if i not in m[:, 0]]].any()
     m0, n0 = tracking.assign_greedy(np.zeros((0, 2)), t, 1.0)
     assert m0.shape == (0, 2) and len(n0) == 0
+
+
+def build_table(gold, X):
+    tab = tracking.DetectionTable()
+    pts, stat = {}, {}
+    for fnr, (dets, flags) in enumerate(zip(gold['clusters'], gold['static'])):
+        for (cid, idx), st in zip(dets, flags):
+            pts[(fnr, cid)] = X[fnr][idx]
+            stat[(fnr, cid)] = st
+            tab.valid[(fnr, cid)] = True
+    return tab, pts, stat
+
+
+def entry_boxes(tab, t):
+    return np.array([t.clone_box[i] if t.prediction[i] else tab.box[t.source[i]] for i in range(len(t))], dtype=np.float64)
+
+
+def test_track_boxes_match_reference(gold, scene):
+    """The track branch of fit_bounding_boxes_simple with the REFERENCE's rectangle routine plugged in (the product plugs in the
+    GPU kernel's all-edges rectangle): motion vectors, motion-aligned boxes, top-3 median size, closest-corner shift."""
+    frames, poses, X = scene
+    tr = run_tracker(gold, X)
+    tab, pts, stat = build_table(gold, X)
+    to_ego = lambda f: np.linalg.inv(poses[f]) @ poses[0]
+    tracking.fit_track_boxes(tr, tab, pts.__getitem__, stat.__getitem__, to_ego, lambda xy: so.minimum_bounding_rectangle(xy, all_edges=False))
+    n_moving = 0
+    for t, g in zip(tr.tracks, gold['tracks']):
+        assert t.static == g['track_static_fit']
+        n_moving += not t.static
+        got = entry_boxes(tab, t)
+        assert got.shape == g['boxes_fit'].shape
+        # float32 medians / arctan2 upstream: agreement to ~1e-5 (identical code path, numpy's float32 arctan2 is <= 1 ulp)
+        assert np.allclose(got, g['boxes_fit'], rtol=0, atol=2e-5), np.abs(got - g['boxes_fit']).max()
+        flags = [t.clone_static_track[i] if t.prediction[i] else tab.static_track.get(t.source[i]) for i in range(len(t))]
+        assert flags == g['static_track_fit']
+    assert n_moving > 0
+
+
+def test_propagate_labels_matches_reference(gold, scene):
+    frames, poses, X = scene
+    tr = run_tracker(gold, X)
+    tab, pts, stat = build_table(gold, X)
+    to_ego = lambda f: np.linalg.inv(poses[f]) @ poses[0]
+    tracking.fit_track_boxes(tr, tab, pts.__getitem__, stat.__getitem__, to_ego, lambda xy: so.minimum_bounding_rectangle(xy, all_edges=False))
+    for fnr, (dets, cls) in enumerate(zip(gold['clusters'], gold['cls_in'])):
+        for (cid, _), (name, score) in zip(dets, cls):
+            tab.name[(fnr, cid)], tab.score[(fnr, cid)] = name, np.float32(score)
+    tracking.propagate_labels(tr, tab, lambda k: len(pts[k]), ['Vehicle', 'Pedestrian', 'Cyclist'], min_length=5)
+    for t, g in zip(tr.tracks, gold['tracks']):
+        assert (t.static, t.valid, t.class_label, t.class_label_corrected, t.class_label_corrected_by_size) == \
+               (g['track_static'], g['track_valid'], g['class_label'], g['corrected'], g['corrected_by_size'])
+        assert np.allclose(entry_boxes(tab, t), g['boxes_final'], rtol=0, atol=2e-5)
+    for fnr, (dets, fin) in enumerate(zip(gold['clusters'], gold['final'])):
+        for (cid, _), f in zip(dets, fin):
+            k = (fnr, cid)
+            assert tab.valid[k] == f['valid'] and tab.name[k] == f['name'] and abs(float(tab.score[k]) - f['score']) < 1e-6
+            assert tab.static_track.get(k) == f['static_track']
+            assert (f['box'] is None and k not in tab.box) or np.allclose(tab.box[k], f['box'], rtol=0, atol=2e-5)
+
+
+def test_small_pieces():
+    assert tracking.size_prior_class(np.array([0, 0, 0, 0.8, 0.7, 1.7, 0])) == 'Pedestrian'
+    assert tracking.size_prior_class(np.array([0, 0, 0, 1.8, 0.7, 1.7, 0])) == 'Cyclist'
+    assert tracking.size_prior_class(np.array([0, 0, 0, 4.5, 1.9, 1.6, 0])) == 'Vehicle'
+    assert tracking.size_prior_class(np.array([0, 0, 0, 12.0, 3.5, 4.0, 0])) == 'Background'
+    a = np.array([0, 0, 0, 4, 2, 1, 0.0]); b = np.array([2.5, 0, 0, 4, 2, 1, np.pi / 2]); c = np.array([4.1, 0, 0, 4, 2, 1, np.pi / 2])
+    assert tracking.rectangles_overlap(a, b) and not tracking.rectangles_overlap(a, c)
+    assert not tracking.rectangles_overlap(a, np.array([0, 0, 5, 4, 2, 1, 0.0]))          # apart in z
+    ang = tracking.dominant_angles([0.10, 0.11, 0.12 + np.pi, 1.5, 3.0 + 2 * np.pi])
+    assert len(ang) == 3 and abs(np.mean(ang) - 0.11) < 1e-9
+    assert tracking.motion_vectors(np.zeros((6, 2), np.float32)) == []                        # a cluster that never moves: static path

@@ -189,3 +189,279 @@ class Tracker:
         for t in self.tracks:
             if t.active:
                 t.finalize()
+
+
+# ================================================================================================================
+# Boxes of tracked clusters -- the track branch of fit_bounding_boxes_simple (zero_shot_detector.py:463-684)
+# ================================================================================================================
+def static_box(points, rectangle):
+    """zero_shot_detector.py:477-488 / :451-461: rectangle of the x,y footprint -> [cx, cy, cz, l, w, h + 0.3, rz] with l >= w.
+    rectangle(xy) -> (corners [4,2], rz, area) is `minimum_bounding_rectangle` (pointcloud_utils.py:300-373)."""
+    corners, rz, _ = rectangle(points[:, :2])
+    l = np.linalg.norm(corners[0] - corners[1])
+    w = np.linalg.norm(corners[0] - corners[-1])
+    c = (corners[0] + corners[2]) / 2
+    if w > l:
+        l, w = w, l
+        rz += np.pi / 2
+    height = points[:, 2].max() - points[:, 2].min()
+    return np.array([c[0], c[1], points[:, 2].min() + height / 2, l, w, height + 0.3, rz])
+
+
+def _angle_deg(v1, v2):
+    """common_utils.py:73-76 (a zero vector gives nan, which fails every comparison below, as upstream)."""
+    with np.errstate(invalid='ignore', divide='ignore'):
+        cos = v1 @ v2 / (np.linalg.norm(v1) * np.linalg.norm(v2))
+    return np.rad2deg(np.arccos(np.clip(cos, -0.9999, 0.9999)))
+
+
+def motion_vectors(centers_xy, look_ahead=10, min_far=0.5, min_step=0.3, max_angle=60):
+    """Direction of travel per track entry from the cluster medians (zero_shot_detector.py:491-566).
+    For entry c: `far` = vector to the entry look_ahead-1 steps on (searched further while shorter than 0.5 m and none is known
+    yet; otherwise the last good one is kept); the steps to the entries in between that point within 60 deg of `far` and are
+    longer than 0.3 m are averaged with weights 0.95^(i+1) / sum 0.9^(i+1) (i = ABSOLUTE entry index) and blended 50:50 with
+    the previous direction; no such step -> previous direction, else `far`.  Any entry without a `far` vector voids the whole
+    track (-> []), which sends it down the static path.  float32 throughout, like the medians."""
+    n = len(centers_xy)
+    out = []
+    far = None
+    for c in range(n):
+        here = centers_xy[c]
+        c_far = min(c + look_ahead - 1, n - 1)
+        cand = np.array([centers_xy[c_far, 0] - here[0], centers_xy[c_far, 1] - here[1]])
+        if np.linalg.norm(cand) < min_far and far is None:
+            k = 1
+            while np.linalg.norm(cand) < min_far and (c_far + k) < n:
+                cand = np.array([centers_xy[c_far + k, 0] - here[0], centers_xy[c_far + k, 1] - here[1]])
+                k += 1
+            if np.linalg.norm(cand) >= min_far:
+                far = cand
+        elif np.linalg.norm(cand) < min_far:
+            pass                                         # slow stretch in the middle / at the end: keep the last direction
+        else:
+            far = cand
+        if far is None:
+            return []
+        steps, wsum = [], 0
+        for i in range(c + 1, c_far):
+            step = np.array([centers_xy[i, 0] - here[0], centers_xy[i, 1] - here[1]])
+            if _angle_deg(far, step) < max_angle and np.linalg.norm(step) > min_step:
+                steps.append(step * (0.95 ** (i + 1)))
+                wsum += (0.9 ** (i + 1))
+        if steps:
+            v = np.mean(steps, axis=0) / wsum
+            if out:
+                v = v * 0.5 + out[-1] * 0.5
+            out.append(v)
+        elif out:
+            out.append(out[-1])
+        else:
+            out.append(far)
+    return out
+
+
+def moving_boxes(points_list, directions, to_ego_list, top_k=3):
+    """zero_shot_detector.py:572-659: a box per entry aligned with its direction of travel, all resized to the median size of the
+    top_k entries with the most points and shifted so that the corner closest to the ego vehicle stays where it was."""
+    from scipy.spatial.transform import Rotation as R
+    boxes, corner_list = [], []
+    for pts_all, d in zip(points_list, directions):
+        angle = np.arctan2(d[1], d[0])
+        rot = R.from_euler('z', angle, degrees=False).as_matrix()
+        center = np.median(pts_all[..., :3], axis=0)
+        proj = np.dot(pts_all[..., :3] - center, rot)
+        min_x, max_x = proj[:, 0].min(), proj[:, 0].max()
+        min_y, max_y = proj[:, 1].min(), proj[:, 1].max()
+        rect = np.array([[max_x, min_y], [min_x, min_y], [min_x, max_y], [max_x, max_y]], dtype=np.float32)
+        corners = np.dot(rect, rot[:2, :2].T)
+        corners += center[:2]
+        w = np.linalg.norm(corners[0] - corners[1])
+        l = np.linalg.norm(corners[0] - corners[-1])
+        c = (corners[0] + corners[2]) / 2
+        corner_list.append(corners)
+        height = pts_all[:, 2].max() - pts_all[:, 2].min()
+        boxes.append(np.array([c[0], c[1], pts_all[:, 2].min() + height / 2, w, l, height, angle]))
+    boxes = np.array(boxes)
+    top = np.argsort([len(p) for p in points_list])[-top_k:]
+    ref = np.median(boxes[top], axis=0)
+    tops = np.array([np.max(p[..., 2]) for p in points_list])
+    for i, (corners, T) in enumerate(zip(corner_list, to_ego_list)):
+        h = np.hstack((np.concatenate([corners, np.zeros((4, 1))], axis=1), np.ones((4, 1))))
+        ego = np.einsum('ij,kj->ki', T, h)[:, :2]                      # apply_transform (pointcloud_utils.py:21-46)
+        cc = int(np.linalg.norm(ego, axis=1).argmin())
+        dw, dl = ref[3] - boxes[i, 3], ref[4] - boxes[i, 4]
+        ang = np.arctan2(directions[i][1], directions[i][0])
+        sx = -1.0 if cc in (0, 3) else 1.0                             # corners 0,3 hold max x: grow towards -x
+        sy = 1.0 if cc in (0, 1) else -1.0                             # corners 0,1 hold min y: grow towards +y
+        boxes[i, 0] += sx * (dw / 2) * np.cos(ang)
+        boxes[i, 1] += sx * (dw / 2) * np.sin(ang)
+        boxes[i, 0] += sy * (dl / 2) * np.sin(-ang)
+        boxes[i, 1] += sy * (dl / 2) * np.cos(-ang)
+    boxes[..., 3:6] = ref[3:6]
+    boxes[..., 2] = tops - (ref[5] / 2)
+    return boxes
+
+
+class DetectionTable:
+    """Mutable per-detection state shared by all tracks that hold the detection (the far-match rule can put one detection into
+    two tracks, and upstream mutates the one Detection object from both): box, static_track, valid, class name / score.
+    Entries that are predictions are private clones of their track (objects.py:311-317) and live in the track instead."""
+
+    def __init__(self):
+        self.box, self.static_track, self.valid, self.name, self.score = {}, {}, {}, {}, {}
+
+
+def _entry_get(tab, t, i, field):
+    return getattr(t, 'clone_' + field)[i] if t.prediction[i] else getattr(tab, field).get(t.source[i])
+
+
+def _entry_set(tab, t, i, field, value):
+    if t.prediction[i]:
+        getattr(t, 'clone_' + field)[i] = value
+    else:
+        getattr(tab, field)[t.source[i]] = value
+
+
+def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle):
+    """The track branch of fit_bounding_boxes_simple for every valid track, in track order: boxes and `static_track` flags of
+    the entries (into `tab` for real detections, into the track for its clones) and `track.static`.
+    points_of(key) -> cluster points [n,>=3]; static_of(key) -> Detection.static (the entropy flag); to_ego_of(fnr) -> 4x4;
+    rectangle(xy) -> (corners, rz, area)."""
+    for t in tracker.tracks_valid:
+        n = len(t)
+        pts = [points_of(k) for k in t.source]
+        t.clone_box = [None] * n
+        t.clone_static_track = [None] * n
+        t.clone_valid = [True] * n
+        if all(static_of(k) for k in t.source):
+            for i in range(n):
+                _entry_set(tab, t, i, 'box', static_box(pts[i], rectangle))
+            continue
+        centers = np.array([np.median(p[..., :2], axis=0) for p in pts])
+        dirs = motion_vectors(centers)
+        if dirs:
+            boxes = moving_boxes(pts, dirs, [to_ego_of(f) for f in t.frames])
+            for i in range(n):
+                _entry_set(tab, t, i, 'box', boxes[i])
+                _entry_set(tab, t, i, 'static_track', False)
+            t.static = False
+        else:
+            for i in range(n):
+                _entry_set(tab, t, i, 'static_track', True)
+                _entry_set(tab, t, i, 'box', static_box(pts[i], rectangle))
+
+
+# ================================================================================================================
+# propagate_labels (zero_shot_detector.py:686-824)
+# ================================================================================================================
+def size_prior_class(box):
+    """check_box (zero_shot_detector.py:691-701)."""
+    l, w, h = box[3:6]
+    if h > 0.8 and h <= 2.3 and w > 0.2 and w <= 1 and l > 0.2 and l <= 1:
+        return 'Pedestrian'
+    if h > 1.4 and h <= 2 and w > 0.5 and w <= 1 and l > 1 and l <= 2.5:
+        return 'Cyclist'
+    if w > 0.5 and w <= 3 and l > 0.5 and l <= 8.0 and h > 1 and h <= 3:
+        return 'Vehicle'
+    return 'Background'
+
+
+def dominant_angles(angles, n_bins=45):
+    """pointcloud_utils.bin_angles (:525-560): the angles (folded into [0, pi]) of the fullest of n_bins bins."""
+    edges = np.linspace(0, np.pi, n_bins + 1)
+    bins = [[] for _ in range(n_bins)]
+    for a in angles:
+        a = a % (2 * np.pi)
+        if a > np.pi:
+            a %= np.pi
+        b = np.digitize(a, edges, right=False) - 1
+        if 0 <= b < n_bins:
+            bins[b].append(a)
+    return bins[int(np.argmax([len(b) for b in bins]))]
+
+
+def rectangles_overlap(a, b):
+    """Do the rotated BEV rectangles of boxes a and b [cx,cy,cz,l,w,h,rz] share area, and their z ranges length?  The only
+    thing upstream asks of `boxes_iou3d_gpu` (a pcdet CUDA op) is `iou > 0` (zero_shot_detector.py:737-739)."""
+    if min(a[2] + a[5] / 2, b[2] + b[5] / 2) - max(a[2] - a[5] / 2, b[2] - b[5] / 2) <= 0:
+        return False
+
+    def corners(bx):
+        c, s = np.cos(bx[6]), np.sin(bx[6])
+        hx, hy = bx[3] / 2, bx[4] / 2
+        loc = np.array([[hx, hy], [-hx, hy], [-hx, -hy], [hx, -hy]])
+        return loc @ np.array([[c, s], [-s, c]]) + bx[:2]
+
+    p, q = corners(np.asarray(a, np.float64)), corners(np.asarray(b, np.float64))
+    for poly in (p, q):
+        for i in range(4):
+            e = poly[(i + 1) % 4] - poly[i]
+            ax = np.array([-e[1], e[0]])
+            pp, qq = p @ ax, q @ ax
+            if pp.max() <= qq.min() or qq.max() <= pp.min():
+                return False
+    return True
+
+
+def propagate_labels(tracker, tab, n_points_of, class_names, min_length=5, top_k=10):
+    """Track-level label and box clean-up; mutates `tab` (real detections), the tracks' clone arrays and track flags."""
+    for t in tracker.tracks_valid:
+        n = len(t)
+        real = [i for i in range(n) if not t.prediction[i]]
+        if n < min_length:
+            for i in range(n):
+                _entry_set(tab, t, i, 'valid', False)
+            continue
+        max_score, class_name, count = 0, 'Background', {}
+        for i in real:
+            k = t.source[i]
+            if tab.score[k] > max_score:
+                max_score, class_name = tab.score[k], tab.name[k]
+            count[tab.name[k]] = count.get(tab.name[k], 0) + 1
+        if not t.static:                                    # a "moving" track whose boxes all overlap its largest one is static
+            boxes = np.array([_entry_get(tab, t, i, 'box') for i in range(n)], dtype=np.float64).astype(np.float32).astype(np.float64)
+            ref = boxes[int(np.argmax(np.prod(boxes[..., 3:5], axis=1)))].copy()
+            ref[2], ref[5] = 0, 1
+            boxes[..., 2], boxes[..., 5] = 0, 1
+            if all(rectangles_overlap(ref, b) for b in boxes):
+                t.static = True
+                for i in range(n):
+                    _entry_set(tab, t, i, 'static_track', True)
+        if t.static:
+            if real:
+                boxes = np.array([tab.box[t.source[i]] for i in real])
+                npts = [n_points_of(t.source[i]) for i in real]
+                boxes = boxes[np.argsort(npts)[::-1][:top_k]]
+                median_box = np.median(boxes, axis=0)
+                median_box[6] = np.mean(dominant_angles(boxes[..., 6]))
+                l, w, h = median_box[3:6]
+                if l < 0.2 or l > 20 or w < 0.2 or w > 3.5 or h < 0.5 or h > 4:
+                    t.valid = False
+                    for i in range(n):
+                        _entry_set(tab, t, i, 'valid', False)
+                    continue
+                for i in range(n):
+                    _entry_set(tab, t, i, 'box', median_box.copy())
+        frac = (lambda: count[class_name] / n)
+        for i in real:
+            k = t.source[i]
+            in_names = class_name in class_names
+            if in_names and (max_score >= 0.5 or frac() >= 0.6):
+                tab.name[k], tab.score[k] = class_name, max_score
+                t.class_label_corrected, t.class_label = True, class_name
+            elif (not t.static) and in_names and class_name in ('Cyclist', 'Pedestrian') and (max_score >= 0.35 or frac() >= 0.6):
+                tab.name[k], tab.score[k] = class_name, 0.7
+                t.class_label_corrected, t.class_label = True, class_name
+            elif class_name == 'Background' and max_score >= 0.3:
+                tab.name[k], tab.score[k] = class_name, (max_score if not t.static else 1.0)
+                t.class_label_corrected, t.class_label = True, class_name
+            elif not t.static:
+                new = size_prior_class(tab.box[k])
+                t.class_label_corrected_by_size = new != tab.name[k]
+                t.class_label = new
+                tab.name[k], tab.score[k] = new, 0.5
+            if not t.static:
+                tab.static_track[k] = False
+            box = np.array(tab.box[k], dtype=np.float64, copy=True)      # enlarge by a small margin
+            box[3:5] += 0.3
+            tab.box[k] = box
