@@ -107,6 +107,7 @@ class FrameState:
         self.valid = np.zeros(0, bool)
         self.static = np.zeros(0, bool)
         self.tid = np.zeros(0, np.int64)
+        self.static_track = np.zeros(0, np.int8)       # -1 = None (never tracked), 0 = moving track, 1 = static track (objects.py:59)
         self.boxes = None                              # [C,7] float64 ref frame, NaN rows = no box
         self.cls = {}                                  # key -> dict(pred, detailed, score [C,V]; name, final [C]; has [C])
         self.filtered = False
@@ -122,6 +123,7 @@ class FrameState:
         self.valid = np.ones(C, bool)                  # Detection.valid default (objects.py:57)
         self.static = np.ones(C, bool)                 # :58
         self.tid = np.full(C, -1, np.int64)            # :64
+        self.static_track = np.full(C, -1, np.int8)
 
     def cluster_index(self, c):
         return self.index[self.seg_off[c]:self.seg_off[c + 1]]
@@ -150,6 +152,8 @@ class FrameState:
         if has:
             d['object_class_predictions'] = {k: self.cls[k]['pred'][c].astype(str) for k in has}
         d['tid'] = int(self.tid[c])
+        if self.static_track[c] >= 0:
+            d['static_track'] = bool(self.static_track[c])
         if has:
             d['object_class_predictions_detailed'] = {k: self.cls[k]['detailed'][c].astype(str) for k in has}
             d['object_class_predictions_score'] = {k: self.cls[k]['score'][c].copy() for k in has}
@@ -187,6 +191,7 @@ class FrameState:
         self.valid = np.array([bool(d.get('valid', True)) for d in dets])
         self.static = np.array([bool(d.get('static', True)) for d in dets])
         self.tid = np.array([int(d.get('tid', -1)) for d in dets], dtype=np.int64)
+        self.static_track = np.array([-1 if d.get('static_track') is None else int(bool(d['static_track'])) for d in dets], dtype=np.int8)
         self.filtered = bool((~self.valid).any())      # zero_shot_detector.py:265-274: any invalid detection = already filtered
         if any('_bounding_box' in d for d in dets):
             self.boxes = np.full((C, 7), np.nan)

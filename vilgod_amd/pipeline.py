@@ -107,17 +107,21 @@ class PseudoLabelPipeline:
         w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         w.timings = {}
         w.stream = torch.cuda.Stream(device=self.device)
+        from concurrent.futures import ThreadPoolExecutor
+        w.thread = ThreadPoolExecutor(max_workers=1)       # a worker's frames run one after the other on ITS thread
         return w
+
+    def _ensure_workers(self, n_workers):
+        if self._workers is None or len(self._workers) < n_workers:
+            self._workers = (self._workers or []) + [self._clone_for_worker() for _ in range(n_workers - len(self._workers or []))]
+        return self._workers[:n_workers]
 
     def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0):
         """Throughput mode: frames (list of CUDA/numpy point arrays) are processed with `n_workers` frames in flight,
         each on its own HIP stream with its own handles.  Ground segmentation is stateful across frames and runs in
         frame order on the caller's stream; everything else of a frame runs on a worker stream after an event wait.
         Returns [(FrameState, result dict, probs tensor)] in frame order."""
-        from concurrent.futures import ThreadPoolExecutor
-        if self._workers is None or len(self._workers) < n_workers:
-            self._workers = [self._clone_for_worker() for _ in range(n_workers)]
-            self._pool = ThreadPoolExecutor(max_workers=n_workers)
+        workers = self._ensure_workers(n_workers)
         main = torch.cuda.current_stream(self.device)
 
         def run(worker, i, d_pts, mask, ev):
@@ -134,7 +138,8 @@ class PseudoLabelPipeline:
             mask = self.ground(d_pts)
             ev = torch.cuda.Event()
             ev.record(main)
-            futures.append(self._pool.submit(run, self._workers[i % n_workers], i, d_pts, mask, ev))
+            w = workers[i % n_workers]
+            futures.append(w.thread.submit(run, w, i, d_pts, mask, ev))
         return [f.result() for f in futures]
 
     @staticmethod
@@ -339,10 +344,7 @@ class PseudoLabelPipeline:
             return out
         # several frames in flight: ground / entropy / the per-frame clustering rows are sequence-level work on the caller's
         # stream; clustering + label transfer + filters + classification + boxes of a frame run on a worker stream
-        from concurrent.futures import ThreadPoolExecutor
-        if self._workers is None or len(self._workers) < n_workers:
-            self._workers = [self._clone_for_worker() for _ in range(n_workers)]
-            self._pool = ThreadPoolExecutor(max_workers=n_workers)
+        workers = self._ensure_workers(n_workers)
         parts = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed).precompute_parts(X_list, ent_list) if use_two else None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
@@ -359,7 +361,7 @@ class PseudoLabelPipeline:
                 worker.stream.synchronize()
             return r
 
-        futures = [self._pool.submit(run, self._workers[i % n_workers], i) for i in range(len(prepared))]
+        futures = [workers[i % n_workers].thread.submit(run, workers[i % n_workers], i) for i in range(len(prepared))]
         return [f.result() for f in futures]
 
     def label(self, fs, d_ref, d_X, gidx, labels, probs, entropy=None, t=None, t0=None, tick=None):

@@ -322,11 +322,12 @@ def _entry_set(tab, t, i, field, value):
         getattr(tab, field)[t.source[i]] = value
 
 
-def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle):
+def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=None, static_box_of=None):
     """The track branch of fit_bounding_boxes_simple for every valid track, in track order: boxes and `static_track` flags of
     the entries (into `tab` for real detections, into the track for its clones) and `track.static`.
     points_of(key) -> cluster points [n,>=3]; static_of(key) -> Detection.static (the entropy flag); to_ego_of(fnr) -> 4x4;
-    rectangle(xy) -> (corners, rz, area)."""
+    rectangle(xy) -> (corners, rz, area), or static_box_of(key) -> the finished static box (the GPU kernel's, vg_cluster_boxes)."""
+    sbox = (lambda k, p: np.array(static_box_of(k), dtype=np.float64)) if static_box_of is not None else (lambda k, p: static_box(p, rectangle))
     for t in tracker.tracks_valid:
         n = len(t)
         pts = [points_of(k) for k in t.source]
@@ -335,7 +336,7 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle):
         t.clone_valid = [True] * n
         if all(static_of(k) for k in t.source):
             for i in range(n):
-                _entry_set(tab, t, i, 'box', static_box(pts[i], rectangle))
+                _entry_set(tab, t, i, 'box', sbox(t.source[i], pts[i]))
             continue
         centers = np.array([np.median(p[..., :2], axis=0) for p in pts])
         dirs = motion_vectors(centers)
@@ -348,7 +349,7 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle):
         else:
             for i in range(n):
                 _entry_set(tab, t, i, 'static_track', True)
-                _entry_set(tab, t, i, 'box', static_box(pts[i], rectangle))
+                _entry_set(tab, t, i, 'box', sbox(t.source[i], pts[i]))
 
 
 # ================================================================================================================

@@ -12,8 +12,9 @@ Stage names, keyword arguments, skip-if-already-done rules and the two pickle fa
   fit_bounding_boxes_simple(method, force, valid_only, ...)         :422-462 (static branch)
   evaluate_sequence(modes, classification_key, ...)                 :826-857
   sync_lidar_frames(mode)                                           :105-123
-SURVEY §8f row N1 (entropy scores, two-frame clustering -- the shipped default) is built; the N2 stages
-`track_clusters` and `propagate_labels` are accepted by name and skipped with a warning.
+SURVEY §8f rows N1 (entropy scores, two-frame clustering) and N2 (`track_clusters`, the track branch of
+`fit_bounding_boxes_simple`, `propagate_labels`; host logic in vilgod_amd/tracking.py) are built: the shipped default
+`pipeline_active` runs end to end.
 
 Execution differs on purpose: per-frame device data (points, ref-frame points, non-ground subset, cluster lists)
 stays resident in HBM across stages (a 199-frame Waymo segment is ~0.6 GB), every stage calls the HIP kernels
@@ -56,6 +57,9 @@ class ZeroShotDetector:
         self._scores = {}                                # fnr -> [n_crops, K] class probabilities
         self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
         self.n_workers = int(dev.get('frames_in_flight', 3))
+        self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
+        self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
+        self._host_X = {}                                # fnr -> points_ref_wo_ground on the host (tracking stages are host logic)
         self.init_lidar_frames()
         try:
             self.sync_lidar_frames(mode='load')
@@ -115,11 +119,8 @@ class ZeroShotDetector:
             for f in frames:
                 body(self.pipe, f)
             return
-        from concurrent.futures import ThreadPoolExecutor
         p = self.pipe
-        if p._workers is None or len(p._workers) < nw:
-            p._workers = [p._clone_for_worker() for _ in range(nw)]
-            p._pool = ThreadPoolExecutor(max_workers=nw)
+        workers = p._ensure_workers(nw)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(p.device))
 
@@ -129,8 +130,26 @@ class ZeroShotDetector:
                 body(worker, f)
                 worker.stream.synchronize()
 
-        for fut in [p._pool.submit(run, p._workers[i % nw], f) for i, f in enumerate(frames)]:
+        # frame i -> worker i % nw, on that worker's own thread: its handles are never used by two threads at once
+        for fut in [workers[i % nw].thread.submit(run, workers[i % nw], f) for i, f in enumerate(frames)]:
             fut.result()
+
+    def _exchange_states(self):
+        """Every rank receives the serialised states of the frames it does not own (small pickled objects)."""
+        if self.world_size == 1:
+            return
+        states = {}
+        for part in vdist.gather_objects({f: self.lidar_frame_list[f].serialize for f in self.my_frames}):
+            states.update(part)
+        for f, data in states.items():
+            if f not in self.my_frames:
+                self.lidar_frame_list[f].clear_detections()
+                self.lidar_frame_list[f].sync(data)
+
+    def _points_host(self, fnr):
+        if fnr not in self._host_X:
+            self._host_X[fnr] = self._ref_and_nonground(fnr)[1].cpu().numpy()
+        return self._host_X[fnr]
 
     def sync_lidar_frames(self, mode='save'):
         path = self.sequence_data_dir_path / f'{self.name}{self.cfg.postfix.sequence_data}'
@@ -333,6 +352,13 @@ class ZeroShotDetector:
             raise NotImplementedError(f'{mname}: only minimum_bounding_rectangle (the configured method) has a kernel')
         valid_only, fg_only = kwargs.get('valid_only', False), kwargs.get('fg_only', False)
         ckey = kwargs.get('classification_key', None)
+        if self.tracker is not None and len(self.tracker.tracks_valid) > 0:
+            # tracks available: static and moving objects are handled differently (zero_shot_detector.py:462-684)
+            for fs in self.lidar_frame_list:
+                fs.boxes = None
+            self._fit_boxes_tracked(valid_only)
+            self.sync_lidar_frames()
+            return
         for fnr in self.my_frames:
             fs = self.lidar_frame_list[fnr]
             if fs.n_detections == 0 or (fs.boxes is not None and not kwargs.get('force', False)):
@@ -357,7 +383,7 @@ class ZeroShotDetector:
         if 'detection_3d' in modes:
             for fnr in self.my_frames:
                 fs = self.lidar_frame_list[fnr]
-                boxes, names, scores = [], [], []
+                boxes, names, scores, moving = [], [], [], []
                 if key in fs.cls and fs.boxes is not None:
                     e = fs.cls[key]
                     for c in range(fs.n_detections):
@@ -365,9 +391,10 @@ class ZeroShotDetector:
                             boxes.append(fs.boxes[c])
                             names.append(str(e['name'][c]))
                             scores.append(e['final'][c])
+                            moving.append(fs.static_track[c] == 0)          # static_track is not None and not static_track (:843)
                 local[fnr] = {'boxes_lidar': self.pipe.boxes_to_ego(np.array(boxes).reshape(-1, 7), fs.transform_to_ego),
                               'name': np.array(names), 'score': np.array(scores),
-                              'moving': np.zeros(len(names), dtype=bool)}
+                              'moving': np.array(moving, dtype=bool)}
         if self.world_size > 1:
             # the one data-path collective: class scores of every crop; results/states are small objects
             self._scores = vdist.gather_scores(self._scores, n_classes=len(self.pipe.class_list), device=self.pipe.device)
@@ -375,22 +402,110 @@ class ZeroShotDetector:
             for part in vdist.gather_objects(local):
                 merged.update(part)
             local = merged
-            states = {}
-            for part in vdist.gather_objects({f: self.lidar_frame_list[f].serialize for f in self.my_frames}):
-                states.update(part)
-            for f, data in states.items():
-                if f not in self.my_frames:
-                    self.lidar_frame_list[f].clear_detections()
-                    self.lidar_frame_list[f].sync(data)
+            self._exchange_states()
             if self.rank == 0:
                 path = self.sequence_data_dir_path / f'{self.name}{self.cfg.postfix.sequence_data}'
                 with open(path, 'wb') as fp:
                     pickle.dump([f.serialize for f in self.lidar_frame_list], fp)
         self.detection_3d_result_list = [local[f] for f in sorted(local)]
 
-    # ---- SURVEY §8f "next" row N2: accepted, not built ----------------------------------------------------------
+    # ---- tracking, motion-aware boxes, label propagation (host logic, vilgod_amd/tracking.py) -------------
     def track_clusters(self, **kwargs):
-        self.logger.warning('track_clusters (SURVEY §8f N2) is not built yet -- skipped')
+        """zero_shot_detector.py:298-327.  The tracker is sequential over the whole sequence and lives in memory only (upstream
+        never writes `tid`); with several ranks every rank first receives all frame states and runs the same deterministic
+        tracker, so the later stages can stay sharded."""
+        from .tracking import Tracker
+        valid_only = kwargs.get('valid_only', False)
+        self._exchange_states()
+        tcfg = self.cfg.preprocessor.tracking.cluster
+        assign = tcfg['assignment'] if isinstance(tcfg, dict) else tcfg.assignment
+        if (assign['method'] if isinstance(assign, dict) else assign.method) != 'assign_detections_greedy':
+            raise NotImplementedError('tracking.cluster.assignment.method: only assign_detections_greedy (the shipped configuration)')
+        g = (lambda k, d=None: tcfg.get(k, d)) if hasattr(tcfg, 'get') else (lambda k, d=None: getattr(tcfg, k, d))
+        self.tracker = Tracker(mode=g('mode', 'cluster_center'), max_distance=(assign['max_distance'] if isinstance(assign, dict) else assign.max_distance),
+                               min_length=g('min_length', 5), max_missed=g('max_missed', 3))
+        self._tab = None
+        med, cnt = {}, {}
+        for fs in self.lidar_frame_list:
+            rows = np.flatnonzero(fs.valid) if valid_only else np.arange(fs.n_detections)
+            keys = [(fs.fnr, int(r)) for r in rows]
+            if keys:
+                X = self._points_host(fs.fnr)
+                for k in keys:
+                    p = X[fs.cluster_index(k[1])]
+                    med[k], cnt[k] = np.median(p, axis=0), len(p)                  # Detection.cluster_mass_center (objects.py:121-123)
+            centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
+            self.tracker.next(fs.fnr, keys, centers, [cnt[k] for k in keys], lambda k: (med[k], cnt[k]))
+        self.tracker.finish()
+        self.logger.info(f'  tracks: {len(self.tracker.tracks)} ({sum(len(t) >= self.tracker.min_length for t in self.tracker.tracks)} of length >= {self.tracker.min_length})')
+
+    def _cluster_points_host(self, key):
+        fnr, row = key
+        return self._points_host(fnr)[self.lidar_frame_list[fnr].cluster_index(row)]
+
+    def _fit_boxes_tracked(self, valid_only):
+        """The track branch of fit_bounding_boxes_simple (zero_shot_detector.py:463-684): the per-detection rectangle boxes come
+        from the GPU kernel (one launch per frame over all tracked clusters), the motion logic is host code."""
+        from .tracking import DetectionTable, fit_track_boxes
+        tracked = {}
+        for t in self.tracker.tracks_valid:
+            for fnr, row in t.source:
+                tracked.setdefault(fnr, set()).add(row)
+        gpu_box = {}
+        for fnr, rows in tracked.items():
+            rows = sorted(rows)
+            _, X = self._ref_and_nonground(fnr)
+            d_index, d_seg = self._cluster_lists(fnr, rows)
+            box, _ = self.pipe.boxes(X, d_index, d_seg)
+            for r, b in zip(rows, box.cpu().numpy()):
+                gpu_box[(fnr, r)] = b
+        tab = DetectionTable()
+        for fs in self.lidar_frame_list:
+            for r in range(fs.n_detections):
+                tab.valid[(fs.fnr, r)] = bool(fs.valid[r])
+        fit_track_boxes(self.tracker, tab, self._cluster_points_host, lambda k: bool(self.lidar_frame_list[k[0]].static[k[1]]),
+                        lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__)
+        self._tab = tab
+        self._write_back_tracked()
+
+    def _write_back_tracked(self, key=None):
+        tab = self._tab
+        for fs in self.lidar_frame_list:
+            if fs.n_detections == 0:
+                continue
+            if fs.boxes is None:
+                fs.boxes = np.full((fs.n_detections, 7), np.nan)
+            for r in range(fs.n_detections):
+                k = (fs.fnr, r)
+                if k in tab.box:
+                    fs.boxes[r] = tab.box[k]
+                st = tab.static_track.get(k)
+                if st is not None:
+                    fs.static_track[r] = int(bool(st))
+                fs.valid[r] = tab.valid.get(k, bool(fs.valid[r]))
+                if key is not None and key in fs.cls and k in tab.name and fs.cls[key]['has'][r]:
+                    fs.cls[key]['name'][r], fs.cls[key]['final'][r] = tab.name[k], tab.score[k]
 
     def propagate_labels(self, **kwargs):
-        self.logger.warning('propagate_labels (SURVEY §8f N2) is not built yet -- skipped')
+        """zero_shot_detector.py:686-824."""
+        from .tracking import propagate_labels
+        if self.tracker is None or self._tab is None:
+            self.logger.warning('propagate_labels needs track_clusters and fit_bounding_boxes_simple in the same run -- skipped')
+            return
+        key = kwargs.get('classification_key', 'clip')
+        self._exchange_states()                         # the class results of the other ranks' frames
+        tab = self._tab
+        for fs in self.lidar_frame_list:
+            if key in fs.cls:
+                e = fs.cls[key]
+                for r in np.flatnonzero(e['has']):
+                    tab.name[(fs.fnr, int(r))], tab.score[(fs.fnr, int(r))] = str(e['name'][r]), e['final'][r]
+        for t in self.tracker.tracks_valid:              # upstream would raise on a tracked detection without a class
+            for i, k in enumerate(t.source):
+                if not t.prediction[i] and k not in tab.name:
+                    raise RuntimeError(f'propagate_labels: detection {k} is tracked but was not classified (run classification with '
+                                       'the same valid_only setting as track_clusters)')
+        propagate_labels(self.tracker, tab, lambda k: len(self.lidar_frame_list[k[0]].cluster_index(k[1])), self.dataset.class_names,
+                         min_length=kwargs.get('min_length', 5))
+        self._write_back_tracked(key)
+        self.sync_lidar_frames()
