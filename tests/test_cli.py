@@ -145,3 +145,28 @@ def test_bench_two_ranks_on_one_gpu(cuda):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['value'] > 0 and d['unit'] == 'frames/s'
     assert d['value'] == pytest.approx(2 * 3 / (d['ms_per_step'] * 3 / 1000.0), rel=1e-3)       # whole-job frames / max-rank time
     assert 0 < d['roofline']['frac'] < 1 and 'cpu_baseline' not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['waymo', 'argoverse'])
+def test_cli_on_openpcdet_layout(cuda, tmp_path, kind, caplog):
+    """the default 9-stage configuration over a data set in OpenPCDet's on-disk layout (written from the seeded
+    generator), read by the real-data adapters, evaluated with the AP / APH evaluation against the generator's ground truth."""
+    import logging
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import preprocess_data
+    from vilgod_amd import fixture_data as fx
+    root = str(tmp_path / kind)
+    writer = fx.write_waymo if kind == 'waymo' else fx.write_argo2
+    names = writer(root, n_sequences=1, n_frames=6, n_points=20000, n_objects=10, seed=0)
+    with caplog.at_level(logging.INFO):
+        res = preprocess_data.main([f'preprocessor={kind}', f'dataset={kind}_openpcdet', f'dataset.DATA_PATH={root}', 'end_sequence=1',
+                                    'device.max_points=24000', 'paths.clip_model=/nonexistent', 'export_pseudo_labels=True',
+                                    'pipeline.8.args.detection_3d.class_agnostic=True', 'pipeline.8.args.eval_range=[-75.,-75.,75.,75.]'])
+    assert len(res) == 6 and sum(len(fr['name']) for fr in res) > 0
+    out, idx, state = _load(root, seq=names[0])
+    assert sorted(idx) == [0, 1, 2, 3, 4, 5] and len(state) == 6       # Argoverse infos are stored out of time order
+    text = caplog.text
+    assert 'Vehicle AP  L2:' in text and 'Vehicle APH L2:' in text
+    ap = float(text.split('Vehicle AP  L2:')[1].split()[0])
+    assert 0.0 <= ap <= 100.0

@@ -104,9 +104,22 @@ def main(argv=None):
         torch.cuda.empty_cache()
 
     if len(detection_results) > 0 and rank == 0:
+        # tools/preprocess_data.py:112-131 of the reference: one evaluation over all sequences with the evaluate_sequence arguments
+        det3d_args = [pp for pp in cfg.pipeline if pp['name'] == 'evaluate_sequence'][0]['args']
+        det3d_cfg = det3d_args['detection_3d']
         logger.info('_' * 100)
-        summary = dataset.evaluation(detection_results, class_names=dataset.class_names, indices=indices)
-        logger.info(f'Summary over all sequences: {summary}')
+        logger.info('Evaluate all Sequences - Detection 3D')
+        logger.info('_' * 100)
+        ap_dict = dataset.evaluation(detection_results, class_names=dataset.class_names, indices=indices, eval_cfg=cfg.eval_cfg,
+                                     class_agnostic=det3d_cfg['class_agnostic'], eval_range=det3d_args['eval_range'], bev=det3d_cfg['bev'],
+                                     moving=det3d_args['moving'], static=det3d_args['static'], score_thresh=det3d_cfg['score_thresh'],
+                                     sampling_rate=det3d_cfg['sampling_rate'])
+        if isinstance(ap_dict, dict):
+            from vilgod_amd.evaluation import print_eval_log
+            print_eval_log(ap_dict, logger)
+            logger.info(f"Summary over all sequences: { {k: v for k, v in ap_dict.items() if '/' not in k} }")
+        else:
+            logger.info(str(ap_dict))
         logger.info('_' * 100)
     return detection_results
 

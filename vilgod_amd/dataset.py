@@ -30,6 +30,10 @@ class SyntheticDataset:
         # the two-frame clustering need; False: independent frames (`synthetic.make_frame`)
         self.coherent = bool(_get(syn, 'coherent', True))
         self._frames = None
+        self.dataset_cfg = dataset_cfg
+        self.point_cloud_range = np.array(_get(dataset_cfg, 'POINT_CLOUD_RANGE', [-75.2, -75.2, -2, 75.2, 75.2, 4]), dtype=np.float32)
+        self.infos = {}                      # global frame index -> info (filled as sequences are generated; `evaluation` reads it)
+        self.index_mapping = []
         self.start_sequence, self.end_sequence = int(start_sequence), int(end_sequence)
         self.sequence_name = None
         self.sequence_infos = []
@@ -60,19 +64,42 @@ class SyntheticDataset:
         if not self.coherent:
             return synthetic.make_frame(self.seed + self._seq_id * 100_003 + fnr, self.points_per_frame,
                                         n_objects=self.objects_per_frame)
-        if self._frames is None:
-            self._frames, _ = synthetic.make_sequence(self.seed + self._seq_id, self.frames_per_sequence, self.points_per_frame,
-                                                      n_objects=self.objects_per_frame, step=self.step)
+        self._generate()
         return self._frames[fnr]
 
-    def get_annos(self, fnr):
-        return {'gt_names': np.array([]), 'moving': np.array([], dtype=bool), 'gt_boxes_lidar': np.zeros((0, 7))}
+    def _generate(self):
+        """The coherent sequence and its ground truth (the generator's boxes in the OpenPCDet `annos` layout), once per sequence."""
+        if self._frames is not None:
+            return
+        from .fixture_data import WAYMO_NAME
+        self._frames, _, truth = synthetic.make_sequence(self.seed + self._seq_id, self.frames_per_sequence, self.points_per_frame,
+                                                         n_objects=self.objects_per_frame, step=self.step, return_objects=True)
+        for info, idx, t in zip(self.sequence_infos, self.sequence_indices, truth):
+            n = len(t['kind'])
+            info['annos'] = {'name': np.array([WAYMO_NAME.get(k, 'unknown') for k in t['kind']]), 'gt_boxes_lidar': t['box'].astype(np.float32),
+                             'num_points_in_gt': t['n_points'].astype(np.int64), 'obj_ids': np.array([f'obj_{i:04d}' for i in t['id']]),
+                             'difficulty': np.zeros(n, np.int32), 'moving': t['moving'].copy()}
+            self.infos[idx] = info
+
+    def get_annos(self, fnr, transformation=None, filtered=True):
+        """Ground truth of the classes of interest (waymo_dataset.py:88-153 without the real-data filters)."""
+        if not self.coherent:
+            return {'gt_names': np.array([]), 'moving': np.array([], dtype=bool), 'gt_boxes': np.zeros((0, 7), np.float32)}
+        self._generate()
+        a = self.sequence_infos[fnr]['annos']
+        keep = np.isin(a['name'], self.class_names) if filtered else np.ones(len(a['name']), bool)
+        return {'gt_names': a['name'][keep], 'gt_boxes': a['gt_boxes_lidar'][keep], 'num_points_in_gt': a['num_points_in_gt'][keep],
+                'obj_ids': a['obj_ids'][keep], 'moving': a['moving'][keep]}
 
     def evaluation(self, det_annos, class_names, **kwargs):
-        """No ground truth for synthetic frames: report label statistics instead of AP (the TF Waymo metrics of
-        src/datasets/waymo_eval.py are out of scope)."""
+        """Coherent sequences carry the generator's ground truth: the same AP / APH evaluation as the real-data adapters
+        (vilgod_amd/evaluation.py).  Independent frames have none: label statistics only."""
         names = np.concatenate([d['name'] for d in det_annos]) if det_annos else np.array([])
         out = {'n_frames': len(det_annos), 'n_labels': int(len(names))}
         for c in class_names:
             out[f'n_{c}'] = int((names == c).sum())
+        indices = list(kwargs.get('indices', []))
+        if self.coherent and len(indices) == len(det_annos) and all(i in self.infos for i in indices):
+            from . import evaluation as ev
+            out.update(ev.evaluate_detections(self, det_annos, class_names, **dict(kwargs, style='waymo')))
         return out

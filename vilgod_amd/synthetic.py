@@ -141,12 +141,13 @@ def make_poses(n_frames, step=0.5, seed=0):
 
 
 def make_sequence(seed=0, n_frames=6, n_points=20_000, n_objects=12, moving_frac=0.35, ground_frac=0.45,
-                  clutter_frac=0.03, step=0.5):
+                  clutter_frac=0.03, step=0.5, return_objects=False):
     """A sequence over ONE world: static objects stay put, a fraction moves along its heading (0.3-1.2 m per frame),
     the ego vehicle follows `make_poses`.  Every frame re-samples the surfaces (a LiDAR never hits the same spot
     twice), so static structure keeps a similar neighbour count from frame to frame (entropy score near 1) and
     moving objects do not (low score) -- the signal `calculate_entropy_scores` measures.
-    -> (list of (n_points,5) float32 frames in the VEHICLE frame, list of 4x4 poses)."""
+    -> (list of (n_points,5) float32 frames in the VEHICLE frame, list of 4x4 poses); with `return_objects` also, per frame,
+    the objects' ground truth in the vehicle frame: dict(kind [n] str, box [n,7] = x,y,z,dx,dy,dz,heading, n_points [n], id [n], moving [n])."""
     rng = np.random.default_rng(seed + 7919)
     poses = make_poses(n_frames, step=step, seed=seed)
     freq = np.array([t[2] for t in OBJECT_TYPES])
@@ -163,7 +164,7 @@ def make_sequence(seed=0, n_frames=6, n_points=20_000, n_objects=12, moving_frac
     n_obj_pts = n_points - n_ground - n_clutter
     clutter_w = np.stack([rng.uniform(-60, 60, n_clutter), rng.uniform(-60, 60, n_clutter), rng.uniform(0.3, 4, n_clutter)], 1)
     rings = np.geomspace(2.5, 75.0, 64)
-    frames = []
+    frames, truth = [], []
     for f in range(n_frames):
         T = poses[f]
         Ti = np.linalg.inv(T)
@@ -190,4 +191,10 @@ def make_sequence(seed=0, n_frames=6, n_points=20_000, n_objects=12, moving_frac
         pts[:, :3] = xyz
         pts[:, 3] = rng.uniform(0, 1, size=len(xyz))
         frames.append(pts)
+        if return_objects:
+            dims = np.array([OBJECT_TYPES[k][1] for k in kinds], dtype=np.float64)
+            truth.append(dict(kind=np.array([OBJECT_TYPES[k][0] for k in kinds]), n_points=cnt.copy(), id=np.arange(n_objects), moving=moving.copy(),
+                              box=np.c_[ce, dims[:, 2] / 2 + 0.02, dims, yaw - ego_yaw]))
+    if return_objects:
+        return frames, poses, truth
     return frames, poses
