@@ -1156,8 +1156,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntm = M / BM;
     const int grp = wave >> 2, wn = wave & 3;
-    long long tr_entry = 0, tr_load = 0, tr_bar = 0, tr_mma = 0, tr_wait = 0, tr_t0 = 0, tr_w0 = 0, tr_main = 0;
-    if (TRACE) tr_entry = clock64();
+    long long tr_entry = 0, tr_load = 0, tr_bar = 0, tr_mma = 0, tr_wait = 0, tr_t0 = 0, tr_w0 = 0, tr_main = 0, tr_w_entry = 0;
+    if (TRACE) { tr_entry = clock64(); tr_w_entry = wall_clock64(); }
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int per_chunk = ntm * cw;
     const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
@@ -1339,6 +1339,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
         const long long t2 = clock64();
         o[0] = tr_main; o[1] = tr_wait; o[2] = tr_bar; o[3] = (t2 - tr_entry) - tr_main; o[4] = tr_load; o[5] = tr_mma; o[6] = wave;
         o[7] = wall_clock64() - tr_w0;
+        if (wave == 0) {                       // second record (slots of wave 1..): where the tile's non-MFMA time goes and on which CU
+            long long* e = trace + (size_t)gridDim.x * 64 + (size_t)blockIdx.x * 8;
+            e[0] = tr_w_entry; e[1] = wall_clock64();
+            e[2] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+            e[3] = tr_t0 - tr_entry; e[4] = t2 - tr_t0 - tr_main; e[5] = 1;
+        }
     }
 }
 
@@ -1661,6 +1667,8 @@ int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bia
         case 22: return launch_gemm_pp<EPI_BIAS, 4, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 23: return launch_gemm_pp<EPI_BIAS, 5, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 32: return launch_gemm_pp64<EPI_BIAS, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        case 33: return launch_gemm_pp64<EPI_BIAS_GELU, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
+        case 34: return launch_gemm_pp64<EPI_BIAS_RESID, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
         default: return VG_ERR_ARG; }
     VG_LAUNCH_CHECK();
     return VG_OK;
