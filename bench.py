@@ -72,8 +72,8 @@ def cpu_baseline(n_points=20_000, n_objects=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=12)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=48)
+    ap.add_argument('--warmup', type=int, default=12)
     ap.add_argument('--points', type=int, default=150_000)
     ap.add_argument('--objects', type=int, default=60)
     ap.add_argument('--views', type=int, default=4)
@@ -82,7 +82,7 @@ def main():
     ap.add_argument('--stage-times', action='store_true', help='print per-stage ms (adds synchronisation; not for the metric)')
     ap.add_argument('--no-roofline-pass', action='store_true', help='skip the sequential GEMM-timing pass (profiling runs)')
     ap.add_argument('--no-sequence-pass', action='store_true', help='skip the extra (untimed-for-the-metric) pass in the reference\'s default stage order')
-    ap.add_argument('--inflight', type=int, default=3, help='frames in flight per GPU (worker streams); 1 = strictly sequential')
+    ap.add_argument('--inflight', type=int, default=6, help='frames in flight per GPU (worker streams); 1 = strictly sequential')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -104,7 +104,7 @@ def main():
                                clip_model_path='/nonexistent')
     # a short synthetic sequence per rank: frames differ, poses follow a smooth trajectory; resident in HBM
     n_distinct = 4
-    poses = synthetic.make_poses(args.steps + args.warmup + 1, seed=rank)
+    poses = synthetic.make_poses(args.steps + max(args.warmup, args.inflight) + 8, seed=rank)   # warm-up covers the worker handles
     frames = [pipe.upload(synthetic.make_frame(1 + rank * 100 + i, args.points, n_objects=args.objects)) for i in range(n_distinct)]
     torch.cuda.synchronize()
 
@@ -222,7 +222,7 @@ def main():
             if world == 1 and not args.no_sequence_pass and not args.stage_times:
                 # additional information, not the metric: the reference's DEFAULT stage order (preprocessing.yaml:50-68 -- entropy
                 # scores over a 15-frame window + two-frame 5-D clustering) on one coherent synthetic sequence
-                n_seq = max(16, args.steps)
+                n_seq = max(48, args.steps)
                 sframes, sposes = synthetic.make_sequence(seed=0, n_frames=n_seq, n_points=args.points, n_objects=args.objects)
                 sframes = [pipe.upload(f) for f in sframes]
                 pipe.process_sequence(sframes[:4], sposes[:4], sposes[0], n_workers=inflight)

@@ -56,7 +56,7 @@ class ZeroShotDetector:
         self._dev = {}                                   # fnr -> dict of device tensors kept across stages
         self._scores = {}                                # fnr -> [n_crops, K] class probabilities
         self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
-        self.n_workers = int(dev.get('frames_in_flight', 3))
+        self.n_workers = int(dev.get('frames_in_flight', 6))
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
         self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
         self._host_X = {}                                # fnr -> points_ref_wo_ground on the host (tracking stages are host logic)
