@@ -92,7 +92,10 @@ int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h
  * (model.py:175-191: in_proj, out_proj + residual, c_fc + QuickGELU, c_proj + residual), exposed so the
  * GEMM can be unit-tested and timed alone.  dtype 1: f16 operands (M%256, N%128, K%64 == 0); 0: f32
  * (M%64, N%64, K%16).  epi 0: +bias -> C   1: +bias, QuickGELU -> C   2: d_resid(f32) += X@Wt^T + bias
- * 3: C float32, no bias (patch embedding, model.py:224). */
+ * 3: C float32, no bias (patch embedding, model.py:224).
+ * 4 (dtype 1, N%256 == 0, K%64 == 0): d_resid points to an fp16 [M,N] residual stream updated in place,
+ *   resid = f16(resid + f16(X@Wt^T + bias)) -- what the reference's fp16 run computes; the f16 tower takes it only with the
+ *   environment variable VG_VIT_RESID16=1 (width%256 == 0); the default keeps the fp32 stream of epi 2. */
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream);
 

@@ -36,7 +36,8 @@ def test_gemm_epilogues(cuda, dtype, epi, shape):
     Xd, Wd = X.to(td).to(cuda), W.to(td).to(cuda)
     C = torch.zeros(M, N, dtype=torch.float32 if epi == 3 else td, device=cuda)
     R = resid.clone().to(cuda)
-    check(lib.vg_gemm(dtype, epi, ptr(Xd), ptr(Wd), ptr(bias.to(cuda)), ptr(C), ptr(R), M, N, K, stream_ptr()))
+    bd = bias.to(cuda)                       # device operands stay referenced until the result has been read back
+    check(lib.vg_gemm(dtype, epi, ptr(Xd), ptr(Wd), ptr(bd), ptr(C), ptr(R), M, N, K, stream_ptr()))
     got = (R if epi == 2 else C).float().cpu()
     want = _ref(Xd.cpu(), Wd.cpu(), bias, resid, epi)
     tol = 3e-3 if dtype == 1 else 2e-4
@@ -49,3 +50,31 @@ def test_gemm_rejects_bad_shapes(cuda):
     from vilgod_amd._lib import lib, ptr, stream_ptr
     x = torch.zeros(100, 64, dtype=torch.float16, device=cuda)
     assert lib.vg_gemm(1, 0, ptr(x), ptr(x), ptr(x), ptr(x), None, 100, 128, 64, stream_ptr()) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(512, 768, 768), (256, 768, 3072), (768, 256, 128), (256, 1024, 1024)])
+def test_gemm_fp16_residual_epilogue(cuda, shape):
+    """epi 4 (fp16 residual stream, in place): resid = f16(resid + f16(X W^T + bias)) -- the arithmetic of the reference's own
+    fp16 run (a half Linear output added to a half tensor).  Checked against that formula evaluated from an fp32 product: the two
+    roundings are reproduced; the fp32-accumulated product may land one fp16 step away where it sits on a rounding boundary."""
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    X = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = torch.randn(N, K, generator=g) * 0.05
+    W[:, 0] += torch.arange(N) * 1e-3
+    W = W.half()
+    bias = torch.randn(N, generator=g) * 0.1
+    resid = (torch.randn(M, N, generator=g) * 2).half()
+    R = resid.clone().to(cuda)
+    Xd, Wd, bd = X.to(cuda), W.to(cuda), bias.to(cuda)      # stay referenced until the result has been read back
+    check(lib.vg_gemm(1, 4, ptr(Xd), ptr(Wd), ptr(bd), None, ptr(R), M, N, K, stream_ptr()))
+    proj = (X.float() @ W.float().t() + bias).half()
+    want = (resid.float() + proj.float()).half().float()
+    got = R.float().cpu()
+    ulp = torch.maximum(want.abs(), proj.float().abs()) * 2.0 ** -10 + 1e-4
+    # a projection that lands one fp16 step away (accumulation order) moves the sum by that step plus one rounding of the sum
+    assert ((got - want).abs() <= 2.5 * ulp).all(), ((got - want).abs() / ulp).max().item()
+    assert (got == want).float().mean().item() > 0.9, (got == want).float().mean().item()
+    assert lib.vg_gemm(1, 4, ptr(Xd), ptr(Wd), ptr(bd), None, ptr(R), M, 128, K, stream_ptr()) == 1     # N % 256

@@ -101,11 +101,14 @@ def test_hip_vit_small_f16(cuda, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', ['f32', 'f16'])
-def test_hip_vit_b16_scores(cuda, dtype):
+@pytest.mark.parametrize('dtype', ['f32', 'f16', 'f16-resid16'])
+def test_hip_vit_b16_scores(cuda, dtype, monkeypatch):
     """Full ViT-B/16, seeded synthetic weights, 10 crops (one more than a multiple of anything) ->
-    probabilities over 24 prompts."""
+    probabilities over 24 prompts.  'f16-resid16' = the opt-in fp16 residual stream (VG_VIT_RESID16=1, read at handle creation)."""
     from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
+    if dtype == 'f16-resid16':
+        monkeypatch.setenv('VG_VIT_RESID16', '1')
+        dtype = 'f16'
     wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
     text = cw.synthetic_text_features(0, 24, 512)
     x = torch.randn(10, 3, 224, 224, generator=torch.Generator().manual_seed(1))

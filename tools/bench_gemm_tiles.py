@@ -1,4 +1,4 @@
-"""Where a 256 x 256 tile's time goes in k_gemm_f16_pp64 (trace variants 32 = +bias f16, 33 = +bias GELU f16, 34 = residual f32):
+"""Where a 256 x 256 tile's time goes in k_gemm_f16_pp64 (trace variants 32 = +bias f16, 33 = +bias GELU f16, 34 = residual f32, 35 = residual f16):
 prologue (entry -> first MMA), main loop, epilogue, and the dead time on a CU between one workgroup's exit and the next one's entry
 (s_memrealtime stamps, 10 ns units, grouped by XCC / SE / CU id)."""
 import os, sys, torch
@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vilgod_amd._lib import lib, ptr, stream_ptr, check
 dev = torch.device('cuda:0')
 M = (int(os.environ.get('CROPS', '325')) * 197 + 255) // 256 * 256
-for var, N, K in [(32, 2304, 768), (33, 3072, 768), (34, 768, 768), (34, 768, 3072)]:
+for var, N, K in [(32, 2304, 768), (33, 3072, 768), (34, 768, 768), (34, 768, 3072), (35, 768, 768), (35, 768, 3072)]:
     X = (torch.randn(M, K, device=dev) * 0.5).half(); W = (torch.randn(N, K, device=dev) * 0.05).half()
     b = torch.randn(N, device=dev)
     C = torch.zeros(M, N, dtype=torch.float32 if var == 34 else torch.float16, device=dev)

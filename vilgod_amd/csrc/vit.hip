@@ -34,7 +34,8 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_NONE_F32 = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_NONE_F32 = 3,
+       EPI_BIAS_RESID_H = 4 };   // 4: fp16 residual stream (k_gemm_f16_pp64 only): resid_h = f16(resid_h + f16(acc + bias))
 
 // ---------------------------------------------------------------------------------------------
 // XCD-aware tile order: consecutive hardware block ids are dealt round-robin to the 8 XCDs; give each
@@ -559,9 +560,10 @@ __global__ void k_im2col(const TI* __restrict__ crops, TO* __restrict__ P, int n
 
 // x[crop][t] = (t == 0 ? class_embedding : patch_out[crop][t-1]) + positional_embedding[t]; x = ln_pre(x)
 // one wave per token row.  (model.py:227-229)
+template <typename TO>
 __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                      const float* __restrict__ pos, const float* __restrict__ lw,
-                                                     const float* __restrict__ lb, float* __restrict__ x, int n_rows,
+                                                     const float* __restrict__ lb, TO* __restrict__ x, int n_rows,
                                                      int T, int W) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n_rows) return;
@@ -584,19 +586,19 @@ __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ p
     float rstd = rsqrtf(vg_wave_sum(q) / (float)W + 1e-5f);
     for (int i = 0; i < per; ++i) {
         int c = lane + 64 * i;
-        x[(size_t)row * W + c] = (v[i] - mean) * rstd * lw[c] + lb[c];
+        x[(size_t)row * W + c] = (TO)((v[i] - mean) * rstd * lw[c] + lb[c]);
     }
 }
 
 // LayerNorm (fp32 statistics, model.py:157-163): x f32 [rows,W] -> h (f16 or f32). one wave per row.
 // W % 256 == 0 takes the vectorised path: float4 loads (1 KB per wave instruction), packed stores.
-template <typename TO>
-__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ lw,
+template <typename TO, typename TI = float>
+__global__ __launch_bounds__(256) void k_layernorm(const TI* __restrict__ x, const float* __restrict__ lw,
                                                    const float* __restrict__ lb, TO* __restrict__ h, int n_rows, int W,
                                                    int row_stride_in /*in rows of W*/) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n_rows) return;
-    const float* src = x + (size_t)row * row_stride_in * W;
+    const TI* src = x + (size_t)row * row_stride_in * W;
     if ((W & 255) == 0 && W <= 1024) {
         const int nv = W >> 8;                       // float4 per lane
         float4 v[4];
@@ -604,7 +606,12 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < nv) {
-                v[i] = *(const float4*)(src + (i * 64 + lane) * 4);
+                if (sizeof(TI) == 2) {
+                    const f16x4 t4 = *(const f16x4*)(src + (i * 64 + lane) * 4);
+                    v[i] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
+                } else {
+                    v[i] = *(const float4*)(src + (i * 64 + lane) * 4);
+                }
                 s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
         const float mean = vg_wave_sum(s) / (float)W;
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     const int per = W / 64;
     float s = 0.f;
     for (int i = 0; i < per; ++i) {
-        v[i] = src[lane + 64 * i];
+        v[i] = (float)src[lane + 64 * i];
         s += v[i];
     }
     float mean = vg_wave_sum(s) / (float)W;
@@ -863,15 +870,16 @@ __global__ __launch_bounds__(256) void k_attention_f32(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // head: ln_post(x[crop, 0, :]) @ proj  (model.py:235-238).  one workgroup per crop.
-__global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, const float* __restrict__ lw,
+template <typename TI>
+__global__ __launch_bounds__(256) void k_head(const TI* __restrict__ x, const float* __restrict__ lw,
                                               const float* __restrict__ lb, const float* __restrict__ proj,
                                               float* __restrict__ feat, int T, int W, int D) {
     extern __shared__ float sm[];   // [W]
     __shared__ float red[8];
     const int crop = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* src = x + (size_t)crop * T * W;
+    const TI* src = x + (size_t)crop * T * W;
     float s = 0.f;
-    for (int c = tid; c < W; c += 256) s += src[c];
+    for (int c = tid; c < W; c += 256) s += (float)src[c];
     s = vg_wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -879,14 +887,14 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, const
     __syncthreads();
     float q = 0.f;
     for (int c = tid; c < W; c += 256) {
-        float d = src[c] - mean;
+        float d = (float)src[c] - mean;
         q += d * d;
     }
     q = vg_wave_sum(q);
     if (lane == 0) red[wave] = q;
     __syncthreads();
     float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)W + 1e-5f);
-    for (int c = tid; c < W; c += 256) sm[c] = (src[c] - mean) * rstd * lw[c] + lb[c];
+    for (int c = tid; c < W; c += 256) sm[c] = ((float)src[c] - mean) * rstd * lw[c] + lb[c];
     __syncthreads();
     for (int j = tid; j < D; j += 256) {
         float a = 0.f;
@@ -936,6 +944,8 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 #define VG_PROF_MAX 4096
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
+    bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
+                                     // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
     int prof_on = 0, prof_n = 0;
     hipEvent_t prof_ev[2 * VG_PROF_MAX];
@@ -1259,7 +1269,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 #undef PP_BAR
     // ---- epilogue: the same chunk-XOR-swizzled LDS image as k_gemm_f16_pp ----
     __syncthreads();
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID_H) {
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int nloc = wn * 64 + ni * 16 + 4 * q4;
@@ -1281,11 +1291,35 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
         }
         __syncthreads();
         const int j = tid & 31, rr = tid >> 5;
+        if (EPI == EPI_BIAS_RESID_H) {
+            // fp16 residual stream, updated in place: x = f16(x + f16(acc + bias)) -- the arithmetic of upstream's fp16 run
+            // (model.py:190-191 on half tensors).  Eight residual loads go out before the first store.
+            f16* xr = (f16*)resid;
+#pragma unroll
+            for (int p8 = 0; p8 < 2; ++p8) {
+                f16x8 x8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = (p8 * 8 + q) * 16 + rr;
+                    x8[q] = *(const f16x8*)(xr + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = (p8 * 8 + q) * 16 + rr;
+                    const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)x8[q][e] + (float)v[e]);
+                    *(f16x8*)(xr + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = o;
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int m = pass * 16 + rr;
-            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
-            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
+            for (int pass = 0; pass < 16; ++pass) {
+                const int m = pass * 16 + rr;
+                const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
+                *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
+            }
         }
     } else {
 #pragma unroll
@@ -1438,6 +1472,10 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
             }
         }
     } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K, use_pp ? 1 : 0};
+    if constexpr (EPI == EPI_BIAS_RESID_H) {      // fp16 residual stream: only the 256 x 256 kernel implements it
+        if (!(use_pp && K % 64 == 0 && K / 64 >= 2)) return VG_ERR_ARG;
+        return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+    } else
     if (v->dtype == 1) {
         if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
         if (use_pp) {
@@ -1473,6 +1511,7 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     vg_vit* v = new vg_vit();
     v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
     v->out_dim = out_dim; v->dtype = dtype; v->T = T;
+    v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4") && !getenv("VG_GEMM_PP16");
     *out = v;
     return VG_OK;
 }
@@ -1574,9 +1613,16 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     }
     int rc = launch_gemm<EPI_NONE_F32>(v, patches, need("conv1.weight"), nullptr, pe, nullptr, (int)Pp, W, (int)Kp, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_embed_lnpre, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
-                       (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
-                       (const float*)need("ln_pre.bias"), x, (int)M, T, W);
+    const bool rh = v->resid_h;
+    f16* xh = (f16*)x;                // the residual stream lives in the same workspace region, as fp16 when `rh`
+    if (rh)
+        hipLaunchKernelGGL((k_embed_lnpre<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
+                           (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
+                           (const float*)need("ln_pre.bias"), xh, (int)M, T, W);
+    else
+        hipLaunchKernelGGL((k_embed_lnpre<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
+                           (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
+                           (const float*)need("ln_pre.bias"), x, (int)M, T, W);
     VG_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
         std::string p = "transformer.resblocks." + std::to_string(l) + ".";
@@ -1591,7 +1637,9 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                 return VG_ERR_ARG;
             }
         }
-        if (v->dtype == 1)
+        if (rh)
+            hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[0], (const float*)wp[1], (f16*)h, (int)M, W, 1);
+        else if (v->dtype == 1)
             hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[0], (const float*)wp[1], (f16*)h, (int)M, W, 1);
         else
             hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[0], (const float*)wp[1], (float*)h, (int)M, W, 1);
@@ -1614,20 +1662,28 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             hipLaunchKernelGGL(k_attention_f32, dim3(n_crops * H), dim3(256), lds, st, (const float*)qkv, (float*)h, T, W, H);
         }
         VG_LAUNCH_CHECK();
-        rc = launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
+        rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
+                : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
         if (rc) return rc;
-        if (v->dtype == 1)
+        if (rh)
+            hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
+        else if (v->dtype == 1)
             hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
         else
             hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (float*)h, (int)M, W, 1);
         VG_LAUNCH_CHECK();
         rc = launch_gemm<EPI_BIAS_GELU>(v, h, wp[8], (const float*)wp[9], mlp, nullptr, (int)Mp, 4 * W, W, st);
         if (rc) return rc;
-        rc = launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
+        rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
+                : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(n_crops), dim3(256), W * sizeof(float), st, x, (const float*)need("ln_post.weight"),
-                       (const float*)need("ln_post.bias"), (const float*)need("proj"), d_feat, T, W, v->out_dim);
+    if (rh)
+        hipLaunchKernelGGL((k_head<f16>), dim3(n_crops), dim3(256), W * sizeof(float), st, (const f16*)xh, (const float*)need("ln_post.weight"),
+                           (const float*)need("ln_post.bias"), (const float*)need("proj"), d_feat, T, W, v->out_dim);
+    else
+        hipLaunchKernelGGL((k_head<float>), dim3(n_crops), dim3(256), W * sizeof(float), st, x, (const float*)need("ln_post.weight"),
+                           (const float*)need("ln_post.bias"), (const float*)need("proj"), d_feat, T, W, v->out_dim);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
@@ -1669,6 +1725,7 @@ int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bia
         case 32: return launch_gemm_pp64<EPI_BIAS, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 33: return launch_gemm_pp64<EPI_BIAS_GELU, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 34: return launch_gemm_pp64<EPI_BIAS_RESID, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
+        case 35: return launch_gemm_pp64<EPI_BIAS_RESID_H, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
         default: return VG_ERR_ARG; }
     VG_LAUNCH_CHECK();
     return VG_OK;
@@ -1676,7 +1733,8 @@ int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bia
 
 /* C = X @ Wt^T (+ epilogue), exposed for unit tests / micro-benchmarks of the GEMM itself.
  * dtype 1: X,Wt f16, M%128==0, N%128==0, K%64==0; dtype 0: f32, M%64, N%64, K%16.
- * epi 0: +bias -> C (compute dtype)   1: +bias, QuickGELU -> C   2: resid(f32) += acc + bias   3: C f32, no bias */
+ * epi 0: +bias -> C (compute dtype)   1: +bias, QuickGELU -> C   2: resid(f32) += acc + bias   3: C f32, no bias
+ * epi 4 (dtype 1, N % 256 == 0, K % 64 == 0): d_resid holds fp16 [M,N]: resid = f16(resid + f16(acc + bias)) */
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream) {
     vg_vit v;
@@ -1687,6 +1745,7 @@ int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* 
         case 1: return launch_gemm<EPI_BIAS_GELU>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
         case 2: return launch_gemm<EPI_BIAS_RESID>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
         case 3: return launch_gemm<EPI_NONE_F32>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st);
+        case 4: return dtype == 1 ? launch_gemm<EPI_BIAS_RESID_H>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st) : VG_ERR_ARG;
     }
     return VG_ERR_ARG;
 }
