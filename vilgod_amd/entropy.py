@@ -49,10 +49,12 @@ class EntropyScorer:
             need.add(f)
         return sorted(need)
 
-    def score_sequence(self, X_list, queries=None):
+    def score_sequence(self, X_list, queries=None, mapper=None):
         """X_list: per frame CUDA float32 [n,>=3] (`points_ref_wo_ground`; entries of frames that are not needed may be
         None).  -> {fnr: float64 CUDA tensor [n] of entropy scores} for the `queries` (default: every frame; then a
-        list).  Every frame's grid is built once and queried by all the frames whose window contains it."""
+        list).  Every frame's grid is built once and queried by all the frames whose window contains it.
+        mapper(items, fn): runs fn(grid_model, item) for the items on several handles / streams at once
+        (PseudoLabelPipeline.map_workers); target frames are independent, every (query, column) row has one writer."""
         L = len(X_list)
         as_list = queries is None
         queries = list(range(L)) if queries is None else sorted(queries)
@@ -64,10 +66,16 @@ class EntropyScorer:
         for f in queries:
             for col, j in enumerate(used[f]):
                 users.setdefault(j, []).append((f, col))
-        for j in sorted(users):
-            self.grid_model.grid(X_list[j])
+        def one_target(model, j):
+            model.grid(X_list[j])
             for f, col in users[j]:
-                self.grid_model.ball_count(X_list[f], self.r2, self.cap, out=counts[f][col])
+                model.ball_count(X_list[f], self.r2, self.cap, out=counts[f][col])
+
+        if mapper is None:
+            for j in sorted(users):
+                one_target(self.grid_model, j)
+        else:
+            mapper(sorted(users), one_target)
         out = {}
         for f in queries:
             frames, seek = wins[f]
@@ -109,12 +117,17 @@ class TwoFrameClusterer:
     def reset(self):
         self._cache = {}
 
-    def precompute_parts(self, X_list, ent_list):
+    def precompute_parts(self, X_list, ent_list, mapper=None):
         """Every frame's clustering rows once, up front (a frame enters the input of two consecutive query frames): the
-        returned dict can be handed to other TwoFrameClusterer instances (worker threads) through `parts=`."""
+        returned dict can be handed to other TwoFrameClusterer instances (worker threads) through `parts=`.
+        mapper: as in EntropyScorer.score_sequence (frames are independent)."""
         L = len(X_list)
         n_used = min(self.n_frames, L)
-        return {(f, n_used): self.frame_part(f, X_list[f], ent_list[f], n_used) for f in range(L)}
+        if mapper is None:
+            return {(f, n_used): self.frame_part(f, X_list[f], ent_list[f], n_used) for f in range(L)}
+        rows = mapper(range(L), lambda model, f: TwoFrameClusterer(model, n_frames=self.n_frames, seed=self.seed)
+                      .frame_part(f, X_list[f], ent_list[f], n_used))
+        return {(f, n_used): r for f, r in enumerate(rows)}
 
     def frame_part(self, f, X, ent, n_used):
         """Rows of frame f that enter the clustering input: [x, y, z, entropy] (CUDA float32 [m,4]).

@@ -116,6 +116,27 @@ class PseudoLabelPipeline:
             self._workers = (self._workers or []) + [self._clone_for_worker() for _ in range(n_workers - len(self._workers or []))]
         return self._workers[:n_workers]
 
+    def map_workers(self, items, fn, n_workers):
+        """fn(worker, item) for every item, item i on worker i % n_workers (its thread, its stream, its handles) after everything
+        queued so far on the caller's stream; returns the results in order once all workers have drained their streams."""
+        items = list(items)
+        n_workers = min(n_workers, len(items))
+        if n_workers <= 1:
+            return [fn(self, it) for it in items]
+        workers = self._ensure_workers(n_workers)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+
+        def run(worker, mine):
+            with torch.cuda.stream(worker.stream):
+                worker.stream.wait_event(ev)
+                out = [fn(worker, it) for it in mine]
+                worker.stream.synchronize()
+            return out
+        futs = [workers[k].thread.submit(run, workers[k], items[k::n_workers]) for k in range(n_workers)]
+        parts = [f.result() for f in futs]
+        return [parts[i % n_workers][i // n_workers] for i in range(len(items))]
+
     def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0):
         """Throughput mode: frames (list of CUDA/numpy point arrays) are processed with `n_workers` frames in flight,
         each on its own HIP stream with its own handles.  Ground segmentation is stateful across frames and runs in
@@ -328,7 +349,8 @@ class PseudoLabelPipeline:
             prepared.append(self.prepare(pts, poses[i], ref_pose, fnr=first_fnr + i))
         X_list = [p[2] for p in prepared]
         scorer = EntropyScorer(self.cluster_model, **(entropy_args or {}))
-        H_list = scorer.score_sequence(X_list)
+        mapper = (lambda items, fn: self.map_workers(items, lambda w, it: fn(w.cluster_model, it), n_workers)) if n_workers > 1 else None
+        H_list = scorer.score_sequence(X_list, mapper=mapper)
         ent_list = []
         for (fs, _, d_X, _), H in zip(prepared, H_list):
             fs.entropy_scores, fs.entropy_indices = scorer.reduce(H)
@@ -345,7 +367,7 @@ class PseudoLabelPipeline:
         # several frames in flight: ground / entropy / the per-frame clustering rows are sequence-level work on the caller's
         # stream; clustering + label transfer + filters + classification + boxes of a frame run on a worker stream
         workers = self._ensure_workers(n_workers)
-        parts = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed).precompute_parts(X_list, ent_list) if use_two else None
+        parts = TwoFrameClusterer(self.cluster_model, n_frames=n_frames, seed=seed).precompute_parts(X_list, ent_list, mapper=mapper) if use_two else None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
 

@@ -234,7 +234,9 @@ class ZeroShotDetector:
             X_list[f] = ref if include_ground else X
         if include_ground:
             raise NotImplementedError('include_ground_points: scores would index points_ref, which nothing downstream reads')
-        H = scorer.score_sequence(X_list, queries=queries)
+        mapper = (lambda items, fn: self.pipe.map_workers(items, lambda w, it: fn(w.cluster_model, it), self.n_workers)) \
+            if self.n_workers > 1 else None
+        H = scorer.score_sequence(X_list, queries=queries, mapper=mapper)
         mine = set(self.my_frames)
         for f, h in H.items():
             kept = scorer.reduce(h)
@@ -276,7 +278,9 @@ class ZeroShotDetector:
                     raise RuntimeError('spatial_clustering with n_frames > 1 reads the entropy scores: activate '
                                        'calculate_entropy_scores first (preprocessing.yaml:50)')
             n_used = min(n_frames, self.lenght)
-            parts = {(g, n_used): two.frame_part(g, X_list[g], ent_list[g], n_used) for g in need}      # shared, read-only
+            rows = self.pipe.map_workers(need, lambda w, g: TwoFrameClusterer(w.cluster_model, n_frames=n_frames, seed=two.seed)
+                                         .frame_part(g, X_list[g], ent_list[g], n_used), self.n_workers)
+            parts = {(g, n_used): r for g, r in zip(need, rows)}                                        # shared, read-only
         seed = two.seed if two is not None else 0
 
         def body(p, fnr):
