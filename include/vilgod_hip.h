@@ -105,9 +105,12 @@ int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* 
 int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
                     void* stream);
 
-/* development aid: k_gemm_f16_pp (var 20..23) and k_gemm_f16_pp64 (var 32) with per-wave cycle stamps.  d_trace receives, per (workgroup, wave),
- * eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, epilogue cycles, LOAD-segment
- * cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks. */
+/* development aid: k_gemm_f16_pp (var 20..23) and k_gemm_f16_pp64 (var 32 +bias, 33 +bias QuickGELU, 34 fp32 residual with d_C = the
+ * float [M,N] stream, 35 fp16 residual with d_C = the half [M,N] stream) with per-wave cycle stamps.  d_trace receives, per
+ * (workgroup, wave), eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, prologue + epilogue
+ * cycles, LOAD-segment cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks.  Variants 32..35 append, after those
+ * 64 * n_workgroups values, eight int64 per workgroup: entry and exit time (100-MHz ticks), XCC id << 32 | HW_ID, prologue
+ * cycles, epilogue cycles, 1 -- size d_trace for 72 * (M/256) * (N/256) values (tools/bench_gemm_tiles.py). */
 int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
                   int K, int ldc, void* stream);
 
