@@ -3,7 +3,7 @@
 # (ViT projection GEMM) on the SAME command the bench uses, sequential mode (1 frame in flight) so that kernel
 # durations are not inflated by other streams.  PMC passes are separate from --stats as the guide prescribes
 # (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: one pass each).
-# usage: tools/collect_profiles.sh <tag>     -> gpurun_out/prof_<tag>/{trace,fetch,write}
+# usage: tools/collect_profiles.sh <tag>     -> gpurun_out/prof_<tag>/{trace,fetch,write,sq}
 set -u
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
@@ -12,4 +12,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $BENCH > $OUT.trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python3 $BENCH > $OUT.fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python3 $BENCH > $OUT.write.log 2>&1
+# MFMA pipe utilisation of the GEMM: busy cycles of the matrix pipe vs the time the GPU was active (SQ and GRBM slots, own pass)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -o bench -- python3 $BENCH > $OUT.sq.log 2>&1
 ls $OUT/*

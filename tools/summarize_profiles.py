@@ -47,6 +47,22 @@ for k in sorted(set(fetch) | set(write)):
                               'avg_ns': float(st['AverageNs']) if st else None}
 out['k_gemm_f16_pp64'] = group(lambda k: 'k_gemm_f16_pp64' in k)                       # the dominant kernel (bench.py roofline)
 out['k_gemm_f16'] = group(lambda k: 'k_gemm_f16' in k and 'k_gemm_f16_pp' not in k)    # fallback kernel (unused by ViT-B/16)
+sq_path = os.path.join(src, 'sq', 'bench_counter_collection.csv')
+if os.path.exists(sq_path):
+    # SQ / GRBM pass: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of every SIMD's matrix pipe (16 per v_mfma_f32_16x16x32_f16),
+    # GRBM_GUI_ACTIVE the active cycles of the 8 XCDs; MFMA utilisation = busy / (GUI_ACTIVE / 8 * 1024 SIMDs)
+    names = ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE')
+    for label, match in (('k_gemm_f16_pp64', lambda k: 'k_gemm_f16_pp64' in k), ('k_attention_f16', lambda k: 'k_attention_f16' in k)):
+        tot = {n: per_kernel(sq_path, n) for n in names}
+        agg = {n: sum(v[1] for k, v in tot[n].items() if match(k)) for n in names}
+        launches = sum(v[0] for k, v in tot['GRBM_GUI_ACTIVE'].items() if match(k))
+        if launches and agg['GRBM_GUI_ACTIVE'] > 0:
+            out[label + '_sq'] = {
+                'launches': launches, **{n + '_per_launch': agg[n] / launches for n in names},
+                'mfma_utilisation': agg['SQ_VALU_MFMA_BUSY_CYCLES'] / (agg['GRBM_GUI_ACTIVE'] / 8 * 1024),
+                'wave_cycles_split': {'waiting (s_waitcnt / barrier)': agg['SQ_WAIT_ANY'] / agg['SQ_WAVE_CYCLES'],
+                                      'issue stalled': agg['SQ_WAIT_INST_ANY'] / agg['SQ_WAVE_CYCLES'],
+                                      'issuing': agg['SQ_ACTIVE_INST_ANY'] / agg['SQ_WAVE_CYCLES']}}
 json.dump(out, open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 json.dump(dict(out['k_gemm_f16_pp64'], kernel='k_gemm_f16_pp64', tag=tag), open(os.path.join(dst, 'gemm_traffic.json'), 'w'), indent=1)
 print(json.dumps({'k_gemm_f16_pp64': out['k_gemm_f16_pp64'], 'k_gemm_f16': out['k_gemm_f16']}, indent=1))
