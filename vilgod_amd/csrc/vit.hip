@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict_
 //   by group 0 in its LOAD_{j+1} (3-deep ring -> at least one interval of lead).
 //   The second k32 sub-step's fragments are read during the first sub-step's MFMAs into the registers those have
 //   just consumed.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that ends its MMA segment.
-template <int EPI, bool TRACE = false>
+template <int EPI, bool TRACE = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
@@ -1163,12 +1163,21 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;
     constexpr int XBUF = 32768, WBASE = 2 * XBUF, WBUF = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave id in an SGPR
     const int ntm = M / BM;
     const int grp = wave >> 2, wn = wave & 3;
     long long tr_entry = 0, tr_load = 0, tr_bar = 0, tr_mma = 0, tr_wait = 0, tr_t0 = 0, tr_w0 = 0, tr_main = 0, tr_w_entry = 0;
     if (TRACE) { tr_entry = clock64(); tr_w_entry = wall_clock64(); }
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    // PERSIST: one workgroup per CU walks its XCD's contiguous run of tiles (slot s of G/8 takes tiles s, s + G/8, ...), which
+    // removes the 1-2 us a CU idles between two workgroups; nothing of consecutive tiles overlaps (the registers are full).
+    const int nt_all = ntm * (N / BN);
+    const int xq = nt_all >> 3, xr_ = nt_all & 7, xcd = blockIdx.x & 7;
+    const int xbase = (xcd < xr_) ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq;
+    const int xcnt = xq + (xcd < xr_ ? 1 : 0);
+    for (int ti = PERSIST ? (int)(blockIdx.x >> 3) : 0; ti < (PERSIST ? xcnt : 1); ti += PERSIST ? (int)(gridDim.x >> 3) : 1) {
+    int lane = tid & 63;
+    if (PERSIST) asm volatile("" : "+v"(lane));      // per-lane offsets are re-derived per tile instead of living through the epilogue
+    const int t = PERSIST ? xbase + ti : xcd_remap(blockIdx.x, gridDim.x);
     const int per_chunk = ntm * cw;
     const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
     const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
@@ -1368,7 +1377,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
             }
         }
     }
-    if (TRACE && lane == 0 && trace) {
+    if (PERSIST) __syncthreads();          // the epilogue's LDS image is read before the next tile's first pieces land
+    }
+    if (TRACE && (tid & 63) == 0 && trace) {
         long long* o = trace + ((size_t)blockIdx.x * 8 + wave) * 8;
         const long long t2 = clock64();
         o[0] = tr_main; o[1] = tr_wait; o[2] = tr_bar; o[3] = (t2 - tr_entry) - tr_main; o[4] = tr_load; o[5] = tr_mma; o[6] = wave;
@@ -1394,11 +1405,11 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
-template <int EPI, bool TRACE = false>
+template <int EPI, bool TRACE = false, bool PERSIST = false>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr) {
     if (M % 256 || N % 256 || K % 64 || K / 64 < 2) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp64<EPI, TRACE>;
+    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST>;
     const int lds = 5 * 32768;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1408,7 +1419,14 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
     const int ntn = N / 256;
     int cwt = gemm_chunk_tiles_256(ntn);
     if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep
-    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
+    int grid = (M / 256) * ntn;
+    if (PERSIST) {
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 8) n_cu = 256; }
+        if (grid > n_cu) grid = n_cu;
+        grid = (grid + 7) / 8 * 8;                 // slot s of XCD x = block 8 s + x
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
                        ldc, cwt, trace);
     VG_LAUNCH_CHECK();
     return VG_OK;
@@ -1480,7 +1498,17 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
         if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
         if (use_pp) {
             // K-step 64 / 128-byte rows when K allows it (every ViT-B/16 projection), else the K-step-32 kernel
-            if (K % 64 == 0 && K / 64 >= 2 && !getenv("VG_GEMM_PP16")) return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+            if (K % 64 == 0 && K / 64 >= 2 && !getenv("VG_GEMM_PP16")) {
+                // experiment, off by default: persistent workgroups (one per CU walking its XCD's run of tiles) per epilogue kind,
+                // bit EPI of VG_GEMM_PERSIST.  Alone at M = 64256: in_proj (+bias) 271 -> 244 us, c_fc (GELU) and out_proj +-0,
+                // c_proj -3 %; inside the pipeline no measurable change (13.65-13.70 ms of GEMMs per frame either way): the next
+                // tile's first pieces still wait for the previous tile's stores (one vmcnt), so only the dispatch gap is saved.
+                static const int persist_mask = getenv("VG_GEMM_PERSIST") ? atoi(getenv("VG_GEMM_PERSIST")) : 0;
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                    if ((persist_mask >> EPI) & 1) return launch_gemm_pp64<EPI, false, true>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+                }
+                return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+            }
             return launch_gemm_pp16<EPI, 4>(X, Wt, bias, C, resid, M, N, K, ldc, st);
         }
         int nwg = (M / GBM) * (N / GBN);
@@ -1708,6 +1736,7 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
         case 23: return launch_gemm_pp<EPI_BIAS, 5, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
         case 30: return launch_gemm_pp16<EPI_BIAS, 4>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
         case 32: return launch_gemm_pp64<EPI_BIAS>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
+        case 36: return launch_gemm_pp64<EPI_BIAS, false, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
         default: return VG_ERR_ARG; }
 #undef VG_VAR
     VG_LAUNCH_CHECK();
