@@ -113,3 +113,30 @@ def test_sequence_pipeline_matches_oracle(cuda):
         assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off)
         assert np.array_equal(fa.valid, fb.valid) and np.array_equal(fa.static, fb.static)
         assert np.array_equal(ra['name'], rb['name']) and np.allclose(ra['boxes_lidar'], rb['boxes_lidar'])
+
+
+@pytest.mark.gpu
+def test_dense_frames_six_views_in_flight_equal_sequential(cuda):
+    """BASELINE config 5 shape (dense 200k-point frames, ~120 objects; 6 rendered views as in config 3): no CPU run at this size,
+    so the check is a property -- processing the frames several at a time on worker streams (own handles per worker, shared
+    weights) gives the same states and results as processing them one by one, and the outputs are well formed."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    pipe = PseudoLabelPipeline(device=cuda, vit_dtype='f16', n_views=6, max_points=210_000, clip_model_path='/nonexistent')
+    poses = synthetic.make_poses(7)
+    frames = [pipe.upload(synthetic.make_frame(40 + f, 200_000, n_objects=120)) for f in range(5)]
+    pipe.new_sequence()
+    seq = []
+    for f in range(5):
+        fs, res = pipe.process_frame(frames[f], poses[f + 1], poses[0], fnr=f)
+        seq.append((fs, res, pipe.last_probs.cpu().numpy()))
+    pipe.new_sequence()
+    par = pipe.process_frames(frames, poses[1:6], poses[0], n_workers=4)
+    assert len(par) == 5
+    for (fa, ra, pa), (fb, rb, pb) in zip(seq, par):
+        assert np.array_equal(np.sort(fa.ground_point_indices), np.sort(fb.ground_point_indices))
+        assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off) and np.array_equal(fa.valid, fb.valid)
+        assert np.array_equal(pa, pb.cpu().numpy())                       # the same kernels on the same crops: bit-identical scores
+        assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
+        assert pa.shape[0] == 6 * int(fa.valid.sum()) and np.allclose(pa.sum(1), 1.0, atol=1e-5)
+        assert fa.n_detections > 60 and len(ra['name']) > 30
+        assert np.isfinite(ra['boxes_lidar']).all() and (ra['boxes_lidar'][:, 3:6] > 0).all()
