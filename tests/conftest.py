@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the Gaussian taps reproduce upstream's mixed numpy / torch arithmetic on purpose (mv_utils.py:204-220); numpy 2 warns about it
+    config.addinivalue_line('filterwarnings', 'ignore:__array_wrap__:DeprecationWarning')
 
 
 @pytest.fixture(scope='session')
