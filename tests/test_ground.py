@@ -151,6 +151,7 @@ def test_hip_ground_pypatchworkpp_interface(cuda, golden_dir):
     assert ground.shape[1] == 4 and len(idx) == pin['n_ground']
     assert len(pp.getNonground()) + len(idx) == len(points)
     assert abs(pp.getHeight() - pin['sensor_height']) < 1e-12
+    assert 0 < pp.getTimeTaken() < 5e6 and pp.getCenters().shape[1] == 3 and pp.getNormals().shape == pp.getCenters().shape
     m = np.zeros(len(points), np.uint8)
     m[idx] = 1
     assert hashlib.sha256(m.tobytes()).hexdigest() == pin['mask_sha256']

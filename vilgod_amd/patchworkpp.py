@@ -9,6 +9,7 @@
 `estimate_mask` is the zero-copy form the fused pipeline uses (CUDA in, CUDA uint8 mask out).
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -84,7 +85,10 @@ class patchworkpp:
         else:
             pts = points[:, :4].contiguous().float()
         self._pts = pts
+        t0 = time.perf_counter()
         self._mask = self.estimate_mask(pts, 0.0)
+        torch.cuda.synchronize(self.device)
+        self._time_taken_us = (time.perf_counter() - t0) * 1e6
 
     def _cloud(self, sel):
         idx = torch.nonzero(sel).squeeze(1)
@@ -106,6 +110,10 @@ class patchworkpp:
 
     def getHeight(self):
         return self.state()['sensor_height']
+
+    def getTimeTaken(self):
+        """microseconds spent in the last estimateGround (patchworkpp.cpp:322, patchworkpp.h:151)."""
+        return float(getattr(self, '_time_taken_us', 0.0))
 
     def patch_info(self):
         n = lib.vg_ground_num_patches(self._h)
