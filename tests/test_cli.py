@@ -170,3 +170,13 @@ def test_cli_on_openpcdet_layout(cuda, tmp_path, kind, caplog):
     assert 'Vehicle AP  L2:' in text and 'Vehicle APH L2:' in text
     ap = float(text.split('Vehicle AP  L2:')[1].split()[0])
     assert 0.0 <= ap <= 100.0
+    # load_detection_results: evaluate the stored result pickle without processing anything (preprocess_data.py:66-70,108-110)
+    stages = '_'.join(DEFAULT_STAGES)
+    caplog.clear()
+    with caplog.at_level(logging.INFO):
+        res2 = preprocess_data.main([f'preprocessor={kind}', f'dataset={kind}_openpcdet', f'dataset.DATA_PATH={root}', 'end_sequence=1',
+                                     'device.max_points=24000', 'paths.clip_model=/nonexistent', 'load_detection_results=True',
+                                     f'result_path={root}/preprocessed_data/results/vilgod_mi355x/{stages}/{names[0]}.pkl',
+                                     'pipeline.8.args.detection_3d.class_agnostic=True', 'pipeline.8.args.eval_range=[-75.,-75.,75.,75.]'])
+    assert len(res2) == 6 and 'stage classification' not in caplog.text
+    assert float(caplog.text.split('Vehicle AP  L2:')[1].split()[0]) == ap

@@ -75,7 +75,14 @@ def main(argv=None):
     logger.info('_' * 40)
 
     indices, detection_results = [], []
+    result_data = None
+    if cfg.load_detection_results and Path(cfg.result_path).exists():       # preprocess_data.py:66-70: evaluate stored results only
+        with Path(cfg.result_path).open('rb') as f:
+            result_data = pickle.load(f)
     for sequence_name in dataset.next_sequence():
+        if result_data is not None:
+            indices.extend(dataset.sequence_indices)        # (upstream leaves this empty and falls back to dataset.index_mapping)
+            continue
         result_file = result_path / f'{sequence_name}.pkl'
         indices_file = result_path / f'{sequence_name}_indices.pkl'
         if cfg.use_cached_results and 'evaluate_sequence' in cfg.pipeline_active and result_file.exists():
@@ -103,6 +110,8 @@ def main(argv=None):
         gc.collect()
         torch.cuda.empty_cache()
 
+    if result_data is not None:
+        detection_results = result_data
     if len(detection_results) > 0 and rank == 0:
         # tools/preprocess_data.py:112-131 of the reference: one evaluation over all sequences with the evaluate_sequence arguments
         det3d_args = [pp for pp in cfg.pipeline if pp['name'] == 'evaluate_sequence'][0]['args']
