@@ -3,7 +3,7 @@ opt-in fp16 residual stream)."""
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 from oracle import vit_oracle as vo
 from vilgod_amd import clip_weights as cw
 from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
