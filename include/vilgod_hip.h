@@ -114,6 +114,12 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
 int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
                   int K, int ldc, void* stream);
 
+/* development aid: the fp16 attention kernel of the tower alone (model.py:175-187 via nn.MultiheadAttention): d_qkv fp16 [n_crops*T, ld] with
+ * q | k | v at column offsets 0 | W | 2W, d_out fp16 [n_crops*T, W].  With d_trace != NULL the traced build runs and writes, per
+ * (workgroup of the persistent grid min(n_crops*heads, 256), wave 0..6), eight int64 cycle sums: staging + barrier, next-item load
+ * issue, S^T MFMA issue, max pass, exp pass, P/V^T/O^T issue, output, end barrier. */
+int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, int64_t* d_trace, void* stream);
+
 /* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
  * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,

@@ -667,12 +667,23 @@ __global__ __launch_bounds__(256) void k_layernorm(const TI* __restrict__ x, con
 // as the B operand (guide §3 "An accumulator tile as the next MFMA's operand").
 #define AT_MAXT 224
 #define AT_KLD 72      // K rows: 64 + 8 halves
-#define AT_VLD 232     // V^T rows: 224 + 8 halves
+#define AT_LDS_BYTES ((AT_MAXT * AT_KLD + 64 * 228 + 7 * 32 * AT_KLD) * 2)   // 93,696 B
+#define AT_VLD 228     // V^T rows: 224 + 4 halves (456 B: 32 rows of a fragment read hit 32 different banks; the 8 x 8 transposed
+                       // writes of a wave land 2-way conflicted)
+template <bool TRACE = false>
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T,
-                                                       int W, int heads, int ld, int n_items) {
-    __shared__ __attribute__((aligned(16))) f16 Ks[AT_MAXT * AT_KLD];
-    __shared__ __attribute__((aligned(16))) f16 Vt[64 * AT_VLD];
+                                                       int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr) {
+    long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;      // TRACE: cycles per phase, summed over this wave's items
+#define AT_STAMP(i) if (TRACE) { const long long c_ = clock64(); tr[i] += c_ - tc; tc = c_; }
+    extern __shared__ __attribute__((aligned(16))) char at_smem[];       // AT_LDS_BYTES: K rows | V^T rows | one 32-row tile per wave
+    f16* const Ks = (f16*)at_smem;
+    f16* const Vt = Ks + AT_MAXT * AT_KLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // per-wave 32 x 64 tile (row stride AT_KLD): the wave's Q rows arrive coalesced (eight lanes per 128-byte row) and are re-read as
+    // MFMA fragments (one row per lane); the output rows go the other way.  Only this wave touches it: LDS operations of one wave
+    // execute in program order, no barrier needed.
+    f16* const Qs = Vt + 64 * AT_VLD + wave * 32 * AT_KLD;
+    const int crow = lane >> 3, cpart = lane & 7;                           // coalesced layout: row it * 8 + crow, 16-byte part
     const int r31 = lane & 31, hh = lane >> 5;
     const int q0 = wave * 32;
     const int q = q0 + r31;
@@ -691,21 +702,29 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         const f16* kbase = qbase + W;
         const f16* vbase = qbase + 2 * W;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qn[s] = *(const f16x8*)(qbase + (size_t)(q < T ? q : T - 1) * ld + s * 16 + hh * 8);
+        for (int it = 0; it < 4; ++it) {
+            const int qr = q0 + it * 8 + crow;
+            qn[it] = *(const f16x8*)(qbase + (size_t)(qr < T ? qr : T - 1) * ld + cpart * 8);
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int c = tid + it * 448, key = c >> 3, part = c & 7;
             kreg[it] = *(const uint4*)(kbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
         }
+        // V rows are fetched like the K rows (eight lanes cover one 128-byte row); the transpose happens on the LDS-write side,
+        // 2-way bank-conflicted.  One key per lane (conflict-free writes, but 64 rows x 16 B per load instruction) kept the waves
+        // that issue last waiting ~3.5 k cycles per item on the address path: 151 -> 146 us per launch; a 16-key x 64-byte
+        // pattern (conflict-free writes, 16 rows per instruction) measured 149 us.
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int c = tid + it * 448, part = c / AT_MAXT, key = c - part * AT_MAXT;
+            const int c = tid + it * 448, key = c >> 3, part = c & 7;
             vreg[it] = *(const f16x8*)(vbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
         }
     };
     int item = blockIdx.x;
     if (item < n_items) fetch(item);
     for (; item < n_items; item += gridDim.x) {
+    if (TRACE) tc = clock64();
     const int crop = item / heads, head = item - crop * heads;
     const size_t row0 = (size_t)crop * T;
     // K -> LDS rows (zero beyond T)
@@ -714,19 +733,23 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         const int c = tid + it * 448, key = c >> 3, part = c & 7;
         *(uint4*)(Ks + key * AT_KLD + part * 8) = key < T ? kreg[it] : make_uint4(0, 0, 0, 0);
     }
-    // V -> LDS transposed (zero beyond T); consecutive lanes take consecutive keys
+    // V -> LDS transposed (zero beyond T)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int c = tid + it * 448, part = c / AT_MAXT, key = c - part * AT_MAXT;
+        const int c = tid + it * 448, key = c >> 3, part = c & 7;
         const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         const f16x8 v = key < T ? vreg[it] : z;
 #pragma unroll
         for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+    for (int it = 0; it < 4; ++it) *(f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8) = qn[it];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(Qs + r31 * AT_KLD + s * 16 + hh * 8);
     __syncthreads();
+    AT_STAMP(0)                                                        // K / V^T into LDS + barrier
     if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);      // in flight during the compute below
+    AT_STAMP(1)                                                        // issue of the next item's loads
     if (q0 < T) {
 
 
@@ -743,6 +766,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
             }
         }
     }
+    AT_STAMP(2)                                                        // S^T MFMAs issued
     // softmax over keys (scores scaled by 1/8 = dh^-0.5, model.py via nn.MultiheadAttention).  Only the last key block
     // can hold keys >= T; blocks beyond it were never computed (zeros) and are skipped below.
     float mx = -INFINITY;
@@ -761,6 +785,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    AT_STAMP(3)                                                        // max pass (waits for the MFMA results)
     const float c2 = 0.125f * 1.4426950408889634f;
     const float mc = -mx * c2;
     float sum = 0.f;
@@ -777,6 +802,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
+    AT_STAMP(4)                                                        // exp pass
 
     f32x16 oacc[2];
 #pragma unroll
@@ -802,21 +828,34 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
             }
         }
     }
-    if (q < T) {
-        f16* o = out + (row0 + q) * (size_t)W + head * 64;
+    AT_STAMP(5)                                                        // P -> fp16, V^T fragments, O^T MFMAs issued
+    // output rows through the wave's tile: a lane's 4-feature pieces in, 16-byte parts of whole 128-byte rows out
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 h4;
+        for (int g = 0; g < 4; ++g) {
+            f16x4 h4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
-                *(f16x4*)(o + dt * 32 + 8 * g + 4 * hh) = h4;
-            }
+            for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
+            *(f16x4*)(Qs + r31 * AT_KLD + dt * 32 + 8 * g + 4 * hh) = h4;
+        }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int qr = q0 + it * 8 + crow;
+        const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
+        if (qr < T) *(f16x8*)(out + (row0 + qr) * (size_t)W + head * 64 + cpart * 8) = v;
     }
     }
+    AT_STAMP(6)                                                        // scaled output (waits for the O^T MFMAs) + stores issued
     __syncthreads();      // every wave is done with this item's K / V^T before the next item overwrites them
+    AT_STAMP(7)                                                        // barrier at the end of the item
     }
+    if (TRACE && trace && lane == 0) {
+        long long* o = trace + ((size_t)blockIdx.x * 7 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = tr[i];
+    }
+#undef AT_STAMP
 }
 
 // fp32 parity-mode attention: one workgroup per (crop, head); K,V in LDS; one wave per query row at a time.
@@ -1677,8 +1716,13 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         if (v->dtype == 1) {
             {
                 const int items = n_crops * H;
-                hipLaunchKernelGGL(k_attention_f16, dim3(items < 256 ? items : 256), dim3(448), 0, st, (const f16*)qkv, (f16*)h, T, W, H,
-                                   qkv_ld, items);
+                static bool at_attr = false;
+                if (!at_attr) {
+                    VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
+                    at_attr = true;
+                }
+                hipLaunchKernelGGL((k_attention_f16<false>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)qkv, (f16*)h,
+                                   T, W, H, qkv_ld, items, (long long*)nullptr);
             }
         } else {
             size_t lds = ((size_t)T * 65 + (size_t)T * 64 + 4 * (size_t)T) * sizeof(float);
@@ -1756,6 +1800,24 @@ int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bia
         case 34: return launch_gemm_pp64<EPI_BIAS_RESID, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
         case 35: return launch_gemm_pp64<EPI_BIAS_RESID_H, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
         default: return VG_ERR_ARG; }
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+/* development aid: k_attention_f16 alone (trace = null) or with per-wave phase cycle counts: d_trace receives, per (workgroup of the
+ * persistent grid min(items, 256), wave 0..6), eight int64 (see the AT_STAMP comments in the kernel). */
+int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, int64_t* d_trace, void* stream) {
+    if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
+    const int items = n_crops * heads;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipFuncSetAttribute((const void*)k_attention_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)k_attention_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES);
+    if (d_trace)
+        hipLaunchKernelGGL((k_attention_f16<true>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)d_qkv, (f16*)d_out,
+                           T, W, heads, ld, items, (long long*)d_trace);
+    else
+        hipLaunchKernelGGL((k_attention_f16<false>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)d_qkv, (f16*)d_out,
+                           T, W, heads, ld, items, (long long*)nullptr);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
