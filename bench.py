@@ -10,7 +10,11 @@ A "step" = one synthetic 150k-point frame through the whole per-frame path on ev
 (ground removal -> ref transform -> HDBSCAN -> filters -> multi-view render -> CLIP ViT-B/16 fp16 encode ->
 scores -> vote -> boxes -> result dict).  Frames are sharded across ranks (weak scaling: K frames per GPU);
 the only collective is ONE all-gather of the per-crop score matrices after the K frames (north_star).
-Inputs are resident in HBM before the timed region starts.
+Inputs are resident in HBM before the timed region starts.  Each rank keeps `--inflight` frames (default 6) in flight on worker
+threads with their own streams and handles; the warm-up runs at least that many frames so that every worker handle exists before
+the timed region, and the K timed frames include filling and draining that pipeline (small K therefore reads a little lower).
+  default_config_mode  (N=1 only, information) the reference's default stage order -- entropy scores + two-frame clustering -- on a
+                coherent synthetic sequence
 
 The JSON line also carries
   roofline      the dominant kernel (ViT projection GEMM, k_gemm_f16_pp64): algorithmic FLOPs / launch duration, measured
