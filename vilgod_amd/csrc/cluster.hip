@@ -728,6 +728,7 @@ __global__ __launch_bounds__(256) void k_cl_ball_count(const float* __restrict__
                 const unsigned int c = cl_code(x, y, z);
                 const int j0 = cl_start(cs, c), j1 = cl_start(cs, c + 1u);
                 for (int j = j0; j < j1; ++j) cnt += cl_d2_f32(qx, qy, qz, spts[j]) < r2 ? 1 : 0;
+                if (cnt >= cap) { counts[i] = cap; return; }                        // the reference stops at nsample hits
             }
     counts[i] = cnt < cap ? cnt : cap;
 }

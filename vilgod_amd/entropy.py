@@ -31,6 +31,14 @@ def window(fnr, length, n_neighbouring_frames):
     return list(range(start, start + n)), fnr - start
 
 
+def spatial_order(X, cell=0.4):
+    """Permutation that sorts the points of X (CUDA [n,>=3]) by 4 x 4-cell column, height, cell within the column."""
+    c = torch.floor(X[:, :3] * (1.0 / cell)).to(torch.int64) + (1 << 18)
+    cx, cy, cz = c[:, 0], c[:, 1], c[:, 2] & 0xFFFF
+    key = ((cy >> 2) << 40) | ((cx >> 2) << 20) | (cz << 4) | ((cy & 3) << 2) | (cx & 3)
+    return torch.sort(key).indices
+
+
 class EntropyScorer:
     def __init__(self, grid_model, n_neighbouring_frames=15, skip_frames=1, max_neighbor_point_dist=0.3,
                  max_neighbor_points=1000, **unused):
@@ -60,6 +68,10 @@ class EntropyScorer:
         queries = list(range(L)) if queries is None else sorted(queries)
         wins = {f: window(f, L, self.n_neighbouring_frames) for f in queries}
         used = {f: wins[f][0][::self.skip] for f in queries}         # pointcloud_utils.py:81 idx_list[::skip]
+        # queries run in a spatially coherent order (4 x 4-cell columns of the 0.4 m grid): a wave's 64 query points then read the
+        # same few cells of the target grid, whatever order the data set stores its points in; the scores are put back at the end
+        order = {f: spatial_order(X_list[f]) for f in queries}
+        Xq = {f: X_list[f].index_select(0, order[f])[:, :3].contiguous() for f in queries}
         counts = {f: torch.zeros((len(used[f]), X_list[f].shape[0]), dtype=torch.int32, device=X_list[f].device)
                   for f in queries}
         users = {}
@@ -69,7 +81,7 @@ class EntropyScorer:
         def one_target(model, j):
             model.grid(X_list[j])
             for f, col in users[j]:
-                model.ball_count(X_list[f], self.r2, self.cap, out=counts[f][col])
+                model.ball_count(Xq[f], self.r2, self.cap, out=counts[f][col])
 
         if mapper is None:
             for j in sorted(users):
@@ -85,7 +97,7 @@ class EntropyScorer:
             if len(used[f]) < 2:
                 raise NotImplementedError('entropy scores need at least two neighbouring frames')
             check(lib.vg_entropy_scores(ptr(counts[f]), len(used[f]), n, seek_row, ptr(H), stream_ptr()), 'vg_entropy_scores')
-            out[f] = H
+            out[f] = torch.empty_like(H).index_copy_(0, order[f], H)          # back to the frame's point order
         return [out[f] for f in range(L)] if as_list else out
 
     @staticmethod
@@ -141,7 +153,9 @@ class TwoFrameClusterer:
         dev = X.device
         m = self.model
         m.grid(X)
-        counts = m.ball_count(X, np.float32(0.2) * np.float32(0.2), 100)             # count_neighbors_inter_frame(points, 0.2)
+        o = spatial_order(X)                                                          # coherent query order, see score_sequence
+        counts = torch.empty(n, dtype=torch.int32, device=dev).index_copy_(
+            0, o, m.ball_count(X.index_select(0, o)[:, :3].contiguous(), np.float32(0.2) * np.float32(0.2), 100))   # count_neighbors_inter_frame(points, 0.2)
         moving = ent < MOVING
         mi = torch.nonzero(moving).squeeze(1)
         mask = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -188,8 +202,10 @@ class TwoFrameClusterer:
         lo, hi, w2 = self.model.mst(seq, dim=5)
         lab_seq, prob_seq, _ = self.model.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), m)
         self.model.grid(seq)
-        idx, _ = self.model.nearest(X_list[fnr], self.gate)
-        idx = idx.cpu().numpy().astype(np.int64)
+        Xf = X_list[fnr]
+        o = spatial_order(Xf)
+        idx_s, _ = self.model.nearest(Xf.index_select(0, o)[:, :3].contiguous(), self.gate)
+        idx = torch.empty_like(idx_s).index_copy_(0, o, idx_s).cpu().numpy().astype(np.int64)
         ok = idx >= 0
         labels = np.where(ok, lab_seq[np.maximum(idx, 0)], -1).astype(np.int64)
         probs = np.where(ok, prob_seq[np.maximum(idx, 0)], 0.0)
