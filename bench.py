@@ -76,7 +76,7 @@ def cpu_baseline(n_points=20_000, n_objects=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=48)
+    ap.add_argument('--steps', type=int, default=96)
     ap.add_argument('--warmup', type=int, default=12)
     ap.add_argument('--points', type=int, default=150_000)
     ap.add_argument('--objects', type=int, default=60)
