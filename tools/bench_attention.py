@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vilgod_amd._lib import lib, ptr, stream_ptr, check
 dev = torch.device('cuda:0')
 n, T, W, H = int(os.environ.get('CROPS', '325')), 197, 768, 12
-ld = 3 * W + 256
+ld = 3 * W + 64
 qkv = (torch.randn(n * T, ld, device=dev) * 1.0).half()
 out = torch.zeros(n * T, W, dtype=torch.float16, device=dev)
 tr = torch.zeros(256 * 7 * 8, dtype=torch.int64, device=dev)

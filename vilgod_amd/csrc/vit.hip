@@ -1643,7 +1643,10 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     char* ws = (char*)d_workspace;
     float* x = (float*)ws;            ws += Mp * W * 4;
     void* h = ws;                     ws += Mp * W * es;
-    const int qkv_ld = v->dtype == 1 ? 3 * W + 256 : 3 * W;   // fp16: padded rows (channel aliasing of 4608-B rows)
+    // fp16: qkv rows padded by 64 halves.  The padding dates from k_gemm_f16, where 4608-byte rows aliased on the memory channels
+    // (+20 %); with k_gemm_f16_pp64 the GEMM time no longer depends on it (13.50-13.58 ms per frame for 0 / 32 / 64 / 128 / 256),
+    // but whole frames run 2.5 % faster with 0-128 than with 256 halves (57.0 vs 55.3 frames/s): less to write and to stride over.
+    const int qkv_ld = v->dtype == 1 ? 3 * W + 64 : 3 * W;
     void* qkv = ws;                   ws += Mp * (3 * W + 256) * es;
     void* mlp = ws;                   ws += Mp * 4 * W * es;
     void* patches = ws;               ws += Pp * Kp * es;
