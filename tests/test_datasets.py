@@ -183,3 +183,28 @@ def test_evaluation_end_to_end(tmp_path):
     assert present
     for c in present:
         assert abs(ap[f'OBJECT_TYPE_TYPE_{c.upper()}_LEVEL_2/AP'][0] - 1) < 1e-9
+
+
+def test_adapter_split_interval_and_sequence_window(tmp_path):
+    """set_split re-reads the infos of the other split; SAMPLED_INTERVAL thins the frames; start/end_sequence pick the sequences
+    (waymo_dataset.py:57-86; OpenPCDet's ImageSets/<split>.txt + SAMPLED_INTERVAL)."""
+    root = str(tmp_path)
+    fx.write_waymo(root, n_sequences=3, n_frames=6, n_points=500, n_objects=6, seed=1, split='train')
+    names_val = fx.write_waymo(root, n_sequences=1, n_frames=4, n_points=500, n_objects=6, seed=9, split='val')
+    ds = WaymoDataset(dict(fx.WAYMO_CFG, DATA_PATH=root), CLASSES, training=True, start_sequence=1, end_sequence=3)
+    assert len(ds.infos) == 18 and len(ds.sequence_mapping) == 3
+    assert len(ds.sequence_names) == 2 and ds.sequence_names == list(ds.sequence_mapping)[1:3]
+    ds.set_split('val')
+    assert len(ds.infos) == 4 and list(ds.sequence_mapping) == names_val
+    assert ds.start_sequence == 0 and ds.end_sequence == 1          # 1 < 1 is false -> start falls back to 0 (create_sequence_mapping)
+    seqs = list(ds.next_sequence())
+    assert seqs == names_val and ds.sequence_length == 4 and ds.get_lidar_points(0).shape[1] == 5
+    thin = WaymoDataset(dict(fx.WAYMO_CFG, DATA_PATH=root, SAMPLED_INTERVAL={'train': 2, 'test': 1}), CLASSES, training=True)
+    assert len(thin.infos) == 9
+    # NLZ rows are dropped unless DISABLE_NLZ_FLAG_ON_POINTS; intensity goes through tanh
+    keep = WaymoDataset(dict(fx.WAYMO_CFG, DATA_PATH=root, DISABLE_NLZ_FLAG_ON_POINTS=False), CLASSES, training=True)
+    next(iter(ds.next_sequence())); next(iter(keep.next_sequence()))
+    full = WaymoDataset(dict(fx.WAYMO_CFG, DATA_PATH=root), CLASSES, training=True)
+    next(iter(full.next_sequence()))
+    a, b = full.get_lidar_points(0), keep.get_lidar_points(0)
+    assert len(b) < len(a) and 0.9 < len(b) / len(a) < 1.0 and (a[:, 3] <= 1.0).all() and (a[:, 3] >= 0.0).all()
