@@ -163,6 +163,14 @@ int vg_ground_estimate(vg_ground* h, const float* d_points, int n, int stride, d
 /* synchronous diagnostics: {sensor_height (getHeight, pybinding.cpp:47), elevation_thr[4], flatness_thr[4],
  * stored elevation counts[4], stored flatness counts[4]} */
 int vg_ground_get_state(vg_ground* h, double* h_out17, void* stream);
+/* the COMPLETE frame-to-frame state (patchworkpp.cpp:315-316, 339-376: sensor height, elevation / flatness thresholds and the
+ * per-ring stores they are recomputed from, patchworkpp.h:171-189 members) as an opaque host blob of vg_ground_state_bytes()
+ * bytes.  export after frame f on one handle + set on another handle (other stream / GPU / rank) = the sequence continues
+ * there bit for bit: the hand-off that frame-sharding a sequence needs (SURVEY 8b "Native surface", 8e exception 1).
+ * Synchronous.  set_state validates the blob's cursors and returns VG_ERR_ARG for a foreign layout. */
+int64_t vg_ground_state_bytes(void);
+int vg_ground_export_state(vg_ground* h, void* h_blob, void* stream);
+int vg_ground_set_state(vg_ground* h, const void* h_blob, void* stream);
 int vg_ground_num_patches(const vg_ground* h);
 /* synchronous: [n_patches,12] = n, n_ground, normal[3] (getNormals), mean[3] (getCenters), singular values[3],
  * decision (0 non-ground, 1 ground) */

@@ -31,6 +31,7 @@ from scipy.spatial import cKDTree
 MIN_CLUSTER_SIZE = 15
 EPSILON = 0.15
 PROB_THRESHOLD = 0.3      # waymo.yaml:63 `propability_threshold`
+PRIM_C_ABOVE = 6000       # larger inputs take the C form of the same Prim (mst_prim_c)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -94,6 +95,24 @@ def mst_prim(X, core2):
         w2[e] = cand[nxt]
         in_tree[nxt] = True
         cur = nxt
+    return edges, w2
+
+
+def mst_prim_c(X, core2):
+    """`mst_prim` in C (oracle/hdbscan_oracle.cpp: same numeric model, same total order; checked against `mst_prim` in
+    tests/test_cluster.py) -- the form that finishes at the benchmark's full size (80k points: seconds instead of minutes)."""
+    import ctypes
+    from . import patchworkpp as _pw
+    lib = _pw.load()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    core2 = np.ascontiguousarray(core2, dtype=np.float64)
+    n, dim = X.shape
+    edges = np.zeros((n - 1, 2), np.int64)
+    w2 = np.zeros(n - 1)
+    lib.vgo_mst_prim.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = lib.vgo_mst_prim(X.ctypes.data, n, dim, core2.ctypes.data, edges.ctypes.data, w2.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f'vgo_mst_prim failed ({rc})')
     return edges, w2
 
 
@@ -277,7 +296,7 @@ def fit(X, min_cluster_size=MIN_CLUSTER_SIZE, eps=EPSILON):
     if n <= min_cluster_size:
         return np.full(n, -1, np.int64), np.zeros(n)
     core2 = core_distances_sq(X, min_cluster_size)
-    edges, w2 = mst_prim(X, core2)
+    edges, w2 = (mst_prim_c if n > PRIM_C_ABOVE else mst_prim)(X, core2)
     e, w2s = sort_edges(edges, w2)
     l, r, v, s = single_linkage(e, np.sqrt(w2s), n)
     rows = condense(l, r, v, s, n, min_cluster_size)

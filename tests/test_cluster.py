@@ -246,3 +246,55 @@ def test_hip_cluster_full_size_properties(cuda):
     ari = adjusted_rand_score(labels[perm], labels2)
     print(f'full size: n={n} clusters={labels.max() + 1} rounds={model.n_rounds_} ARI under permutation={ari:.5f}')
     assert ari > 0.99
+
+
+def test_prim_in_c_equals_python_prim():
+    """oracle/hdbscan_oracle.cpp (the form that finishes at full size) == the readable Python Prim, ties and 5-D included."""
+    rng = np.random.default_rng(3)
+    for n, dim in [(300, 3), (1500, 3), (900, 5)]:
+        X = rng.normal(size=(n, dim)).astype(np.float32)
+        X[:40] = X[40:80]                                   # exact duplicates -> equal weights and equal pair distances
+        X[100:160, :] = np.round(X[100:160, :] * 4) / 4       # lattice points -> many equal distances
+        core2 = ho.core_distances_sq(X)
+        e1, w1 = ho.mst_prim(X, core2)
+        e2, w2 = ho.mst_prim_c(X, core2)
+        assert np.array_equal(e1, e2) and np.array_equal(w1, w2)
+
+
+def test_full_size_fixture_is_committed(golden_dir):
+    import json
+    g = json.load(open(f'{golden_dir}/cluster_full_golden.json'))
+    assert g['n'] > 70_000 and g['n_clusters'] > 50 and len(g['mst_w2_sha256']) == 64
+
+
+@pytest.mark.gpu
+def test_hip_cluster_full_size_equals_oracle_fixture(cuda, golden_dir):
+    """BASELINE size: the HIP clustering of the ~79k non-ground points of one synthetic 150k-point frame against the CPU
+    oracle's result frozen by tests/golden/make_cluster_fixture.py (core distances, MST edges + weights, labels,
+    probabilities, detection lists: sha256, i.e. bit for bit)."""
+    import json
+    import sys
+    import torch
+    sys.path.insert(0, golden_dir)
+    import make_cluster_fixture as mk
+    g = json.load(open(f'{golden_dir}/cluster_full_golden.json'))
+    X = mk.build_input()
+    if mk.sha(X) != g['x_sha256']:
+        # the input itself came out differently on this host (libm / compiler of the ground oracle): re-run the oracle here
+        core2 = ho.core_distances_sq(X)
+        edges, ew2 = ho.mst_prim_c(X, core2)
+        e, w2s = ho.sort_edges(edges, ew2)
+        wl, wp = ho.tree_from_mst(e, w2s, len(X))
+        g = mk.digests(X, core2, e[:, 0], e[:, 1], w2s, wl, wp)
+        print('fixture input differs on this host: oracle re-run live')
+    n = len(X)
+    model = _gpu_model(cuda, n)
+    lo, hi, w2, core2 = model.mst(torch.from_numpy(X).to(cuda), want_core=True)
+    lo, hi, w2, core2 = lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), core2.cpu().numpy()
+    order = np.lexsort((hi, lo, w2))
+    m = model.fit(X)
+    got = mk.digests(X, core2, lo[order], hi[order], w2[order], m.labels_, m.probabilities_)
+    for k in ('n', 'core2_sha256', 'mst_w2_sha256', 'mst_edges_sha256', 'labels_sha256', 'canonical_labels_sha256', 'probs_sha256',
+              'n_clusters', 'n_noise', 'n_detections', 'detection_sizes_sha256'):
+        assert got[k] == g[k], (k, got[k], g[k])
+    print(f"full-size fixture: n={n} clusters={got['n_clusters']} noise={got['n_noise']} rounds={model.n_rounds_}: identical")

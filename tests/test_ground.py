@@ -2,8 +2,8 @@
 
 The reference's Patchwork++ cannot be built here (Eigen3 absent) and holds no test vectors -> PARITY UNPINNED
 against the reference; what IS checked:
-  CPU: the oracle's eigen-solver against numpy; invariants of the oracle; a regression pin on two of the
-       KITTI scans the reference ships as demo data (third_party/patchwork-plusplus/data/00000[01].bin).
+  CPU: the oracle's eigen-solver against numpy; invariants of the oracle; a regression pin on the
+       KITTI scans (all six) the reference ships as demo data (third_party/patchwork-plusplus/data/00000[0-5].bin).
   GPU: csrc/ground.hip (through the C ABI) returns EXACTLY the oracle's ground index set, frame after frame
        (the adaptive state is carried), on KITTI, on 150k-point synthetic frames and on edge cases.
 """
@@ -96,7 +96,7 @@ def _same_sequence(frames, z_offset, cuda, min_range=1.5, tweak=None):
 
 @pytest.mark.gpu
 def test_hip_ground_kitti_sequence(cuda, golden_dir):
-    _same_sequence([kitti(golden_dir, 0), kitti(golden_dir, 1)], 0.0, cuda)
+    _same_sequence([kitti(golden_dir, i) for i in range(6)], 0.0, cuda)        # all six scans, one stateful object
 
 
 @pytest.mark.gpu
@@ -159,3 +159,34 @@ def test_hip_ground_pypatchworkpp_interface(cuda, golden_dir):
     pp.reset()
     pp.estimateGround(pts)
     assert np.array_equal(np.sort(pp.getGround()[..., -1].astype(int)), np.sort(idx))
+
+
+@pytest.mark.gpu
+def test_hip_ground_state_handoff(cuda, golden_dir):
+    """vg_ground_export_state / vg_ground_set_state: the state after frame f exported from one handle and set on a
+    fresh one continues the sequence bit for bit -- what a frame-sharded sequence hands from rank to rank."""
+    from vilgod_amd import patchworkpp as gpw
+    p = gpw.Parameters()
+    p.min_range = 1.5
+    frames = [kitti(golden_dir, i) for i in range(6)]
+    one = gpw.patchworkpp(p, max_points=130_000, device=cuda)
+    want = [np.sort(gpw.mask_ground_points_patchwork_pp(f, one, 0.0)) for f in frames]
+    a = gpw.patchworkpp(p, max_points=130_000, device=cuda)
+    for f in frames[:3]:
+        gpw.mask_ground_points_patchwork_pp(f, a, 0.0)
+    blob = a.export_state()
+    assert len(blob) == int(gpw.lib.vg_ground_state_bytes())
+    b = gpw.patchworkpp(p, max_points=130_000, device=cuda)
+    b.set_state(blob)
+    for k in range(3, 6):
+        assert np.array_equal(np.sort(gpw.mask_ground_points_patchwork_pp(frames[k], b, 0.0)), want[k]), k
+    assert b.export_state() == one.export_state()
+    pin = json.load(open(f'{golden_dir}/ground_kitti.json'))['frames']
+    assert b.state()['sensor_height'] == pin[5]['sensor_height']
+    # a foreign blob is refused, the handle keeps working
+    bad = bytearray(blob)
+    bad[9 * 8:9 * 8 + 4] = (10 ** 6).to_bytes(4, 'little')          # elev_head[0] out of range
+    with pytest.raises(Exception):
+        b.set_state(bytes(bad))
+    with pytest.raises(ValueError):
+        b.set_state(blob[:-8])

@@ -173,3 +173,54 @@ def test_hip_attention_alone(cuda, n_crops, T):
     out2 = torch.zeros_like(out)
     check(lib.vg_attention_trace(ptr(d_qkv), ptr(out2), n_crops, T, W, H, ld, ptr(tr), stream_ptr()))
     assert torch.equal(out, out2) and int((tr.view(-1, 8)[:, 0] > 0).sum()) >= min(n_crops * H, 256)
+
+
+@pytest.mark.gpu
+def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
+    """The fp16 tower (the benchmarked mode: fp16 GEMM operands / activations, fp32 accumulate, LayerNorm and residual stream
+    in fp32) against the fp32 oracle (pinned to the reference's model.py) on crops the RENDERER produced -- through the
+    production path (patch rows written by the renderer, no CHW crop in between).  north_star's tolerance for the fp32 path is
+    1e-3 on the probabilities; the fp16 mode is asserted at <= 2e-3 max probability error and <= 1e-3 relative L2 feature
+    error (measured ~6e-4 / ~3.5e-4), top-1 identical wherever the oracle's margin exceeds twice that bound."""
+    from vilgod_amd import synthetic
+    from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
+    from vilgod_amd.projection import RealisticProjection
+    rng = np.random.default_rng(11)
+    # six object-like clusters (surface points of boxes seen from the sensor) at several ranges -> 24 crops
+    clusters = []
+    for k, (l, w, h) in enumerate([(4.5, 1.9, 1.6), (0.6, 0.6, 1.7), (1.8, 0.6, 1.7), (0.3, 0.3, 4.0), (8.0, 0.3, 2.5), (11.0, 2.6, 3.2)]):
+        n = [900, 120, 260, 60, 1500, 2600][k]
+        p = rng.uniform(-0.5, 0.5, size=(n, 3)) * [l, w, h]
+        face = rng.integers(0, 2, n)
+        p[face == 0, 0] = -l / 2
+        p[face == 1, 1] = -w / 2
+        yaw = rng.uniform(0, np.pi)
+        R2 = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        p[:, :2] = p[:, :2] @ R2.T
+        p += [rng.uniform(8, 45) * np.cos(k), rng.uniform(8, 45) * np.sin(k), h / 2 - 1.7]
+        clusters.append(p.astype(np.float32))
+    X = np.concatenate(clusters)
+    seg = np.r_[0, np.cumsum([len(c) for c in clusters])].astype(np.int32)
+    d_X = torch.from_numpy(X).to(cuda)
+    d_index = torch.arange(len(X), dtype=torch.int32, device=cuda)
+    d_seg = torch.from_numpy(seg).to(cuda)
+    proj = RealisticProjection(dict(depth_bias=0.2, obj_ratio=0.8, bg_clr=0.0, resolution=112, depth=8,
+                                    gaussian_kernel=dict(sigma=3, zsigma=1)), device=cuda)
+    crops32 = proj.render_frame(d_X, d_index, d_seg, np.eye(4), out='f32')
+    patches = proj.render_frame(d_X, d_index, d_seg, np.eye(4), out='patch16')
+    n = crops32.shape[0]
+    assert n == 24 and float(crops32.std()) > 0.05
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    text = cw.synthetic_text_features(0, 24, 512)
+    f_want, p_want = _oracle_probs(wd, 12, crops32.cpu(), text)
+    enc = VitEncoder(wd, dtype='f16', device=cuda)
+    f = enc.encode_patches(patches, n)
+    probs, top1, _ = clip_scores(f, text.to(cuda))
+    f, probs, top1 = f.cpu(), probs.cpu(), top1.cpu().numpy()
+    rel = ((f - f_want).norm() / f_want.norm()).item()
+    perr = (probs - p_want).abs().max().item()
+    print(f'f16 tower on {n} rendered crops: feature rel L2 {rel:.2e}, max prob err {perr:.2e}')
+    assert rel <= 1e-3 and perr <= 2e-3
+    srt = np.sort(p_want.numpy(), axis=1)
+    sure = (srt[:, -1] - srt[:, -2]) > 4e-3
+    assert np.array_equal(top1[sure], vo.top1(p_want)[0][sure])

@@ -1,0 +1,85 @@
+"""Per-cluster oriented boxes: `fit_bounding_boxes_simple`, static branch
+(src/vilgod/zero_shot_detector.py:444-462) over `minimum_bounding_rectangle` (src/utils/pointcloud_utils.py:309-372).
+
+Two modes, selected by `PseudoLabelPipeline(box_mode=...)` / `device.box_mode`:
+
+  'reference' (default)  the boxes the reference writes.  `minimum_bounding_rectangle` evaluates the rectangle only for the
+              directions of qhull's vertex cycle WITHOUT its closing edge (:329-330 `hull_points[1:] - hull_points[:-1]`), so
+              the result depends on which vertex qhull lists first -- an artefact of qhull's incremental construction (the
+              oldest surviving facet) that no closed-form rule predicts.  The mode therefore does what the reference does where
+              it matters: the hull comes from the same library call (`scipy.spatial.ConvexHull` on the cluster's float32 xy
+              points), and the rectangle over its <= few dozen vertices is evaluated with the reference's own float32 numpy
+              expression sequence (numpy's float32 `arctan2` / `cos` are SIMD routines whose last bit is host dependent, so only
+              the same calls reproduce the reference's float32 boxes).  The per-point work stays on the GPU: cluster membership
+              and packing, z extent (`vg_cluster_filter` statistics) and the validity filters; this module touches each
+              cluster's xy points once, on the worker thread of the frame, while the GPU classifies the frame's crops (the
+              boxes do not depend on the classes).
+  'fast'      `vg_cluster_boxes` (csrc/segment.hip k_cluster_box): exact-predicate hull + rectangle over ALL hull edges in
+              float64 on the GPU.  Identical to the reference whenever the best direction is not the dropped closing edge
+              (~85 % of clusters), otherwise its rectangle is the smaller one.
+
+Host code is numpy because the reference's is; there is no CPU fallback for the GPU parts.
+"""
+import numpy as np
+from scipy import spatial
+
+PI2 = np.pi / 2.
+
+
+def minimum_bounding_rectangle(points):
+    """pointcloud_utils.py:309-372, expression by expression (float32 in, float32 arithmetic like upstream).
+    -> (corners (4,2) float64 array holding float32 values, rz, area)."""
+    try:
+        hull_points = points[spatial.ConvexHull(points).vertices]
+    except Exception:                                     # qhull raises on < 3 points / flat input (:320-326)
+        corners = np.ones((4, 2)) * np.mean(points[:, :2], axis=0)[:2]
+        corners += np.array([[-0.05, -0.05], [0.05, -0.05], [0.05, 0.05], [-0.05, 0.05]])
+        return corners, 0, 0
+    edges = hull_points[1:] - hull_points[:-1]            # the closing edge of the vertex cycle is NOT there (:329-330)
+    angles = np.arctan2(edges[:, 1], edges[:, 0])
+    angles = np.abs(np.mod(angles, PI2))
+    angles = np.unique(angles)
+    rotations = np.vstack([np.cos(angles), np.cos(angles - PI2), np.cos(angles + PI2), np.cos(angles)]).T
+    rotations = rotations.reshape((-1, 2, 2))
+    rot_points = np.dot(rotations, hull_points.T)
+    min_x = np.nanmin(rot_points[:, 0], axis=1)
+    max_x = np.nanmax(rot_points[:, 0], axis=1)
+    min_y = np.nanmin(rot_points[:, 1], axis=1)
+    max_y = np.nanmax(rot_points[:, 1], axis=1)
+    areas = (max_x - min_x) * (max_y - min_y)
+    best_idx = np.argmin(areas)
+    x1, x2, y1, y2 = max_x[best_idx], min_x[best_idx], max_y[best_idx], min_y[best_idx]
+    r = rotations[best_idx]
+    rval = np.zeros((4, 2))
+    rval[0] = np.dot([x1, y2], r)
+    rval[1] = np.dot([x2, y2], r)
+    rval[2] = np.dot([x2, y1], r)
+    rval[3] = np.dot([x1, y1], r)
+    return rval, angles[best_idx], areas[best_idx]
+
+
+def box_from_rectangle(corners, rz, zmin, zmax):
+    """zero_shot_detector.py:452-461.  zmin / zmax: float32 scalars (the cluster's z extent)."""
+    l = np.linalg.norm(corners[0] - corners[1])
+    w = np.linalg.norm(corners[0] - corners[-1])
+    c = (corners[0] + corners[2]) / 2
+    if w > l:
+        l, w = w, l
+        rz += np.pi / 2
+    height = zmax - zmin
+    return np.array([c[0], c[1], zmin + height / 2, l, w, height + 0.3, rz])
+
+
+def reference_boxes(xy_host, index, seg, zmin, zmax):
+    """Boxes of the packed clusters (index / seg as in frame_state.pack_clusters), reference mode.
+    xy_host: [M,>=2] float32 host array of points_ref_wo_ground; zmin / zmax: [C] float32 (vg_cluster_filter stats).
+    -> [C,7] float64 [cx,cy,cz,l,w,h,rz] in the reference frame."""
+    C = len(seg) - 1
+    out = np.empty((C, 7))
+    zmin = np.asarray(zmin, dtype=np.float32)
+    zmax = np.asarray(zmax, dtype=np.float32)
+    for c in range(C):
+        pts = xy_host[index[seg[c]:seg[c + 1]], :2]
+        corners, rz, _ = minimum_bounding_rectangle(pts)
+        out[c] = box_from_rectangle(corners, rz, zmin[c], zmax[c])
+    return out

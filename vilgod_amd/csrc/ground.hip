@@ -701,6 +701,30 @@ int vg_ground_get_state(vg_ground* h, double* h_out17, void* stream) {
     return VG_OK;
 }
 
+/* The complete frame-to-frame state (PwState: sensor height, thresholds, the elevation / flatness stores with their ring
+ * cursors) as an opaque host blob of vg_ground_state_bytes() bytes: export after frame f on one handle, set on another
+ * (another stream, another GPU / rank) and frame f+1 continues exactly as on the first.  Both synchronous. */
+int64_t vg_ground_state_bytes(void) { return (int64_t)sizeof(PwState); }
+
+int vg_ground_export_state(vg_ground* h, void* h_blob, void* stream) {
+    if (!h || !h_blob) return VG_ERR_ARG;
+    VG_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    VG_CHECK(hipMemcpy(h_blob, h->d_state, sizeof(PwState), hipMemcpyDeviceToHost));
+    return VG_OK;
+}
+
+int vg_ground_set_state(vg_ground* h, const void* h_blob, void* stream) {
+    if (!h || !h_blob) return VG_ERR_ARG;
+    const PwState* st = (const PwState*)h_blob;
+    for (int i = 0; i < 4; ++i)                 // a blob from a handle with other storage limits would index out of range
+        if (st->elev_cnt[i] < 0 || st->elev_cnt[i] > PW_STORE_CAP || st->flat_cnt[i] < 0 || st->flat_cnt[i] > PW_STORE_CAP ||
+            st->elev_head[i] < 0 || st->elev_head[i] >= PW_STORE_CAP || st->flat_head[i] < 0 || st->flat_head[i] >= PW_STORE_CAP)
+            return VG_ERR_ARG;
+    VG_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    VG_CHECK(hipMemcpy(h->d_state, h_blob, sizeof(PwState), hipMemcpyHostToDevice));
+    return VG_OK;
+}
+
 int vg_ground_num_patches(const vg_ground* h) { return h ? h->g.n_patches : 0; }
 
 /* synchronous: [n_patches,12] = n, n_ground, normal[3], mean[3], sv[3], decision */

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_cluster_box(const float* __restrict__ p
     __shared__ double red_d[4];
     __shared__ int red_i[4];
     __shared__ float red_z[8];
-    __shared__ int sh_cur, sh_n, sh_start;
+    __shared__ int sh_cur, sh_start;
     __shared__ double sh_sum[2];
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p0 = seg_off[c], n = seg_off[c + 1] - p0;
@@ -219,7 +219,6 @@ __global__ __launch_bounds__(256) void k_cluster_box(const float* __restrict__ p
         }
         sh_start = red_i[0];
         sh_cur = red_i[0];
-        sh_n = 0;
     }
     // NOTE: sx, sy partial sums are per wave; finish them through shared memory
     __syncthreads();
@@ -231,13 +230,13 @@ __global__ __launch_bounds__(256) void k_cluster_box(const float* __restrict__ p
     zmax = red_z[4];
     // ---- gift wrapping (counter-clockwise): next = the point with no other point to its right; farthest on ties ----
     bool degenerate = n < 3;
+    int hn = 0;                       // hull vertices so far: counted by every thread (uniform), so the loop exit never reads a
+                                      // shared counter that thread 0 may already be advancing for the next iteration
     while (!degenerate) {
         const int cur = sh_cur;
         const double cx0 = PX(cur), cy0 = PY(cur);
-        if (tid == 0) {
-            if (sh_n < BOX_MAX_HULL) { hx[sh_n] = cx0; hy[sh_n] = cy0; }
-            sh_n++;
-        }
+        if (tid == 0 && hn < BOX_MAX_HULL) { hx[hn] = cx0; hy[hn] = cy0; }
+        hn++;
         int best = -1;
         double bxx = 0, byy = 0, bd2 = -1;
         for (int i = tid; i < n; i += 256) {
@@ -281,9 +280,9 @@ __global__ __launch_bounds__(256) void k_cluster_box(const float* __restrict__ p
         const int nxt = sh_cur;
         if (nxt < 0) { degenerate = true; break; }                       // all points coincide
         if (PX(nxt) == PX(sh_start) && PY(nxt) == PY(sh_start)) break;    // closed
-        if (sh_n >= BOX_MAX_HULL) break;                                 // safety (keeps a valid, coarser polygon)
+        if (hn >= BOX_MAX_HULL) break;                                   // safety (keeps a valid, coarser polygon)
     }
-    const int nh = degenerate ? 0 : min(sh_n, BOX_MAX_HULL);
+    const int nh = degenerate ? 0 : min(hn, BOX_MAX_HULL);
     // hull area (shoelace) to detect collinear input (qhull raises -> reference falls back to a 0.1 m square)
     __shared__ double sh_area2;
     if (tid == 0) {

@@ -15,8 +15,9 @@
 //                  plain fp32 VALU kernels, no MFMA, same epilogues.
 //
 // Layout (all row-major, K contiguous):
-//   tokens M = n_crops * T (T = 1 + (res/patch)^2), rows padded to a multiple of 256 (workspace is
-//   zero-initialised by the host once, padding rows stay finite).
+//   tokens M = n_crops * T (T = 1 + (res/patch)^2), rows padded to a multiple of 256 (the padding rows of the
+//   residual stream are re-zeroed by k_embed_lnpre on every call; the other buffers' padding rows are written by
+//   the GEMMs from them and stay finite).
 //   x    [Mp, W]   f32   residual stream
 //   h    [Mp, W]   f16|f32   LayerNorm output / attention output
 //   qkv  [Mp, 3W]  f16|f32
@@ -564,9 +565,15 @@ template <typename TO>
 __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ patch_out, const float* __restrict__ cls,
                                                      const float* __restrict__ pos, const float* __restrict__ lw,
                                                      const float* __restrict__ lb, TO* __restrict__ x, int n_rows,
-                                                     int T, int W) {
+                                                     int T, int W, int n_rows_padded) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n_rows) return;
+    if (row >= n_rows_padded) return;
+    if (row >= n_rows) {
+        // padding rows of the residual stream (GEMM row tile): re-zeroed on every call -- every residual epilogue adds its
+        // bias into them, and the workspace carve-up moves when n_crops changes
+        for (int c = lane; c < W; c += 64) x[(size_t)row * W + c] = (TO)0.f;
+        return;
+    }
     const int crop = row / T, t = row - crop * T;
     const float* src = (t == 0) ? cls : patch_out + ((size_t)crop * (T - 1) + (t - 1)) * W;
     float v[16];
@@ -1686,13 +1693,13 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     const bool rh = v->resid_h;
     f16* xh = (f16*)x;                // the residual stream lives in the same workspace region, as fp16 when `rh`
     if (rh)
-        hipLaunchKernelGGL((k_embed_lnpre<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
+        hipLaunchKernelGGL((k_embed_lnpre<f16>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
                            (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
-                           (const float*)need("ln_pre.bias"), xh, (int)M, T, W);
+                           (const float*)need("ln_pre.bias"), xh, (int)M, T, W, (int)Mp);
     else
-        hipLaunchKernelGGL((k_embed_lnpre<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
+        hipLaunchKernelGGL((k_embed_lnpre<float>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
                            (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
-                           (const float*)need("ln_pre.bias"), x, (int)M, T, W);
+                           (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp);
     VG_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
         std::string p = "transformer.resblocks." + std::to_string(l) + ".";

@@ -85,3 +85,28 @@ def gather_objects(obj):
     out = [None] * ws
     dist.all_gather_object(out, obj)
     return out
+
+
+def chain_ground_state(ground_model, run_my_block, device=None):
+    """Patchwork++'s adaptive state runs through the whole sequence (SURVEY 8e exception 1).  With contiguous frame blocks the
+    state is HANDED from rank to rank instead of every rank replaying the frames before its block: rank r waits for the state
+    after frame start_r - 1 from rank r - 1 (point to point, ~131 KB), sets it, runs the ground stage over its OWN block
+    (`run_my_block()`), and passes the state on to rank r + 1 before it starts the heavy stages.  Same masks and same final
+    state as one sequential pass (tests/test_cli.py, tests/test_ground.py)."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return run_my_block()
+    gloo = dist.get_backend() == 'gloo'
+    dev = torch.device('cpu') if gloo else (device or torch.device('cuda', torch.cuda.current_device()))
+    from ._lib import lib
+    nbytes = int(lib.vg_ground_state_bytes())
+    if rank > 0:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dist.recv(buf, src=rank - 1)
+        ground_model.set_state(buf.cpu().numpy().tobytes())
+    out = run_my_block()
+    if rank < ws - 1:
+        blob = torch.frombuffer(bytearray(ground_model.export_state()), dtype=torch.uint8).to(dev)
+        dist.send(blob, dst=rank + 1)
+    return out

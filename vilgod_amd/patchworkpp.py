@@ -108,6 +108,18 @@ class patchworkpp:
         return dict(sensor_height=o[0], elevation_thr=o[1:5].copy(), flatness_thr=o[5:9].copy(),
                     n_elevation=o[9:13].astype(int), n_flatness=o[13:17].astype(int))
 
+    def export_state(self):
+        """The complete frame-to-frame state as bytes (vg_ground_export_state): hand it to `set_state` of another object
+        (another stream / GPU / rank) and the sequence continues there exactly (frame-sharded sequences)."""
+        buf = ctypes.create_string_buffer(int(lib.vg_ground_state_bytes()))
+        check(lib.vg_ground_export_state(self._h, buf, stream_ptr()), 'vg_ground_export_state')
+        return buf.raw
+
+    def set_state(self, blob):
+        if len(blob) != int(lib.vg_ground_state_bytes()):
+            raise ValueError(f'ground state blob of {len(blob)} bytes, expected {int(lib.vg_ground_state_bytes())}')
+        check(lib.vg_ground_set_state(self._h, ctypes.c_char_p(bytes(blob)), stream_ptr()), 'vg_ground_set_state')
+
     def getHeight(self):
         return self.state()['sensor_height']
 

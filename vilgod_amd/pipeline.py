@@ -60,7 +60,8 @@ def _get(cfg, key, default=None):
 
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
-                 clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None):
+                 clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
+                 box_mode='reference'):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -89,6 +90,11 @@ class PseudoLabelPipeline:
         self.class_names = list(_get(cfg, 'class_names', ['Vehicle', 'Pedestrian', 'Cyclist']))
         self.cls_key = f"{_get(clip_cfg, 'name', 'clip')}_" + '_'.join(str(_get(clip_cfg, 'prompt_template')).format('').split(' ')[:-1])
         self.plane_seed = int(plane_seed)
+        if box_mode not in ('reference', 'fast'):
+            raise ValueError("box_mode: 'reference' (the reference's boxes: qhull vertex order, closing edge dropped) or 'fast' "
+                             "(GPU hull + rectangle over all edges)")
+        self.box_mode = box_mode
+        self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         self.timings = {}
         self._clip_cfg, self._clip_model_path, self._mcfg, self._n_views = clip_cfg, clip_model_path, mcfg, n_views
@@ -105,6 +111,7 @@ class PseudoLabelPipeline:
                                            views=VIEWS_4 if self._n_views == 4 else VIEWS_6)
         w.clip = self.clip.view()                # shared read-only weights, own workspace
         w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
+        w._xy_pinned = None
         w.timings = {}
         w.stream = torch.cuda.Stream(device=self.device)
         from concurrent.futures import ThreadPoolExecutor
@@ -275,12 +282,55 @@ class PseudoLabelPipeline:
 
     # [E1]
     def boxes(self, d_X, d_index, d_seg):
+        """'fast' mode kernel: exact hull + rectangle over ALL hull edges, float64 (csrc/segment.hip k_cluster_box)."""
         C = d_seg.numel() - 1
         box = torch.empty((C, 7), dtype=torch.float64, device=self.device)
         aux = torch.empty((C, 3), dtype=torch.float32, device=self.device)
         check(lib.vg_cluster_boxes(ptr(d_X), d_X.stride(0), ptr(d_index), ptr(d_seg), C, ptr(box), ptr(aux), stream_ptr()),
               'vg_cluster_boxes')
         return box, aux
+
+    def xy_to_host_async(self, d_X):
+        """Start the D2H copy of points_ref_wo_ground[:, :2] into this worker's pinned buffer (reference box mode reads each
+        cluster's xy points once on the host, vilgod_amd/boxes.py).  -> (host array view, event to wait for)."""
+        n = d_X.shape[0]
+        if self._xy_pinned is None or self._xy_pinned.shape[0] < n:
+            self._xy_pinned = torch.empty((max(n, self.max_points), 2), dtype=torch.float32, pin_memory=True)
+        dst = self._xy_pinned[:n]
+        dst.copy_(d_X[:, :2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return dst.numpy(), ev
+
+    def z_extent(self, d_X, d_index, d_seg):
+        """float32 (zmin, zmax) per packed cluster from the statistics kernel (vg_cluster_filter, thresholds open)."""
+        C = d_seg.numel() - 1
+        stats = torch.empty((C, 6), dtype=torch.float32, device=self.device)
+        valid = torch.empty(C, dtype=torch.uint8, device=self.device)
+        d_plane = torch.tensor([0.0, 0.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
+        check(lib.vg_cluster_filter(ptr(d_X), d_X.stride(0), ptr(d_index), ptr(d_seg), C, ptr(d_plane), 0, 2 ** 31 - 1, 1e300, -1e300,
+                                    -1e300, 1e300, ptr(stats), ptr(valid), stream_ptr()), 'vg_cluster_filter')
+        st = stats.cpu().numpy()
+        return st[:, 1], st[:, 2]
+
+    def fit_boxes(self, d_X, index, seg, d_index=None, d_seg=None, xy_host=None, zmin=None, zmax=None):
+        """fit_bounding_boxes_simple, static branch (zero_shot_detector.py:444-462), for the packed clusters (index, seg).
+        -> [C,7] float64 numpy boxes in the reference frame, by `self.box_mode` (vilgod_amd/boxes.py)."""
+        C = len(seg) - 1
+        if C == 0:
+            return np.zeros((0, 7))
+        if d_index is None:
+            d_index = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32)).to(self.device)
+            d_seg = torch.from_numpy(np.ascontiguousarray(seg, dtype=np.int32)).to(self.device)
+        if self.box_mode == 'fast':
+            return self.boxes(d_X, d_index, d_seg)[0].cpu().numpy()
+        from .boxes import reference_boxes
+        if zmin is None:
+            zmin, zmax = self.z_extent(d_X, d_index, d_seg)
+        if xy_host is None:
+            xy_host, ev = self.xy_to_host_async(d_X)
+            ev.synchronize()
+        return reference_boxes(xy_host, index, seg, zmin, zmax)
 
     # [F1]
     @staticmethod
@@ -392,6 +442,8 @@ class PseudoLabelPipeline:
         if tick is None:
             tick = lambda name, t0: time.perf_counter()
             t0 = time.perf_counter()
+        # per-crop score matrix of THIS frame (empty unless the frame reaches classification): never a previous frame's
+        self.last_probs = torch.zeros((0, len(self.class_list)), dtype=torch.float32, device=self.device)
         ids, index, seg = pack_clusters(labels, probs, self.prob_threshold)
         fs.set_clusters(ids, index, seg)
         C = len(ids)
@@ -405,9 +457,12 @@ class PseudoLabelPipeline:
             return fs, result
         d_index = torch.from_numpy(index).to(self.device)
         d_seg = torch.from_numpy(seg).to(self.device)
+        xy_host = xy_ev = None
+        if self.box_mode == 'reference':
+            xy_host, xy_ev = self.xy_to_host_async(d_X)            # lands while the plane fit / filters / classification run
         plane = self.ground_plane(d_ref, gidx) if self._filters['use_plane'] else np.array([0.0, 0.0, 1.0, 0.0])
         fs.ground_plane_model_ref = plane
-        valid, _ = self.filter(d_X, d_index, d_seg, plane)
+        valid, stats = self.filter(d_X, d_index, d_seg, plane)
         fs.valid = valid.cpu().numpy().astype(bool)
         fs.filtered = True
         t0 = tick('filter', t0)
@@ -422,10 +477,15 @@ class PseudoLabelPipeline:
         d_vindex = torch.from_numpy(v_index).to(self.device)
         d_vseg = torch.from_numpy(v_seg).to(self.device)
         probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
-        box, _ = self.boxes(d_X, d_vindex, d_vseg)
+        if self.box_mode == 'reference':
+            # host part of the reference-exact box fit (vilgod_amd/boxes.py) while the GPU encodes the frame's crops
+            st = stats.cpu().numpy()
+            xy_ev.synchronize()
+            box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
+        else:
+            box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg)
         top1 = top1.cpu().numpy()
         score = score.cpu().numpy()
-        box = box.cpu().numpy()
         t0 = tick('classify+boxes', t0)
         V = self.projection.num_views
         nv = len(vrows)

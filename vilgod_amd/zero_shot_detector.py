@@ -48,7 +48,8 @@ class ZeroShotDetector:
             pipeline = PseudoLabelPipeline(cfg.preprocessor, device=device, vit_dtype=dev.get('vit_dtype', 'f16'),
                                            n_views=dev.get('n_views', 4), max_points=dev.get('max_points', 300_000),
                                            clip_model_path=cfg.paths.clip_model, min_range=ga['min_range'],
-                                           z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666), clip=clip_model)
+                                           z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666), clip=clip_model,
+                                           box_mode=dev.get('box_mode', 'reference'))
         self.pipe = pipeline
         self.sequence_data_dir_path = Path(cfg.paths.sequence_data)
         self.my_frames = vdist.shard_frames(self.lenght, self.rank, self.world_size)
@@ -57,6 +58,8 @@ class ZeroShotDetector:
         self._scores = {}                                # fnr -> [n_crops, K] class probabilities
         self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
         self.n_workers = int(dev.get('frames_in_flight', 6))
+        self.sync_every_stage = bool(dev.get('sync_every_stage', False))
+        self._dirty = False
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
         self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
         self._host_X = {}                                # fnr -> points_ref_wo_ground on the host (tracking stages are host logic)
@@ -151,13 +154,22 @@ class ZeroShotDetector:
             self._host_X[fnr] = self._ref_and_nonground(fnr)[1].cpu().numpy()
         return self._host_X[fnr]
 
-    def sync_lidar_frames(self, mode='save'):
+    def sync_lidar_frames(self, mode='save', final=False):
         path = self.sequence_data_dir_path / f'{self.name}{self.cfg.postfix.sequence_data}'
         if mode == 'save':
+            if self.world_size > 1 and not final:
+                return                                   # several ranks: written once per run, after the gather (process())
+            if not self.sync_every_stage and not final:
+                self._dirty = True                       # one write at the end of process() instead of one per stage
+                return
             if self.world_size > 1:
-                return                                   # written once, after the gather in evaluate_sequence
+                self._exchange_states()
+                if self.rank != 0:
+                    self._dirty = False
+                    return
             with open(path, 'wb') as fp:
-                pickle.dump([f.serialize for f in self.lidar_frame_list], fp)
+                pickle.dump([f.serialize for f in self.lidar_frame_list], fp, protocol=pickle.HIGHEST_PROTOCOL)
+            self._dirty = False
         elif mode == 'load':
             if path.exists():
                 with open(path, 'rb') as fp:
@@ -178,6 +190,11 @@ class ZeroShotDetector:
                 self.logger.info(f'  stage {task_name}: {1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1):.2f} ms per frame')
             else:
                 self.logger.warning(f'{task_name} NOT FOUND!!!')
+        # the sequence-state pickle (zero_shot_detector.py:105-114): the reference rewrites it after every stage; here it is
+        # written once per run unless device.sync_every_stage asks for the reference's per-stage files (same final content).
+        # With several ranks it is written by rank 0 after the states were gathered, whatever stages ran.
+        if self._dirty or self.world_size > 1:
+            self.sync_lidar_frames(final=True)
         self.logger.info(f'Finished processing sequence: {self.name}')
 
     # ---- stages ------------------------------------------------------------------------------------------
@@ -186,12 +203,38 @@ class ZeroShotDetector:
             return
         self.pipe.z_offset = float(z_offset)
         self.pipe.new_sequence()                         # one stateful Patchwork++ object per sequence, :137-140
+        dev = self.cfg.get('device', {}) if hasattr(self.cfg, 'get') else {}
+        handoff = dev.get('ground_handoff', 'chain') if self.world_size > 1 else 'replay'
+
+        def run(frames):
+            for fnr in frames:                           # sequential and stateful
+                fs = self.lidar_frame_list[fnr]
+                pts = self._points(fnr) if fnr in mine else self.pipe.upload(self.dataset.get_lidar_points(fnr))
+                mask = self.pipe.ground(pts)
+                fs.n_points = pts.shape[0]
+                fs.ground_point_indices = torch.nonzero(mask).squeeze(1).cpu().numpy()
+
         mine = set(self.my_frames)
-        for fs in self.lidar_frame_list:                 # sequential and stateful: every rank replays all frames
-            pts = self.pipe.upload(self.dataset.get_lidar_points(fs.fnr)) if fs.fnr not in mine else self._points(fs.fnr)
-            mask = self.pipe.ground(pts)
-            fs.n_points = pts.shape[0]
-            fs.ground_point_indices = torch.nonzero(mask).squeeze(1).cpu().numpy()
+        if handoff == 'chain':
+            # the adaptive state is handed from rank to rank (vg_ground_export_state / set_state): every rank runs the ground
+            # stage over its own block only; the ground sets of the other blocks arrive with the frame states later
+            vdist.chain_ground_state(self.pipe.ground_model, lambda: run(self.my_frames), device=self.pipe.device)
+            # the other blocks' ground sets (halo frames of the entropy window, the final state pickle) travel as bit masks:
+            # 19 KB per 150k-point frame, small pickled objects like the result dicts -- not a data-path collective
+            packed = {}
+            for f in self.my_frames:
+                fs = self.lidar_frame_list[f]
+                m = np.zeros(fs.n_points, bool)
+                m[fs.ground_point_indices] = True
+                packed[f] = (fs.n_points, np.packbits(m))
+            for part in vdist.gather_objects(packed):
+                for f, (n, bits) in part.items():
+                    if f not in mine:
+                        fs = self.lidar_frame_list[f]
+                        fs.n_points = n
+                        fs.ground_point_indices = np.flatnonzero(np.unpackbits(bits, count=n))
+        else:
+            run(range(self.lenght))                      # every rank replays all frames (no communication)
         self.sync_lidar_frames()
 
     def _entropy_full(self, fnr):
@@ -358,6 +401,9 @@ class ZeroShotDetector:
         ckey = kwargs.get('classification_key', None)
         if self.tracker is not None and len(self.tracker.tracks_valid) > 0:
             # tracks available: static and moving objects are handled differently (zero_shot_detector.py:462-684)
+            if not kwargs.get('force', False) and any(fs.boxes is not None and np.isfinite(fs.boxes[:, 0]).any()
+                                                      for fs in self.lidar_frame_list):
+                return                                   # boxes exist and force is off: upstream skips the stage (:424-432)
             for fs in self.lidar_frame_list:
                 fs.boxes = None
             self._fit_boxes_tracked(valid_only)
@@ -376,10 +422,17 @@ class ZeroShotDetector:
             if len(rows) == 0:
                 continue
             _, X = self._ref_and_nonground(fnr)
-            d_index, d_seg = self._cluster_lists(fnr, rows)
-            box, _ = self.pipe.boxes(X, d_index, d_seg)
-            fs.boxes[rows] = box.cpu().numpy()
+            fs.boxes[rows] = self._fit_rows(fnr, rows, X)
         self.sync_lidar_frames()
+
+    def _fit_rows(self, fnr, rows, X):
+        """Static-branch boxes of clusters `rows` of frame fnr (pipeline.fit_boxes: reference or fast mode)."""
+        fs = self.lidar_frame_list[fnr]
+        parts = [fs.cluster_index(c) for c in rows]
+        index = np.concatenate(parts).astype(np.int32)
+        seg = np.r_[0, np.cumsum([len(p) for p in parts])].astype(np.int32)
+        xy = self._host_X[fnr] if (self.pipe.box_mode == 'reference' and fnr in self._host_X) else None
+        return self.pipe.fit_boxes(X, index, seg, xy_host=xy)
 
     def evaluate_sequence(self, modes=('detection_3d',), logger=None, **kwargs):
         key = kwargs.get('classification_key', 'clip')
@@ -406,11 +459,6 @@ class ZeroShotDetector:
             for part in vdist.gather_objects(local):
                 merged.update(part)
             local = merged
-            self._exchange_states()
-            if self.rank == 0:
-                path = self.sequence_data_dir_path / f'{self.name}{self.cfg.postfix.sequence_data}'
-                with open(path, 'wb') as fp:
-                    pickle.dump([f.serialize for f in self.lidar_frame_list], fp)
         self.detection_3d_result_list = [local[f] for f in sorted(local)]
 
     # ---- tracking, motion-aware boxes, label propagation (host logic, vilgod_amd/tracking.py) -------------
@@ -459,9 +507,7 @@ class ZeroShotDetector:
         for fnr, rows in tracked.items():
             rows = sorted(rows)
             _, X = self._ref_and_nonground(fnr)
-            d_index, d_seg = self._cluster_lists(fnr, rows)
-            box, _ = self.pipe.boxes(X, d_index, d_seg)
-            for r, b in zip(rows, box.cpu().numpy()):
+            for r, b in zip(rows, self._fit_rows(fnr, rows, X)):
                 gpu_box[(fnr, r)] = b
         tab = DetectionTable()
         for fs in self.lidar_frame_list:
