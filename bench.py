@@ -5,43 +5,55 @@
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (without a launcher: bench.py starts the N ranks itself, as child processes)
 
-A "step" = one synthetic 150k-point frame through the whole per-frame path on every rank
-(ground removal -> ref transform -> HDBSCAN -> filters -> multi-view render -> CLIP ViT-B/16 fp16 encode ->
-scores -> vote -> boxes -> result dict).  Frames are sharded across ranks (weak scaling: K frames per GPU);
-the only collective is ONE all-gather of the per-crop score matrices after the K frames (north_star).
-Inputs are resident in HBM before the timed region starts.  Each rank keeps `--inflight` frames (default 6) in flight on worker
-threads with their own streams and handles; the warm-up runs at least that many frames so that every worker handle exists before
-the timed region, and the K timed frames include filling and draining that pipeline (small K therefore reads a little lower).
-  default_config_mode  (N=1 only, information) the reference's default stage order -- entropy scores + two-frame clustering -- on a
-                coherent synthetic sequence
+A "step" = one synthetic 150k-point frame through the whole per-frame path (ground removal -> ref transform -> HDBSCAN ->
+filters -> multi-view render -> CLIP ViT-B/16 fp16 encode -> scores -> vote -> boxes -> result dict).  Weak scaling: ONE
+sequence of N*K frames is sharded over the N ranks in contiguous blocks of K frames, exactly as the stage dispatcher shards a
+sequence (vilgod_amd/zero_shot_detector.py, vilgod_amd/dist.py).  Patchwork++'s adaptive state runs through the whole
+sequence: inside the timed region rank r receives the state after frame r*K - 1 from rank r - 1 (`--ground-handoff chain`,
+vg_ground_export_state / vg_ground_set_state) or replays the ground stage over the r*K frames before its block
+(`--ground-handoff replay`).  The only data-path collective is ONE all-gather of the per-crop score matrices after the K
+frames (north_star).  Inputs are resident in HBM before the timed region starts.  Each rank keeps `--inflight` frames (default
+6) in flight on worker threads with their own streams and handles; the warm-up runs at least that many frames so that every
+worker handle exists before the timed region, and the K timed frames include filling and draining that pipeline (small K
+therefore reads a little lower: the driver's K = 20 run vs the default K = 96).
 
 The JSON line also carries
-  roofline      the dominant kernel (ViT projection GEMM, k_gemm_f16_pp64): algorithmic FLOPs / launch duration, measured
-                live with HIP event pairs on the launch stream (csrc/vit.hip vg_vit_profile), vs the dense fp16
-                MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md
-  cpu_baseline  the CPU oracle (oracle/pipeline_oracle.py, kind "port": the reference cannot travel to the GPU box)
-                timed on a bounded sample on the host cores of the same box (rank 0, N=1 only)
+  roofline      the dominant kernel (the ViT projection GEMM): algorithmic FLOPs / launch duration, measured live with HIP
+                event pairs on the launch stream (csrc/vit.hip vg_vit_profile), vs the dense fp16 MFMA peak of
+                /opt/skills/guides/MI355X_MICROARCH.md
+  cpu_baseline  the CPU oracle (oracle/pipeline_oracle.py, kind "port": the reference cannot travel to the GPU box) timed on a
+                bounded sample of the metric's workload on the host cores of the same box (rank 0, N=1 only)
+and, as information beside the metric (N=1 only; each block reports its own failure instead of costing the metric line):
+  box_modes            the same frames with box_mode 'fast' (GPU hull, all edges) next to the default 'reference' mode
+  views6, dense200k    BASELINE configs 3 (6 rendered views) and 5 (200k points, ~120 objects) shapes
+  default_config_mode  the reference's default stage order -- entropy scores + two-frame clustering -- as a library call
+  cli_mode             tools/preprocess_data.py itself: the default 9-stage list on a 199-frame 150k-point synthetic sequence
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 VIT_FLOP_PER_CROP = 2 * 17_563_453_440          # SURVEY §8d
 PEAK_F16_MFMA_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+DOMINANT_KERNEL = 'k_gemm_f16_pp64'
 
 
-def cpu_baseline(n_points=20_000, n_objects=8):
-    """Whole path on the host cores for one bounded frame (BASELINE config 0 shape)."""
+def cpu_baseline(n_points=150_000, n_objects=60, vit_crops=32, with_20k=True):
+    """Whole path on the host cores on a BOUNDED sample of the metric's workload: ONE 150k-point frame through every stage, the
+    ViT (the dominant CPU cost, linear in the crops) on the first `vit_crops` crops and extrapolated to the frame's crops."""
+    import torch
     from oracle.pipeline_oracle import OraclePipeline
+    from oracle import vit_oracle as vo
     from vilgod_amd import synthetic, clip_weights as cw
     from vilgod_amd.pipeline import default_preprocessor_cfg
     n_threads = min(16, os.cpu_count())        # more threads make the small per-cluster ops slower (measured on the 256-core box)
@@ -49,28 +61,73 @@ def cpu_baseline(n_points=20_000, n_objects=8):
     cfg = default_preprocessor_cfg()
     wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
     text = cw.synthetic_text_features(0, 24, 512)
-    orc = OraclePipeline(wd, text, cfg['clip']['class_list'], cfg['clip']['class_mapping'], clusterer='sklearn')
-    n_frames = 3
-    frames = [synthetic.make_frame(1000 + i, n_points, n_objects=n_objects) for i in range(n_frames)]
-    poses = synthetic.make_poses(n_frames + 1)
-    t0 = time.perf_counter()
-    crops = valid = 0
-    tsum = {}
-    for i in range(n_frames):
-        o = orc.process_frame(frames[i], poses[i + 1], poses[0])
-        crops += len(o['u8'])
-        valid += int(o['valid'].sum())
-        for k, v in orc.timings.items():
-            tsum[k] = tsum.get(k, 0.0) + v
-    dt = time.perf_counter() - t0
-    return {
-        'value': round(n_frames / dt, 5), 'unit': 'frames/s (20k-pt frames)', 'cores': n_threads, 'kind': 'port',
-        'sample': (f'{n_frames} consecutive synthetic frames of {n_points} points ({valid} valid clusters, {crops} crops in total; '
-                   f'BASELINE config 0 shape -- a 150k-pt frame carries ~5x the crops and ~8x the points), all stages, '
-                   f'{dt:.1f} s: ' + ', '.join(f'{k} {v:.2f}s' for k, v in tsum.items()) +
-                   '; clustering = sklearn.cluster.HDBSCAN stand-in (the reference\'s hdbscan package is absent), '
-                   'ViT = torch-CPU fp32, same synthetic weights'),
+    orc = OraclePipeline(wd, text, cfg['clip']['class_list'], cfg['clip']['class_mapping'], clusterer='sklearn', box_all_edges=False)
+    poses = synthetic.make_poses(4)
+    out = {}
+
+    def run(points, objects, n_frames, crop_cap):
+        frames = [synthetic.make_frame(1000 + i, points, n_objects=objects) for i in range(n_frames)]
+        orig = vo.encode_in_chunks
+        seen = {'crops': 0, 'encoded': 0, 'vit_s': 0.0}
+
+        def capped(wd_, x, heads, chunk):
+            # time the tower on at most crop_cap crops, return features for all (the rest repeats the last one: only the
+            # timing is used below, never the classes)
+            n = len(x)
+            k = n if crop_cap is None else min(n, crop_cap)
+            t0 = time.perf_counter()
+            f = orig(wd_, x[:k], heads, chunk)
+            seen['vit_s'] += time.perf_counter() - t0
+            seen['crops'] += n
+            seen['encoded'] += k
+            return f if k == n else torch.cat([f, f[-1:].expand(n - k, -1)])
+        vo.encode_in_chunks = capped
+        try:
+            t0 = time.perf_counter()
+            valid = 0
+            tsum = {}
+            for i in range(n_frames):
+                o = orc.process_frame(frames[i], poses[i + 1], poses[0])
+                valid += int(o['valid'].sum())
+                for k, v in orc.timings.items():
+                    tsum[k] = tsum.get(k, 0.0) + v
+            dt = time.perf_counter() - t0
+        finally:
+            vo.encode_in_chunks = orig
+        vit_full = seen['vit_s'] * seen['crops'] / max(seen['encoded'], 1)
+        tsum['vit'] = tsum.get('vit', 0.0) - seen['vit_s'] + vit_full           # the 'vit' tick also holds scores/top-1 (negligible)
+        total = dt - seen['vit_s'] + vit_full
+        return total, dt, valid, seen, tsum
+
+    orc.new_sequence()
+    total, dt, valid, seen, tsum = run(n_points, n_objects, 1, vit_crops)
+    out = {
+        'value': round(1.0 / total, 5), 'unit': 'frames/s', 'cores': n_threads, 'kind': 'port',
+        'sample': (f'ONE synthetic frame of {n_points} points (the metric\'s workload; {valid} valid clusters, {seen["crops"]} crops) through '
+                   f'all stages in {dt:.1f} s of CPU work; the ViT was run on the first {seen["encoded"]} crops ({seen["vit_s"]:.1f} s) and '
+                   f'extrapolated linearly to all {seen["crops"]} (-> {total:.1f} s per frame): ' + ', '.join(f'{k} {v:.2f}s' for k, v in tsum.items()) +
+                   '; clustering = sklearn.cluster.HDBSCAN stand-in (the reference\'s hdbscan package is absent; its Boruvka is '
+                   'faster than this Prim), ViT = torch-CPU fp32, same synthetic weights; boxes = scipy qhull + numpy like the reference'),
     }
+    if with_20k:
+        orc.new_sequence()
+        total2, dt2, valid2, seen2, tsum2 = run(20_000, 8, 3, None)
+        out['config0_20k'] = {'value': round(3 / total2, 5), 'unit': 'frames/s (20k-pt frames)',
+                              'sample': f'3 consecutive synthetic frames of 20000 points, everything run ({valid2} valid clusters, '
+                                        f'{seen2["crops"]} crops, {dt2:.1f} s): ' + ', '.join(f'{k} {v:.2f}s' for k, v in tsum2.items())}
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (nothing here has touched the GPU) through
+    torch.distributed.run and pass their output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -82,16 +139,27 @@ def main():
     ap.add_argument('--objects', type=int, default=60)
     ap.add_argument('--views', type=int, default=4)
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+    ap.add_argument('--box-mode', default='reference', choices=['reference', 'fast'])
+    ap.add_argument('--ground-handoff', default='chain', choices=['chain', 'replay'],
+                    help='N > 1: how rank r obtains the Patchwork++ state at the start of its frame block (both inside the timed region)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the information blocks beside the metric (box_modes, views6, dense200k, cli_mode)')
+    ap.add_argument('--cli-frames', type=int, default=199, help='frames of the synthetic sequence of the cli_mode block')
     ap.add_argument('--stage-times', action='store_true', help='print per-stage ms (adds synchronisation; not for the metric)')
     ap.add_argument('--no-roofline-pass', action='store_true', help='skip the sequential GEMM-timing pass (profiling runs)')
     ap.add_argument('--no-sequence-pass', action='store_true', help='skip the extra (untimed-for-the-metric) pass in the reference\'s default stage order')
     ap.add_argument('--inflight', type=int, default=6, help='frames in flight per GPU (worker streams); 1 = strictly sequential')
     args = ap.parse_args()
 
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} '
+                 f'(or run `python bench.py --gpus {args.gpus}` without a launcher)')
+    import torch
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -102,79 +170,97 @@ def main():
     dev = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(dev)
 
-    from vilgod_amd import synthetic
+    from vilgod_amd import synthetic, dist as vdist
     from vilgod_amd.pipeline import PseudoLabelPipeline
     pipe = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=args.views, max_points=args.points + 1024,
-                               clip_model_path='/nonexistent')
-    # a short synthetic sequence per rank: frames differ, poses follow a smooth trajectory; resident in HBM
+                               clip_model_path='/nonexistent', box_mode=args.box_mode)
+    K, W = args.steps, max(args.warmup, args.inflight if args.inflight > 1 else 0)       # warm-up covers the worker handles
+    # ONE sequence of world * K timed frames (+ a warm-up stretch in front), contiguous block of K frames per rank, smooth
+    # trajectory; four distinct point clouds per rank are cycled, resident in HBM
     n_distinct = 4
-    poses = synthetic.make_poses(args.steps + max(args.warmup, args.inflight) + 8, seed=rank)   # warm-up covers the worker handles
+    poses = synthetic.make_poses(W + world * K + 8, seed=0)
     frames = [pipe.upload(synthetic.make_frame(1 + rank * 100 + i, args.points, n_objects=args.objects)) for i in range(n_distinct)]
     torch.cuda.synchronize()
-
     inflight = 1 if args.stage_times else max(1, args.inflight)
+    stage = {}
 
-    def run_steps(first, count):
-        """`count` frames (steps) starting at step index `first`; returns [(FrameState, result, probs)]."""
-        idx = list(range(first, first + count))
+    def run_steps(p, first_pose, count, first_fnr, after_ground=None):
+        """`count` frames whose poses start at index `first_pose`; returns [(FrameState, result, probs)]."""
+        idx = list(range(count))
         if inflight == 1:
             out = []
             for i in idx:
-                fs, res = pipe.process_frame(frames[i % n_distinct], poses[i + 1], poses[0], fnr=i, timing=args.stage_times)
-                out.append((fs, res, pipe.last_probs))
-                for k, v in pipe.timings.items():
+                fs, res = p.process_frame(frames[i % n_distinct], poses[first_pose + i], poses[0], fnr=first_fnr + i, timing=args.stage_times)
+                out.append((fs, res, p.last_probs))
+                for k, v in p.timings.items():
                     stage[k] = stage.get(k, 0.0) + v
+            if after_ground is not None:
+                after_ground()
             return out
-        return pipe.process_frames([frames[i % n_distinct] for i in idx], [poses[i + 1] for i in idx], poses[0],
-                                   n_workers=inflight, first_fnr=first)
+        return p.process_frames([frames[i % n_distinct] for i in idx], [poses[first_pose + i] for i in idx], poses[0],
+                                n_workers=inflight, first_fnr=first_fnr, after_ground=after_ground)
 
-    stage = {}
-    pipe.new_sequence()
-    run_steps(0, max(args.warmup, inflight if inflight > 1 else 0))        # also builds the worker handles
-    stage = {}
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    crops = clusters = labelled = 0
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    score_mats = []
-    for fs, res, probs in run_steps(args.warmup, args.steps):
-        score_mats.append(probs)
-        crops += probs.shape[0]
-        clusters += fs.n_detections
-        labelled += len(res['name'])
-    # the one collective of the path: all-gather of the per-crop score matrices (padded to a common length)
-    scores = torch.cat(score_mats) if score_mats else torch.zeros((0, 24), device=dev)
-    if dist is not None:
-        cdev = 'cpu' if dist.get_backend() == 'gloo' else dev
-        n_loc = torch.tensor([scores.shape[0]], device=cdev, dtype=torch.int64)
-        n_all = [torch.zeros_like(n_loc) for _ in range(world)]
-        dist.all_gather(n_all, n_loc)
-        mx = int(max(int(x.item()) for x in n_all))
-        pad = torch.zeros((mx, scores.shape[1]), device=dev, dtype=scores.dtype)
-        pad[:scores.shape[0]] = scores
-        gathered = torch.empty((world * mx, scores.shape[1]), device=dev, dtype=scores.dtype)
-        if dist.get_backend() == 'gloo':                  # host-staged in the self test; RCCL gathers device tensors directly
-            parts = [torch.empty_like(pad.cpu()) for _ in range(world)]
-            dist.all_gather(parts, pad.cpu())
-            gathered = torch.cat(parts).to(dev)
+    def timed_block(p):
+        """The timed region of one rank: ground-state hand-off + K frames + the one all-gather.  -> (elapsed, outputs)."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p.new_sequence()
+        out = []
+        if world > 1 and args.ground_handoff == 'replay':
+            for i in range(rank * K):                    # the frames before this rank's block: ground stage only
+                p.ground(frames[i % n_distinct])
+            out = run_steps(p, W + rank * K, K, rank * K)
+        elif world > 1:
+            # chain: the block's ground passes are queued first on the caller's stream (process_frames does that), the state after
+            # them is exported and sent on while the workers are already busy with the block's frames
+            vdist.recv_ground_state(p.ground_model, dev)
+            out = run_steps(p, W + rank * K, K, rank * K, after_ground=lambda: vdist.send_ground_state(p.ground_model, dev))
         else:
-            dist.all_gather_into_tensor(gathered, pad)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device='cpu' if (dist is not None and dist.get_backend() == 'gloo') else dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    # roofline of the dominant kernel: HIP event pairs around every k_gemm_f16_pp64 launch on its launch stream, over a
-    # SEQUENTIAL pass (1 frame in flight) of the same workload right after the timed region -- with several frames in
-    # flight the pairs would also span other streams' kernels and stop measuring this kernel.
+            out = run_steps(p, W, K, 0)
+        score_mats = [probs for _, _, probs in out]
+        # the one collective of the path: all-gather of the per-crop score matrices (padded to a common length)
+        scores = torch.cat(score_mats) if score_mats else torch.zeros((0, 24), device=dev)
+        if dist is not None:
+            cdev = 'cpu' if dist.get_backend() == 'gloo' else dev
+            n_loc = torch.tensor([scores.shape[0]], device=cdev, dtype=torch.int64)
+            n_all = [torch.zeros_like(n_loc) for _ in range(world)]
+            dist.all_gather(n_all, n_loc)
+            mx = int(max(int(x.item()) for x in n_all))
+            pad = torch.zeros((mx, scores.shape[1]), device=dev, dtype=scores.dtype)
+            pad[:scores.shape[0]] = scores
+            gathered = torch.empty((world * mx, scores.shape[1]), device=dev, dtype=scores.dtype)
+            if dist.get_backend() == 'gloo':                  # host-staged in the self test; RCCL gathers device tensors directly
+                parts = [torch.empty_like(pad.cpu()) for _ in range(world)]
+                dist.all_gather(parts, pad.cpu())
+                gathered = torch.cat(parts).to(dev)
+            else:
+                dist.all_gather_into_tensor(gathered, pad)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], device='cpu' if (dist is not None and dist.get_backend() == 'gloo') else dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), out
+
+    pipe.new_sequence()
+    run_steps(pipe, 0, W, 0)                                   # warm-up, also builds the worker handles
+    stage = {}
+    elapsed, outs = timed_block(pipe)
+    crops = sum(p.shape[0] for _, _, p in outs)
+    clusters = sum(fs.n_detections for fs, _, _ in outs)
+    labelled = sum(len(res['name']) for _, res, _ in outs)
+
+    # roofline of the dominant kernel: HIP event pairs around every launch of it on its launch stream, over a SEQUENTIAL pass
+    # (1 frame in flight) of the same workload right after the timed region -- with several frames in flight the pairs would
+    # also span other streams' kernels and stop measuring this kernel.
     launches = gemm_ms = gemm_flops = all_launches = all_ms = all_flops = 0
+    n_pass = min(4, K)
     if not args.no_roofline_pass:
-        n_pass = min(4, args.steps)
         pipe.clip.encoder.profile(True)
         for i in range(n_pass):
             pipe.process_frame(frames[i % n_distinct], poses[i + 1], poses[0], fnr=i)
@@ -183,50 +269,109 @@ def main():
         pipe.clip.encoder.profile(False)
 
     if rank == 0:
-        frames_total = world * args.steps
+        frames_total = world * K
         value = frames_total / elapsed
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None
+        traffic = traffic_src = None
         tpath = os.path.join(ROOT, 'profiles', 'gemm_traffic.json')       # tools/collect_profiles.sh + summarize_profiles.py
         if os.path.exists(tpath):
-            traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
+            tj = json.load(open(tpath))
+            traffic = round(tj['hbm_bytes_per_launch'])
+            traffic_src = f"profiles/gemm_traffic.json ({tj.get('kernel', '?')}, {tj.get('tag', '?')}): rocprofv3 PMC passes of this command, not measured in this run"
         out = {
             'metric': 'pseudo-labeled LiDAR frames/sec (150k pts, ~60 clusters)',
-            'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1000.0 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+            'ms_per_step': round(1000.0 * elapsed / K, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f16' if args.dtype == 'f16' else 'f32', 'data': 'synthetic',
             'config': {
                 'workload': (f'full per-frame path (ground removal, HDBSCAN, filters, {args.views}-view render, CLIP ViT-B/16 '
-                             f'{args.dtype} encode, scores, vote, boxes) on synthetic {args.points}-pt frames, '
-                             f'{args.objects} objects (BASELINE config 3 shape), frames sharded {world}-way, '
-                             'one all-gather of the score matrices'),
-                'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': args.steps,
-                'clusters_per_frame': round(clusters / max(args.steps, 1), 1),
-                'crops_per_frame': round(crops / max(args.steps, 1), 1),
-                'labelled_per_frame': round(labelled / max(args.steps, 1), 1),
+                             f'{args.dtype} encode, scores, vote, boxes [{args.box_mode} mode]) on synthetic {args.points}-pt frames, '
+                             f'{args.objects} objects (BASELINE config 3 shape, 4 views), ONE sequence of {frames_total} frames sharded '
+                             f'{world}-way in contiguous blocks' + (f', ground state by {args.ground_handoff}' if world > 1 else '') +
+                             ', one all-gather of the score matrices'),
+                'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,
+                'clusters_per_frame': round(clusters / max(K, 1), 1),
+                'crops_per_frame': round(crops / max(K, 1), 1),
+                'labelled_per_frame': round(labelled / max(K, 1), 1),
                 'weights': pipe.clip.weights_source, 'parallelism': f'frame-sharded x{world}', 'frames_in_flight_per_gpu': inflight,
+                'box_mode': args.box_mode,
             },
             'roofline': {
-                'kernel': 'k_gemm_f16_pp64 (every ViT projection GEMM: in_proj, out_proj, c_fc, c_proj, patch embedding)',
+                'kernel': f'{DOMINANT_KERNEL} (every ViT projection GEMM: in_proj, out_proj, c_fc, c_proj, patch embedding)',
                 'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)',
-                'method': 'HIP event pairs on the launch stream around every k_gemm_f16_pp64 launch, sequential pass (1 frame in flight) of the same frames right after the timed region',
+                'traffic_source': traffic_src,
+                'method': f'HIP event pairs on the launch stream around every {DOMINANT_KERNEL} launch, sequential pass (1 frame in flight) of the same frames right after the timed region',
                 'launches': launches, 'avg_launch_us': round(1000.0 * gemm_ms / max(launches, 1), 2),
                 'algorithmic_flops_per_launch': round(gemm_flops / max(launches, 1)),
-                'gemm_ms_per_frame': round(gemm_ms / max(min(4, args.steps), 1), 3),
-                'all_projection_gemms': {'kernels': 'k_gemm_f16_pp64 (+ k_gemm_f16_pp16 / k_gemm_f16 for shapes it does not take: none in ViT-B/16)', 'launches': all_launches,
+                'gemm_ms_per_frame': round(gemm_ms / max(n_pass, 1), 3),
+                'all_projection_gemms': {'launches': all_launches,
                                          'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
-                                         'ms_per_frame': round(all_ms / max(min(4, args.steps), 1), 3)},
+                                         'ms_per_frame': round(all_ms / max(n_pass, 1), 3)},
             },
         }
         if args.stage_times:
-            out['stage_ms_per_frame'] = {k: round(1000.0 * v / args.steps, 3) for k, v in stage.items()}
-        # the two extra passes must never cost the metric line: failures are reported inside the JSON
-        try:
-            if world == 1 and not args.no_sequence_pass and not args.stage_times:
-                # additional information, not the metric: the reference's DEFAULT stage order (preprocessing.yaml:50-68 -- entropy
-                # scores over a 15-frame window + two-frame 5-D clustering) on one coherent synthetic sequence
-                n_seq = max(48, args.steps)
+            out['stage_ms_per_frame'] = {k: round(1000.0 * v / K, 3) for k, v in stage.items()}
+        extras = world == 1 and not args.no_extras and not args.stage_times
+
+        def block(name, fn):
+            """An information block must never cost the metric line: failures are reported inside the JSON."""
+            try:
+                t0 = time.perf_counter()
+                out[name] = fn()
+                if isinstance(out[name], dict):
+                    out[name]['block_seconds'] = round(time.perf_counter() - t0, 1)
+            except Exception as e:          # noqa: BLE001
+                out[name] = {'error': f'{type(e).__name__}: {e}'}
+
+        def other_shape(points, objects, views, steps, box_mode=None):
+            p2 = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=views, max_points=points + 1024, clip_model_path='/nonexistent',
+                                     clip=pipe.clip, box_mode=box_mode or args.box_mode)
+            fr = frames if points == args.points and objects == args.objects else \
+                [p2.upload(synthetic.make_frame(501 + i, points, n_objects=objects)) for i in range(n_distinct)]
+            p2.new_sequence()
+            w2 = max(inflight, 2)
+            p2.process_frames([fr[i % n_distinct] for i in range(w2)], [poses[i] for i in range(w2)], poses[0], n_workers=inflight)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = p2.process_frames([fr[i % n_distinct] for i in range(steps)], [poses[W + i] for i in range(steps)], poses[0], n_workers=inflight)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            return dt, res
+
+        if extras:
+            def box_modes():
+                other = 'fast' if args.box_mode == 'reference' else 'reference'
+                dt, res = other_shape(args.points, args.objects, args.views, K, box_mode=other)
+                n = differ = 0
+                for (fa, _, _), (fb, _, _) in zip(outs, res):
+                    if fa.boxes is None or fb.boxes is None:
+                        continue
+                    rows = np.flatnonzero(fa.valid)
+                    a, b = fa.boxes[rows], fb.boxes[rows]
+                    n += len(rows)
+                    differ += int((np.abs(a[:, 3] * a[:, 4] - b[:, 3] * b[:, 4]) > 2e-4 * np.maximum(1.0, a[:, 3] * a[:, 4])).sum())
+                return {args.box_mode: {'value': round(value, 3), 'unit': 'frames/s'}, other: {'value': round(K / dt, 3), 'unit': 'frames/s'},
+                        'boxes_compared': n, 'boxes_that_differ': differ,
+                        'note': "same frames, same steps; 'reference' = the reference's boxes (qhull vertex order, closing hull edge dropped: "
+                                "host qhull on the worker threads), 'fast' = GPU hull + rectangle over all edges; a box differs when its "
+                                'footprint area differs by more than 2e-4 relative'}
+            block('box_modes', box_modes)
+
+            def shape_block(points, objects, views, cfg_name):
+                def fn():
+                    dt, res = other_shape(points, objects, views, K)
+                    return {'value': round(K / dt, 3), 'unit': 'frames/s', 'steps': K, 'points_per_frame': points, 'objects': objects, 'views': views,
+                            'clusters_per_frame': round(sum(r[0].n_detections for r in res) / K, 1),
+                            'crops_per_frame': round(sum(r[2].shape[0] for r in res) / K, 1), 'workload': cfg_name}
+                return fn
+            block('views6', shape_block(args.points, args.objects, 6, 'BASELINE config 3 as written: 150k points, 6 rendered views'))
+            block('dense200k', shape_block(200_000, 120, args.views, 'BASELINE config 5 shape: dense 200k-point frames, ~120 objects, fp16 ViT'))
+        if world == 1 and not args.no_sequence_pass and not args.stage_times:
+            def default_config_mode():
+                # the reference's DEFAULT stage order (preprocessing.yaml:50-68 -- entropy scores over a 15-frame window + two-frame
+                # 5-D clustering, SURVEY 8f N1) on one coherent synthetic sequence, as a library call
+                n_seq = max(48, K)
                 sframes, sposes = synthetic.make_sequence(seed=0, n_frames=n_seq, n_points=args.points, n_objects=args.objects)
                 sframes = [pipe.upload(f) for f in sframes]
                 pipe.process_sequence(sframes[:4], sposes[:4], sposes[0], n_workers=inflight)
@@ -235,17 +380,45 @@ def main():
                 sres = pipe.process_sequence(sframes, sposes, sposes[0], n_workers=inflight)
                 torch.cuda.synchronize()
                 ts = time.perf_counter() - ts
-                out['default_config_mode'] = {
-                    'value': round(n_seq / ts, 3), 'unit': 'frames/s', 'frames': n_seq,
-                    'workload': ('mask_ground_points -> calculate_entropy_scores (15-frame window, skip 1) -> spatial_clustering n_frames=2 '
-                                 '(5-D HDBSCAN + nearest-label transfer) -> filter -> classification -> boxes on one coherent '
-                                 f'synthetic sequence of {n_seq} frames x {args.points} points'),
-                    'labelled_per_frame': round(sum(len(r[1]['name']) for r in sres) / n_seq, 1),
-                    'moving_clusters_per_frame': round(sum(int((~r[0].static).sum()) for r in sres) / n_seq, 1)}
-            if world == 1 and not args.no_cpu_baseline:
-                out['cpu_baseline'] = cpu_baseline()
-        except Exception as e:          # noqa: BLE001
-            out.setdefault('extras_error', f'{type(e).__name__}: {e}')
+                return {'value': round(n_seq / ts, 3), 'unit': 'frames/s', 'frames': n_seq,
+                        'workload': ('mask_ground_points -> calculate_entropy_scores (15-frame window, skip 1) -> spatial_clustering n_frames=2 '
+                                     '(5-D HDBSCAN + nearest-label transfer) -> filter -> classification -> boxes on one coherent '
+                                     f'synthetic sequence of {n_seq} frames x {args.points} points'),
+                        'labelled_per_frame': round(sum(len(r[1]['name']) for r in sres) / n_seq, 1),
+                        'moving_clusters_per_frame': round(sum(int((~r[0].static).sum()) for r in sres) / n_seq, 1)}
+            block('default_config_mode', default_config_mode)
+        if extras and args.cli_frames > 0:
+            def cli_mode():
+                # the entry point itself (north_star's boundary): tools/preprocess_data.py preprocessor=waymo, default stage list
+                import tempfile
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import preprocess_data
+                import logging
+                with tempfile.TemporaryDirectory() as root:
+                    ovr = ['preprocessor=waymo', f'dataset.DATA_PATH={root}', f'dataset.SYNTHETIC.frames_per_sequence={args.cli_frames}',
+                           f'dataset.SYNTHETIC.points_per_frame={args.points}', f'dataset.SYNTHETIC.objects_per_frame={args.objects}',
+                           'dataset.SYNTHETIC.n_sequences=1', 'end_sequence=0', f'device.max_points={args.points + 1024}',
+                           f'device.frames_in_flight={inflight}', 'paths.clip_model=/nonexistent', f'device.box_mode={args.box_mode}']
+                    logging.disable(logging.INFO)
+                    try:
+                        t0 = time.perf_counter()
+                        preprocess_data.main(ovr)
+                        total = time.perf_counter() - t0
+                    finally:
+                        logging.disable(logging.NOTSET)
+                seq = preprocess_data.LAST_RUN['sequences'][0]
+                return {'value': round(seq['frames'] / seq['seconds'], 3), 'unit': 'frames/s', 'frames': seq['frames'],
+                        'ms_per_frame': round(1000.0 * seq['seconds'] / seq['frames'], 2),
+                        'stage_ms_per_frame': {k: round(v, 2) for k, v in seq['stage_ms_per_frame'].items()},
+                        'whole_command_seconds': round(total, 1),
+                        'workload': (f'tools/preprocess_data.py preprocessor=waymo on ONE coherent synthetic sequence of {seq["frames"]} frames x '
+                                     f'{args.points} points, the reference\'s default 9-stage pipeline_active (ground, entropy scores, two-frame '
+                                     'clustering, filters, tracking, classification, boxes, label propagation, evaluate_sequence); clock from '
+                                     '"sequence selected" to "both pickle families written"; whole_command_seconds adds start-up, the synthetic '
+                                     'generator and the AP evaluation over the generator\'s ground truth')}
+            block('cli_mode', cli_mode)
+        if world == 1 and not args.no_cpu_baseline:
+            block('cpu_baseline', cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

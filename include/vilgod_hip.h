@@ -99,26 +99,10 @@ int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream);
 
-/* development aid: the f16 GEMM kernels by number, bias epilogue (k_gemm_f16: 0, ablations 1 no in-loop DMA, 2 DMA only,
- * 3 no epilogue; k_gemm_f16_pp (32x32x16, K-step 32): 22, 20 two phases per K-step, 21/23 five stages; k_gemm_f16_pp16: 30;
- * k_gemm_f16_pp64, the production kernel: 32) */
-int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
-                    void* stream);
-
-/* development aid: k_gemm_f16_pp (var 20..23) and k_gemm_f16_pp64 (var 32 +bias, 33 +bias QuickGELU, 34 fp32 residual with d_C = the
- * float [M,N] stream, 35 fp16 residual with d_C = the half [M,N] stream) with per-wave cycle stamps.  d_trace receives, per
- * (workgroup, wave), eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, prologue + epilogue
- * cycles, LOAD-segment cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks.  Variants 32..35 append, after those
- * 64 * n_workgroups values, eight int64 per workgroup: entry and exit time (100-MHz ticks), XCC id << 32 | HW_ID, prologue
- * cycles, epilogue cycles, 1 -- size d_trace for 72 * (M/256) * (N/256) values (tools/bench_gemm_tiles.py). */
-int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
-                  int K, int ldc, void* stream);
-
-/* development aid: the fp16 attention kernel of the tower alone (model.py:175-187 via nn.MultiheadAttention): d_qkv fp16 [n_crops*T, ld] with
- * q | k | v at column offsets 0 | W | 2W, d_out fp16 [n_crops*T, W].  With d_trace != NULL the traced build runs and writes, per
- * (workgroup of the persistent grid min(n_crops*heads, 256), wave 0..6), eight int64 cycle sums: staging + barrier, next-item load
- * issue, S^T MFMA issue, max pass, exp pass, P/V^T/O^T issue, output, end barrier. */
-int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, int64_t* d_trace, void* stream);
+/* The fp16 attention kernel of the tower alone (model.py:175-187 via nn.MultiheadAttention): d_qkv fp16 [n_crops*T, ld] with
+ * q | k | v at column offsets 0 | W | 2W (what in_proj writes), d_out fp16 [n_crops*T, W] = softmax(q k^T / 8) v per (crop, head).
+ * Exposed so that the kernel can be unit-tested against a plain fp32 attention. */
+int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, void* stream);
 
 /* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
  * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */

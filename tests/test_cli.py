@@ -23,6 +23,29 @@ SINGLE_STAGES = ['mask_ground_points', 'spatial_clustering', 'filter_detections'
                  'evaluate_sequence']
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return str(s.getsockname()[1])
+
+
+def _wait_all(procs, timeout=600):
+    """Wait for all ranks; when one exits non-zero the others would wait in a collective forever: end them (by PID)."""
+    import time
+    t0 = time.time()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() - t0 > timeout:
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait(timeout=30)
+
+
 def _load(root, seq='synthetic_train_0000', stage_list=DEFAULT_STAGES):
     stages = '_'.join(stage_list)
     with open(f'{root}/preprocessed_data/results/vilgod_mi355x/{stages}/{seq}.pkl', 'rb') as f:
@@ -92,14 +115,13 @@ def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
     r = subprocess.run([sys.executable, cli, 'preprocessor=waymo', f'dataset.DATA_PATH={root1}'] + OVR,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29544', WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
     # the ranks log to files: with pipes, reading one rank's output while the other's pipe fills up would stall a collective
     logs = [open(tmp_path / f'rank{k}.log', 'w') for k in range(2)]
     procs = [subprocess.Popen([sys.executable, cli, 'preprocessor=waymo', f'dataset.DATA_PATH={root2}'] + OVR,
                               env=dict(env, RANK=str(k), LOCAL_RANK='0'), stdout=logs[k], stderr=subprocess.STDOUT, text=True)
              for k in range(2)]
-    for p in procs:
-        p.wait(timeout=600)
+    _wait_all(procs)
     for k, p in enumerate(procs):
         logs[k].close()
         assert p.returncode == 0, open(tmp_path / f'rank{k}.log').read()[-3000:]
@@ -124,7 +146,7 @@ def test_bench_two_ranks_on_one_gpu(cuda):
     """bench.py's N > 1 path (barriers, padded all-gather of the score matrices, max-over-ranks timing, one JSON line from
     rank 0) with two processes sharing the single GPU of the test box over gloo; the driver's multi-GPU runs use RCCL."""
     import json
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--points', '30000',
            '--objects', '12', '--no-cpu-baseline', '--no-sequence-pass']
     import tempfile
@@ -132,8 +154,7 @@ def test_bench_two_ranks_on_one_gpu(cuda):
     files = [(open(f'{tmp}/o{k}', 'w'), open(f'{tmp}/e{k}', 'w')) for k in range(2)]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(k), LOCAL_RANK='0'), stdout=files[k][0], stderr=files[k][1], text=True)
              for k in range(2)]
-    for p in procs:
-        p.wait(timeout=600)
+    _wait_all(procs)
     for fo, fe in files:
         fo.close(); fe.close()
     outs = [(open(f'{tmp}/o{k}').read(), open(f'{tmp}/e{k}').read()) for k in range(2)]

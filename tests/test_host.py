@@ -84,15 +84,38 @@ WORKER = textwrap.dedent('''
     # empty shard on one rank
     got = vdist.gather_scores(local if rank == 0 else {}, 24, torch.device('cpu'))
     assert sorted(got) == vdist.shard_frames(5, 0, 2)
+    # ground-state hand-off down the rank chain (vilgod_amd/dist.py): rank 1 receives what rank 0 exported AFTER its block
+    from vilgod_amd._lib import lib
+    nbytes = int(lib.vg_ground_state_bytes())
+    class FakeGround:
+        def __init__(self): self.state, self.ran = None, False
+        def export_state(self):
+            assert self.ran
+            return bytes([7 + rank]) * nbytes
+        def set_state(self, blob): self.state = bytes(blob)
+    fg = FakeGround()
+    def block():
+        assert (fg.state is not None) == (rank > 0)
+        fg.ran = True
+        return rank
+    assert vdist.chain_ground_state(fg, block) == rank
+    assert fg.state == (bytes([7]) * nbytes if rank == 1 else None)
     dist.barrier()
     print('rank', rank, 'ok')
 ''')
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return str(s.getsockname()[1])
+
+
 def test_two_rank_gather_gloo(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', WORLD_SIZE='2', OMP_NUM_THREADS='1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2', OMP_NUM_THREADS='1')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]

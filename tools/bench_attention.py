@@ -1,7 +1,9 @@
 """k_attention_f16 alone: time per launch and the per-wave phase split (vg_attention_trace)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vilgod_amd._lib import lib, ptr, stream_ptr, check
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dev'))
+from devlib import lib, ptr, stream_ptr, check        # the development build (tools/dev)
 dev = torch.device('cuda:0')
 n, T, W, H = int(os.environ.get('CROPS', '325')), 197, 768, 12
 ld = 3 * W + 64

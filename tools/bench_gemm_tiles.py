@@ -3,7 +3,9 @@ prologue (entry -> first MMA), main loop, epilogue, and the dead time on a CU be
 (s_memrealtime stamps, 10 ns units, grouped by XCC / SE / CU id)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vilgod_amd._lib import lib, ptr, stream_ptr, check
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dev'))
+from devlib import lib, ptr, stream_ptr, check        # the development build (tools/dev)
 dev = torch.device('cuda:0')
 M = (int(os.environ.get('CROPS', '325')) * 197 + 255) // 256 * 256
 for var, N, K in [(32, 2304, 768), (33, 3072, 768), (34, 768, 768), (34, 768, 3072), (35, 768, 768), (35, 768, 3072)]:

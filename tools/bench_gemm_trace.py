@@ -1,7 +1,9 @@
 """Per-wave cycle breakdown of the tiled GEMM variants (main loop / waiting for the DMA / barrier / epilogue)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vilgod_amd._lib import lib, ptr, stream_ptr, check
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dev'))
+from devlib import lib, ptr, stream_ptr, check        # the development build (tools/dev)
 dev = torch.device('cuda:0')
 M = (240 * 197 + 255) // 256 * 256
 vars_ = [int(v) for v in (sys.argv[1:] or ['22'])]

@@ -1,6 +1,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vilgod_amd._lib import lib, ptr, stream_ptr, check
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dev'))
+from devlib import lib, ptr, stream_ptr, check        # the development build (tools/dev)
 dev = torch.device('cuda:0')
 M = (int(os.environ.get("CROPS", "240")) * 197 + 255) // 256 * 256
 vars_ = [int(v) for v in (sys.argv[1:] or ['0', '22', '30', '32'])]      # k_gemm_f16, _pp (32x32), _pp16, _pp64

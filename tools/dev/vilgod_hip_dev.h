@@ -1,0 +1,35 @@
+/* Development entry points of libvilgod_hip_dev.so (python -m vilgod_amd.build --dev: the product sources compiled with -DVG_DEV).
+ * NOT part of the product ABI (include/vilgod_hip.h): ablation variants and cycle-stamp builds of the GEMM / attention kernels and
+ * the superseded GEMM kernels they are compared with, used by tools/bench_gemm_*.py and tools/bench_attention.py only. */
+#ifndef VILGOD_HIP_DEV_H
+#define VILGOD_HIP_DEV_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* development aid: the f16 GEMM kernels by number, bias epilogue (k_gemm_f16: 0, ablations 1 no in-loop DMA, 2 DMA only,
+ * 3 no epilogue; k_gemm_f16_pp (32x32x16, K-step 32): 22, 20 two phases per K-step, 21/23 five stages; k_gemm_f16_pp16: 30;
+ * k_gemm_f16_pp64, the production kernel: 32) */
+int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
+                    void* stream);
+
+/* development aid: k_gemm_f16_pp (var 20..23) and k_gemm_f16_pp64 (var 32 +bias, 33 +bias QuickGELU, 34 fp32 residual with d_C = the
+ * float [M,N] stream, 35 fp16 residual with d_C = the half [M,N] stream) with per-wave cycle stamps.  d_trace receives, per
+ * (workgroup, wave), eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, prologue + epilogue
+ * cycles, LOAD-segment cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks.  Variants 32..35 append, after those
+ * 64 * n_workgroups values, eight int64 per workgroup: entry and exit time (100-MHz ticks), XCC id << 32 | HW_ID, prologue
+ * cycles, epilogue cycles, 1 -- size d_trace for 72 * (M/256) * (N/256) values (tools/bench_gemm_tiles.py). */
+int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
+                  int K, int ldc, void* stream);
+
+/* vg_attention (include/vilgod_hip.h) with cycle stamps: with d_trace != NULL the traced build runs and writes, per
+ * (workgroup of the persistent grid min(n_crops*heads, 256), wave 0..6), eight int64 cycle sums: staging + barrier, next-item load
+ * issue, S^T MFMA issue, max pass, exp pass, P/V^T/O^T issue, output, end barrier. */
+int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, int64_t* d_trace, void* stream);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -16,6 +16,7 @@ import os
 import pickle
 import random
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -27,6 +28,11 @@ from vilgod_amd import config as vconfig          # noqa: E402
 from vilgod_amd import dist as vdist              # noqa: E402
 
 
+# timings of the last main() call (bench.py's cli_mode block reads them): per sequence wall seconds from "sequence selected" to
+# "both pickle families written" and the per-stage ms per frame the dispatcher measured
+LAST_RUN = {'sequences': []}
+
+
 def set_random_seed(seed):
     """src/utils/common_utils.py:13-19."""
     random.seed(seed)
@@ -36,6 +42,7 @@ def set_random_seed(seed):
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    LAST_RUN['sequences'] = []
     logging.basicConfig(level=logging.INFO, format='[%(asctime)s][%(levelname)s] - %(message)s', stream=sys.stdout)
     logger = logging.getLogger('preprocess_data')
     cfg = vconfig.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs'), 'preprocessing', argv)
@@ -62,7 +69,8 @@ def main(argv=None):
     pipeline = PseudoLabelPipeline(cfg.preprocessor, device=f'cuda:{torch.cuda.current_device()}',
                                    vit_dtype=dev.get('vit_dtype', 'f16'), n_views=dev.get('n_views', 4),
                                    max_points=dev.get('max_points', 300_000), clip_model_path=cfg.paths.clip_model,
-                                   min_range=ga['min_range'], z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666))
+                                   min_range=ga['min_range'], z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666),
+                                   box_mode=dev.get('box_mode', 'reference'), box_workers=dev.get('box_workers', 4))
     logger.info(f'CLIP weights: {pipeline.clip.weights_source}')
 
     result_path = Path(cfg.paths.results) / cfg.results_folder / '_'.join(cfg.pipeline_active)
@@ -91,6 +99,9 @@ def main(argv=None):
             with indices_file.open('rb') as f:
                 indices.extend(pickle.load(f))
             continue
+        if hasattr(dataset, 'prefetch_sequence'):
+            dataset.prefetch_sequence()                 # synthetic data: generate the sequence before the clock starts (stands for disk IO)
+        t_seq = time.perf_counter()
         zsd = ZeroShotDetector(dataset, sequence_name, cfg=cfg, logger=logger, pipeline=pipeline)
         zsd.process()
         detection_results.extend(zsd.detection_3d_result_list)
@@ -106,6 +117,9 @@ def main(argv=None):
                 ids = [info.get('frame_id', f'{sequence_name}_{i:03d}') for i, info in enumerate(dataset.sequence_infos)]
                 export.write_sequence(cfg.paths.pseudo_label, sequence_name, zsd.detection_3d_result_list, ids,
                                       dataset.sequence_indices, class_names=dataset.class_names)
+        torch.cuda.synchronize()
+        LAST_RUN['sequences'].append({'name': sequence_name, 'frames': dataset.sequence_length, 'world_size': world,
+                                      'seconds': time.perf_counter() - t_seq, 'stage_ms_per_frame': dict(zsd.stage_ms)})
         del zsd
         gc.collect()
         torch.cuda.empty_cache()

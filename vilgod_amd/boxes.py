@@ -12,8 +12,8 @@ Two modes, selected by `PseudoLabelPipeline(box_mode=...)` / `device.box_mode`:
               expression sequence (numpy's float32 `arctan2` / `cos` are SIMD routines whose last bit is host dependent, so only
               the same calls reproduce the reference's float32 boxes).  The per-point work stays on the GPU: cluster membership
               and packing, z extent (`vg_cluster_filter` statistics) and the validity filters; this module touches each
-              cluster's xy points once, on the worker thread of the frame, while the GPU classifies the frame's crops (the
-              boxes do not depend on the classes).
+              cluster's xy points once, in a helper process (see `submit_reference_boxes`), while the GPU classifies the
+              frame's crops (the boxes do not depend on the classes).
   'fast'      `vg_cluster_boxes` (csrc/segment.hip k_cluster_box): exact-predicate hull + rectangle over ALL hull edges in
               float64 on the GPU.  Identical to the reference whenever the best direction is not the dropped closing edge
               (~85 % of clusters), otherwise its rectangle is the smaller one.
@@ -68,6 +68,132 @@ def box_from_rectangle(corners, rz, zmin, zmax):
         rz += np.pi / 2
     height = zmax - zmin
     return np.array([c[0], c[1], zmin + height / 2, l, w, height + 0.3, rz])
+
+
+def reference_boxes_packed(xy_packed, seg, zmin, zmax):
+    """Boxes of clusters whose xy points are already packed cluster after cluster ([P,2] float32, seg offsets)."""
+    C = len(seg) - 1
+    out = np.empty((C, 7))
+    for c in range(C):
+        corners, rz, _ = minimum_bounding_rectangle(xy_packed[seg[c]:seg[c + 1]])
+        out[c] = box_from_rectangle(corners, rz, zmin[c], zmax[c])
+    return out
+
+
+# ---- helper processes ------------------------------------------------------------------------------------------------
+# The loop above is ~100 us of interpreter time per cluster (scipy's ConvexHull object + ~25 tiny numpy calls), i.e. ~9 ms per
+# 150k-point frame -- in a process whose worker threads share one interpreter lock with the code that launches the GPU
+# kernels of six frames in flight (measured: 53 -> 40 frames/s when it ran in the frames' threads).  It therefore runs in a
+# small pool of helper PROCESSES (`python -m vilgod_amd.box_worker`: numpy / scipy only, never the GPU runtime); a frame's
+# packed xy points (~0.3 MB) travel over a pipe, the frame's worker thread collects the boxes after it has queued the frame's
+# classification.
+class BoxWorkerPool:
+    def __init__(self, n_procs):
+        import os
+        import queue
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
+        self.procs = [subprocess.Popen([sys.executable, '-m', 'vilgod_amd.box_worker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                       env=env, cwd=root) for _ in range(int(n_procs))]
+        self.idle = queue.Queue()
+        for p in self.procs:
+            self.idle.put(p)
+
+    def submit(self, *req):
+        import pickle
+        import struct
+        p = self.idle.get()                      # blocks while every helper is busy
+        blob = pickle.dumps(req, protocol=pickle.HIGHEST_PROTOCOL)
+        try:
+            p.stdin.write(struct.pack('<q', len(blob)))
+            p.stdin.write(blob)
+            p.stdin.flush()
+        except Exception:
+            self.idle.put(p)
+            raise
+        return _Pending(self, p)
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:           # noqa: BLE001
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:           # noqa: BLE001
+                p.kill()
+        self.procs = []
+
+
+class _Pending:
+    def __init__(self, pool, proc):
+        self.pool, self.proc, self._v = pool, proc, None
+
+    def result(self):
+        import pickle
+        import struct
+        if self.proc is not None:
+            p, self.proc = self.proc, None
+            try:
+                head = p.stdout.read(8)
+                if len(head) < 8:
+                    raise RuntimeError('box helper process ended unexpectedly')
+                (n,) = struct.unpack('<q', head)
+                status, val = pickle.loads(p.stdout.read(n))
+            finally:
+                self.pool.idle.put(p)
+            if status != 'ok':
+                raise RuntimeError(f'box helper process: {val}')
+            self._v = val
+        return self._v
+
+
+class _Done:
+    def __init__(self, value):
+        self._v = value
+
+    def result(self):
+        return self._v
+
+
+_POOL = None
+_POOL_LOCK = None
+
+
+def _pool(n_procs):
+    global _POOL, _POOL_LOCK
+    import threading
+    if _POOL_LOCK is None:
+        _POOL_LOCK = threading.Lock()
+    with _POOL_LOCK:
+        if _POOL is None:
+            import atexit
+            _POOL = BoxWorkerPool(n_procs)
+            atexit.register(shutdown_pool)
+    return _POOL
+
+
+def shutdown_pool():
+    global _POOL
+    if _POOL is not None:
+        _POOL.close()
+        _POOL = None
+
+
+def submit_reference_boxes(xy_host, index, seg, zmin, zmax, n_procs=4):
+    """-> an object with .result() -> [C,7] boxes.  n_procs = 0 computes in the calling thread."""
+    xy_packed = np.ascontiguousarray(xy_host[index, :2], dtype=np.float32)
+    seg = np.asarray(seg, dtype=np.int64)
+    zmin = np.asarray(zmin, dtype=np.float32).copy()
+    zmax = np.asarray(zmax, dtype=np.float32).copy()
+    if n_procs <= 0 or len(seg) <= 1:
+        return _Done(reference_boxes_packed(xy_packed, seg, zmin, zmax))
+    return _pool(n_procs).submit(xy_packed, seg, zmin, zmax)
 
 
 def reference_boxes(xy_host, index, seg, zmin, zmax):

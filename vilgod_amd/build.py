@@ -2,6 +2,8 @@
 
     python -m vilgod_amd.build            # incremental
     python -m vilgod_amd.build --force
+    python -m vilgod_amd.build --dev      # libvilgod_hip_dev.so: the same sources with -DVG_DEV (ablation / trace entry points
+                                          # of tools/dev/vilgod_hip_dev.h and the superseded kernels; tools/ only)
 
 The .so lands next to this file so it travels with the repository snapshot to the GPU box; it
 is git-ignored.  No torch involvement: plain `hipcc -shared`.
@@ -47,7 +49,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, dev=False):
+    OBJ = os.path.join(HERE, 'csrc', '_obj_dev' if dev else '_obj')
+    LIB = os.path.join(HERE, 'libvilgod_hip_dev.so' if dev else 'libvilgod_hip.so')
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
@@ -63,7 +67,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _stale(obj, [path] + headers):
             lang = ['-x', 'hip'] if src.endswith('.cpp') else []
-            jobs.append((src, [hipcc] + COMMON + extra + lang + ['-c', path, '-o', obj]))
+            jobs.append((src, [hipcc] + COMMON + (['-DVG_DEV'] if dev else []) + extra + lang + ['-c', path, '-o', obj]))
 
     def run(job):
         src, cmd = job
@@ -89,5 +93,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB)
+    print(build(force='--force' in sys.argv, dev='--dev' in sys.argv))

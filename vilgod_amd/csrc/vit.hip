@@ -206,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_f16(const f16* __restrict__ X, 
     }
 }
 
+#ifdef VG_DEV      // superseded K-step-32 ping-pong kernel: kept for the cycle-stamp tools (tools/dev), not in the product library
 // ---------------------------------------------------------------------------------------------
 // Ping-pong GEMM: 256 x 256 x 32 tiles, 8 waves = two groups of four (group = 128-row half of the tile, one wave of each
 // group per SIMD), each wave 128 (m) x 64 (n).  A PHASE is one k16 sub-step of one wave: LOAD segment (6 ds_read_b128 for
@@ -487,6 +488,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp(const f16* __restrict__ 
         }
     }
 }
+
+#endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
 // fp32 parity-mode GEMM (VALU): 64x64 tile, 256 threads, 4x4 micro-tile, same epilogues.
@@ -1021,13 +1024,14 @@ static int gemm_chunk_tiles(int N, int K) {
     return ntn / nchunks;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef VG_DEV      // K-step-32 predecessor of k_gemm_f16_pp64 (tools/dev only)
 // ---------------------------------------------------------------------------------------------
 // The same ping-pong schedule on v_mfma_f32_16x16x32_f16 (one MFMA spans the whole 32-wide K-step of a 16 x 16 block:
 // 32 MFMAs of 16 cycles per wave and K-step instead of 16 of 32).  MI355X_MICROARCH.md "DVFS give-back" item 7: on
 // random operands the 16x16x32 form holds a higher clock at equal cycles per FLOP.
 //   A operand (weight rows): lane l -> row l & 15, 16-byte K chunk l >> 4;  B operand (activation rows): the same.
 //   D: column (activation row m) = l & 15, rows (features n) = 4 (l >> 4) + r  -> a lane owns 4 consecutive n of one m.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int EPI, int STAGES>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
@@ -1188,6 +1192,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict_
         }
     }
 }
+
+#endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
 // K-step 64 (128-byte rows).  Measured with tools/micro/dma_rate.hip: LDS-DMA from L2-resident data streams at
@@ -1479,6 +1485,7 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
 }
 
 
+#ifdef VG_DEV
 template <int EPI, int STAGES>
 static int launch_gemm_pp16(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st) {
@@ -1517,13 +1524,15 @@ static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void
     return VG_OK;
 }
 
+#endif  // VG_DEV
+
 template <int EPI>
 static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
                        int N, int K, hipStream_t st, int ldc = 0) {
     if (ldc == 0) ldc = N;
     vg_vit* v = const_cast<vg_vit*>(cv);
     // f16 ViT shapes (N % 256 == 0, K >= 128) take the ping-pong kernel; k_gemm_f16 serves the remaining legal shapes.
-    const bool use_pp = v->dtype == 1 && N % 256 == 0 && K / GK >= 4 && !getenv("VG_GEMM_V4");
+    const bool use_pp = v->dtype == 1 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 2 && !getenv("VG_GEMM_V4");
     const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
     if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
     struct Closer {
@@ -1543,8 +1552,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
     if (v->dtype == 1) {
         if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
         if (use_pp) {
-            // K-step 64 / 128-byte rows when K allows it (every ViT-B/16 projection), else the K-step-32 kernel
-            if (K % 64 == 0 && K / 64 >= 2 && !getenv("VG_GEMM_PP16")) {
+            {
                 // experiment, off by default: persistent workgroups (one per CU walking its XCD's run of tiles) per epilogue kind,
                 // bit EPI of VG_GEMM_PERSIST.  Alone at M = 64256: in_proj (+bias) 271 -> 244 us, c_fc (GELU) and out_proj +-0,
                 // c_proj -3 %; inside the pipeline no measurable change (13.65-13.70 ms of GEMMs per frame either way): the next
@@ -1555,7 +1563,6 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                 }
                 return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
             }
-            return launch_gemm_pp16<EPI, 4>(X, Wt, bias, C, resid, M, N, K, ldc, st);
         }
         int nwg = (M / GBM) * (N / GBN);
         static bool attr_set = false;
@@ -1585,7 +1592,7 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     vg_vit* v = new vg_vit();
     v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
     v->out_dim = out_dim; v->dtype = dtype; v->T = T;
-    v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4") && !getenv("VG_GEMM_PP16");
+    v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
     *out = v;
     return VG_OK;
 }
@@ -1770,6 +1777,20 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     return VG_OK;
 }
 
+/* k_attention_f16 alone: softmax(q k^T / 8) v per (crop, head) on the padded qkv rows in_proj writes (model.py:175-187 via
+ * nn.MultiheadAttention); exposed so that the kernel can be unit-tested against a plain fp32 attention. */
+int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, void* stream) {
+    if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
+    const int items = n_crops * heads;
+    hipStream_t st = (hipStream_t)stream;
+    VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
+    hipLaunchKernelGGL((k_attention_f16<false>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)d_qkv, (f16*)d_out,
+                       T, W, heads, ld, items, (long long*)nullptr);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+#ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces
 /* ablation variants of the f16 GEMMs (development aid, epi 0 only): k_gemm_f16 var 0 = as shipped, 1 = no DMA inside the
  * K loop, 2 = DMA only (no LDS reads / MFMA), 3 = no epilogue; k_gemm_f16_pp var 22 = as shipped (4 stages, one phase per
  * K-step), 20 = two phases per K-step, 21 / 23 = 5 stages */
@@ -1831,6 +1852,8 @@ int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
+
+#endif  // VG_DEV
 
 /* C = X @ Wt^T (+ epilogue), exposed for unit tests / micro-benchmarks of the GEMM itself.
  * dtype 1: X,Wt f16, M%128==0, N%128==0, K%64==0; dtype 0: f32, M%64, N%64, K%16.

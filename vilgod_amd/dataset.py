@@ -67,6 +67,11 @@ class SyntheticDataset:
         self._generate()
         return self._frames[fnr]
 
+    def prefetch_sequence(self):
+        """Generate the current sequence now (tools/preprocess_data.py calls it before it starts the sequence clock)."""
+        if self.coherent:
+            self._generate()
+
     def _generate(self):
         """The coherent sequence and its ground truth (the generator's boxes in the OpenPCDet `annos` layout), once per sequence."""
         if self._frames is not None:

@@ -87,26 +87,40 @@ def gather_objects(obj):
     return out
 
 
+def _state_device(device=None):
+    import torch.distributed as dist
+    return torch.device('cpu') if dist.get_backend() == 'gloo' else (device or torch.device('cuda', torch.cuda.current_device()))
+
+
+def recv_ground_state(ground_model, device=None):
+    """Rank r > 0: wait for the Patchwork++ state after the last frame of rank r - 1's block and set it (point to point, ~131 KB)."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1 or rank == 0:
+        return
+    from ._lib import lib
+    buf = torch.empty(int(lib.vg_ground_state_bytes()), dtype=torch.uint8, device=_state_device(device))
+    dist.recv(buf, src=rank - 1)
+    ground_model.set_state(buf.cpu().numpy().tobytes())
+
+
+def send_ground_state(ground_model, device=None):
+    """Rank r < N - 1: export the state after this rank's last ground pass (synchronises the caller's stream) and send it on."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1 or rank == ws - 1:
+        return
+    blob = torch.frombuffer(bytearray(ground_model.export_state()), dtype=torch.uint8).to(_state_device(device))
+    dist.send(blob, dst=rank + 1)
+
+
 def chain_ground_state(ground_model, run_my_block, device=None):
     """Patchwork++'s adaptive state runs through the whole sequence (SURVEY 8e exception 1).  With contiguous frame blocks the
     state is HANDED from rank to rank instead of every rank replaying the frames before its block: rank r waits for the state
-    after frame start_r - 1 from rank r - 1 (point to point, ~131 KB), sets it, runs the ground stage over its OWN block
-    (`run_my_block()`), and passes the state on to rank r + 1 before it starts the heavy stages.  Same masks and same final
-    state as one sequential pass (tests/test_cli.py, tests/test_ground.py)."""
-    import torch.distributed as dist
-    rank, ws = world()
-    if ws == 1:
-        return run_my_block()
-    gloo = dist.get_backend() == 'gloo'
-    dev = torch.device('cpu') if gloo else (device or torch.device('cuda', torch.cuda.current_device()))
-    from ._lib import lib
-    nbytes = int(lib.vg_ground_state_bytes())
-    if rank > 0:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        dist.recv(buf, src=rank - 1)
-        ground_model.set_state(buf.cpu().numpy().tobytes())
+    after frame start_r - 1 from rank r - 1, sets it, runs the ground stage over its OWN block (`run_my_block()`), and passes
+    the state on to rank r + 1 before it starts the heavy stages.  Same masks and same final state as one sequential pass
+    (tests/test_cli.py, tests/test_ground.py)."""
+    recv_ground_state(ground_model, device)
     out = run_my_block()
-    if rank < ws - 1:
-        blob = torch.frombuffer(bytearray(ground_model.export_state()), dtype=torch.uint8).to(dev)
-        dist.send(blob, dst=rank + 1)
+    send_ground_state(ground_model, device)
     return out

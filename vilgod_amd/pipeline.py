@@ -61,7 +61,7 @@ def _get(cfg, key, default=None):
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
                  clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
-                 box_mode='reference'):
+                 box_mode='reference', box_workers=4):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -94,6 +94,7 @@ class PseudoLabelPipeline:
             raise ValueError("box_mode: 'reference' (the reference's boxes: qhull vertex order, closing edge dropped) or 'fast' "
                              "(GPU hull + rectangle over all edges)")
         self.box_mode = box_mode
+        self.box_workers = int(box_workers)      # helper processes for the host part of the reference box mode (0 = in the frame's thread)
         self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         self.timings = {}
@@ -144,10 +145,11 @@ class PseudoLabelPipeline:
         parts = [f.result() for f in futs]
         return [parts[i % n_workers][i // n_workers] for i in range(len(items))]
 
-    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0):
+    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0, after_ground=None):
         """Throughput mode: frames (list of CUDA/numpy point arrays) are processed with `n_workers` frames in flight,
         each on its own HIP stream with its own handles.  Ground segmentation is stateful across frames and runs in
         frame order on the caller's stream; everything else of a frame runs on a worker stream after an event wait.
+        `after_ground()` is called once all ground passes are queued, before the results are awaited.
         Returns [(FrameState, result dict, probs tensor)] in frame order."""
         workers = self._ensure_workers(n_workers)
         main = torch.cuda.current_stream(self.device)
@@ -168,6 +170,8 @@ class PseudoLabelPipeline:
             ev.record(main)
             w = workers[i % n_workers]
             futures.append(w.thread.submit(run, w, i, d_pts, mask, ev))
+        if after_ground is not None:
+            after_ground()             # every ground pass of the block is queued: e.g. hand the ground state to the next rank
         return [f.result() for f in futures]
 
     @staticmethod
@@ -324,13 +328,20 @@ class PseudoLabelPipeline:
             d_seg = torch.from_numpy(np.ascontiguousarray(seg, dtype=np.int32)).to(self.device)
         if self.box_mode == 'fast':
             return self.boxes(d_X, d_index, d_seg)[0].cpu().numpy()
-        from .boxes import reference_boxes
+        return self.fit_boxes_async(d_X, index, seg, d_index, d_seg, xy_host, zmin, zmax).result()
+
+    def fit_boxes_async(self, d_X, index, seg, d_index=None, d_seg=None, xy_host=None, zmin=None, zmax=None):
+        """Reference mode: start the host part (vilgod_amd/boxes.py) in a helper process; .result() -> [C,7] boxes."""
+        from .boxes import submit_reference_boxes
+        if d_index is None:
+            d_index = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32)).to(self.device)
+            d_seg = torch.from_numpy(np.ascontiguousarray(seg, dtype=np.int32)).to(self.device)
         if zmin is None:
             zmin, zmax = self.z_extent(d_X, d_index, d_seg)
         if xy_host is None:
             xy_host, ev = self.xy_to_host_async(d_X)
             ev.synchronize()
-        return reference_boxes(xy_host, index, seg, zmin, zmax)
+        return submit_reference_boxes(xy_host, index, seg, zmin, zmax, self.box_workers)
 
     # [F1]
     @staticmethod
@@ -476,16 +487,20 @@ class PseudoLabelPipeline:
         v_seg = np.r_[0, np.cumsum([len(p) for p in parts])].astype(np.int32)
         d_vindex = torch.from_numpy(v_index).to(self.device)
         d_vseg = torch.from_numpy(v_seg).to(self.device)
-        probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
+        box_fut = None
         if self.box_mode == 'reference':
-            # host part of the reference-exact box fit (vilgod_amd/boxes.py) while the GPU encodes the frame's crops
+            # host part of the reference-exact box fit (vilgod_amd/boxes.py) in a helper process, started before the frame's crops
+            # are queued (the boxes do not depend on the classes)
             st = stats.cpu().numpy()
             xy_ev.synchronize()
-            box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
-        else:
+            box_fut = self.fit_boxes_async(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
+        probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
+        if box_fut is None:
             box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg)
         top1 = top1.cpu().numpy()
         score = score.cpu().numpy()
+        if box_fut is not None:
+            box = box_fut.result()
         t0 = tick('classify+boxes', t0)
         V = self.projection.num_views
         nv = len(vrows)

@@ -49,7 +49,7 @@ class ZeroShotDetector:
                                            n_views=dev.get('n_views', 4), max_points=dev.get('max_points', 300_000),
                                            clip_model_path=cfg.paths.clip_model, min_range=ga['min_range'],
                                            z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666), clip=clip_model,
-                                           box_mode=dev.get('box_mode', 'reference'))
+                                           box_mode=dev.get('box_mode', 'reference'), box_workers=dev.get('box_workers', 4))
         self.pipe = pipeline
         self.sequence_data_dir_path = Path(cfg.paths.sequence_data)
         self.my_frames = vdist.shard_frames(self.lenght, self.rank, self.world_size)
@@ -59,6 +59,7 @@ class ZeroShotDetector:
         self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
         self.n_workers = int(dev.get('frames_in_flight', 6))
         self.sync_every_stage = bool(dev.get('sync_every_stage', False))
+        self.stage_ms = {}                               # stage name -> ms per (own) frame of the last process()
         self._dirty = False
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
         self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
@@ -187,14 +188,18 @@ class ZeroShotDetector:
                 t0 = time.perf_counter()
                 getattr(self, task_name)(**self.cfg.pipeline[available.index(task_name)]['args'])
                 torch.cuda.synchronize()
-                self.logger.info(f'  stage {task_name}: {1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1):.2f} ms per frame')
+                ms = 1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1)
+                self.stage_ms[task_name] = self.stage_ms.get(task_name, 0.0) + ms
+                self.logger.info(f'  stage {task_name}: {ms:.2f} ms per frame')
             else:
                 self.logger.warning(f'{task_name} NOT FOUND!!!')
         # the sequence-state pickle (zero_shot_detector.py:105-114): the reference rewrites it after every stage; here it is
         # written once per run unless device.sync_every_stage asks for the reference's per-stage files (same final content).
         # With several ranks it is written by rank 0 after the states were gathered, whatever stages ran.
         if self._dirty or self.world_size > 1:
+            t0 = time.perf_counter()
             self.sync_lidar_frames(final=True)
+            self.stage_ms['write_sequence_state'] = 1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1)
         self.logger.info(f'Finished processing sequence: {self.name}')
 
     # ---- stages ------------------------------------------------------------------------------------------
