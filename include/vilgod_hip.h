@@ -250,6 +250,12 @@ int vg_cluster_filter(const float* d_points, int stride, const int32_t* d_index,
 int vg_cluster_boxes(const float* d_points, int stride, const int32_t* d_index, const int32_t* d_seg_off, int n_clusters,
                      double* d_box7, float* d_aux3, void* stream);
 
+/* Detection.cluster_mass_center (src/dataclass/objects.py:121-123: np.median(cluster_points, axis=0)) of every packed cluster over the
+ * first n_cols columns of the point rows (the tracker reads all five: src/vilgod/tracker.py:52-59, objects.py:238-306).  Exact
+ * order statistics; an even count gives the float32 mean of the two middle values like np.median.  d_median: [n_clusters, n_cols] f32. */
+int vg_cluster_medians(const float* d_points, int stride, int n_cols, const int32_t* d_index, const int32_t* d_seg_off, int n_clusters,
+                       float* d_median, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,3 +252,25 @@ def test_hip_reference_box_mode_matches_reference_boxes(cuda, golden):
     print(f'reference box mode: {len(idxs)} boxes within {tol:g} of the reference (host numpy reproduces the golden: {host_ok}); '
           f'fast mode equals the reference in {int(same.sum())}/{len(idxs)}')
     assert (fast[:, 3] * fast[:, 4] <= g['boxes_ref'][:, 3] * g['boxes_ref'][:, 4] * (1 + 1e-4) + 1e-6).all()   # never a larger rectangle
+
+
+@pytest.mark.gpu
+def test_hip_cluster_medians_equal_numpy(cuda):
+    """vg_cluster_medians == np.median(cluster_points, axis=0) (Detection.cluster_mass_center, objects.py:121-123) bit for bit:
+    odd and even sizes, duplicates, all five columns, one-point and large clusters."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    rng = np.random.default_rng(4)
+    sizes = [1, 2, 3, 10, 11, 64, 257, 1000, 4097, 9000]
+    X = rng.normal(size=(sum(sizes) + 500, 5)).astype(np.float32) * [30, 30, 2, 0.3, 0]
+    X[:2000, 0] = np.round(X[:2000, 0])                       # ties
+    perm = rng.permutation(len(X))
+    idxs, o = [], 0
+    for n in sizes:
+        idxs.append(np.sort(perm[o:o + n]))
+        o += n
+    index = np.concatenate(idxs).astype(np.int32)
+    seg = np.r_[0, np.cumsum(sizes)].astype(np.int32)
+    pipe = PseudoLabelPipeline(device=cuda, max_points=len(X) + 16, clip_model_path='/nonexistent')
+    got = pipe.cluster_medians(torch.from_numpy(X).to(cuda), torch.from_numpy(index).to(cuda), torch.from_numpy(seg).to(cuda)).cpu().numpy()
+    want = np.stack([np.median(X[i], axis=0) for i in idxs])
+    assert got.dtype == np.float32 and np.array_equal(got, want)

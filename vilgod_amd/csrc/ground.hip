@@ -449,6 +449,10 @@ __device__ void pw_mean_stdev(const double* v, int head, int cnt, double& mean, 
 __global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__ P, const PwGeom* __restrict__ G,
                                                   PwState* __restrict__ S, PwPatchRec* __restrict__ recs) {
     const int lane = threadIdx.x;
+    __shared__ double sh_rf[4][64];          // per near ring: the flatness values it appends to `ringwise_flatness`
+    __shared__ int sh_nrf[4], sh_ncand[4];
+    if (lane < 4) { sh_nrf[lane] = 0; sh_ncand[lane] = 0; }
+    __syncthreads();
     int n_rings = 0;
     for (int k = 0; k < P->num_zones; ++k) n_rings += P->num_rings_each_zone[k];
     if (lane < n_rings) {
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__
         const int ns = P->num_sectors_each_zone[zone];
         const int base = G->patch_base[zone] + ring * ns;
         const bool is_near = cidx < P->num_rings_of_interest;
-        double rf[64];    // ringwise_flatness (<= sectors per ring <= 64)
+        double* rf = sh_rf[cidx < 4 ? cidx : 0];    // this ring's part of `ringwise_flatness` (<= sectors per ring <= 64; only near rings add to it)
         int nrf = 0, ncand = 0;
         for (int s = 0; s < ns; ++s) {
             PwPatchRec& r = recs[base + s];
@@ -491,13 +495,31 @@ __global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__
             else { decision = 2; ncand++; }
             r.decision = decision;
         }
+        if (cidx < 4) { sh_nrf[cidx] = nrf; sh_ncand[cidx] = ncand; }
+    }
+    __syncthreads();
+    if (lane < n_rings) {
+        int zone = 0, ring = lane;
+        while (ring >= P->num_rings_each_zone[zone]) { ring -= P->num_rings_each_zone[zone]; zone++; }
+        const int cidx = lane;
+        const int ns = P->num_sectors_each_zone[zone];
+        const int base = G->patch_base[zone] + ring * ns;
+        const int ncand = cidx < 4 ? sh_ncand[cidx] : 0;
         if (ncand > 0) {                                     // :293-305
+            // `ringwise_flatness` is cleared only at the end of a ring that HAD candidates (:303-304 sit inside
+            // `if (!candidates.empty())`): the values of the candidate-free rings before this one are still in it
+            int first = cidx;
+            while (first > 0 && sh_ncand[first - 1] == 0) --first;
+            int nrf = 0;
+            for (int r2 = first; r2 <= cidx; ++r2) nrf += sh_nrf[r2];
             double mean_f = 0.0, std_f = 0.0;
             if (nrf > 1) {
                 double sm = 0.0;
-                for (int i = 0; i < nrf; ++i) sm += rf[i];
+                for (int r2 = first; r2 <= cidx; ++r2)
+                    for (int i = 0; i < sh_nrf[r2]; ++i) sm += sh_rf[r2][i];
                 mean_f = sm / (double)nrf;
-                for (int i = 0; i < nrf; ++i) std_f += (rf[i] - mean_f) * (rf[i] - mean_f);
+                for (int r2 = first; r2 <= cidx; ++r2)
+                    for (int i = 0; i < sh_nrf[r2]; ++i) std_f += (sh_rf[r2][i] - mean_f) * (sh_rf[r2][i] - mean_f);
                 std_f /= (double)(nrf - 1);
                 std_f = sqrt(std_f);
             }

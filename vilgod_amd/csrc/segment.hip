@@ -412,7 +412,69 @@ __global__ void k_subsample_keys(unsigned long long seed, unsigned long long tag
     keys[i] = (long long)(vg_mix64(seed * 0x100000001B3ull + (tag << 32) + (unsigned long long)i) >> 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Detection.cluster_mass_center = np.median(cluster_points, axis=0) (objects.py:121-123) for every packed cluster
+// and the first n_cols columns of the point rows: exact order statistics by a 4-pass byte radix select per (cluster, column);
+// an even count gives the float32 mean of the two middle values, like np.median on a float32 array.
+__device__ float vg_select_gather(const float* __restrict__ pts, int stride, int col, const int* __restrict__ idx, int n, int k,
+                                  uint32_t* hist, uint32_t* sh) {
+    uint32_t prefix = 0;
+    for (int pass = 3; pass >= 0; --pass) {
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t key = vg_fkey(pts[(size_t)idx[i] * stride + col]);
+            if (pass == 3 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t cum = 0;
+            int b = 0;
+            for (; b < 256; ++b) {
+                if (cum + hist[b] > (uint32_t)k) break;
+                cum += hist[b];
+            }
+            sh[0] = (uint32_t)b;
+            sh[1] = cum;
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sh[0];
+        k -= (int)sh[1];
+        __syncthreads();
+    }
+    return vg_fkey_inv(prefix);
+}
+
+__global__ __launch_bounds__(256) void k_cluster_medians(const float* __restrict__ pts, int stride, int n_cols,
+                                                         const int* __restrict__ index, const int* __restrict__ seg_off,
+                                                         float* __restrict__ out) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh[2];
+    const int c = blockIdx.x;
+    const int p0 = seg_off[c], n = seg_off[c + 1] - p0;
+    for (int col = 0; col < n_cols; ++col) {
+        float m = 0.f;
+        if (n > 0) {
+            const float hi = vg_select_gather(pts, stride, col, index + p0, n, n / 2, hist, sh);
+            if (n & 1) m = hi;
+            else m = (vg_select_gather(pts, stride, col, index + p0, n, n / 2 - 1, hist, sh) + hi) / 2.0f;
+        }
+        if (threadIdx.x == 0) out[(size_t)c * n_cols + col] = m;
+    }
+}
+
 extern "C" {
+
+int vg_cluster_medians(const float* d_points, int stride, int n_cols, const int32_t* d_index, const int32_t* d_seg_off, int n_clusters,
+                       float* d_median, void* stream) {
+    if (n_clusters <= 0) return VG_OK;
+    if (!d_points || !d_index || !d_seg_off || !d_median || n_cols <= 0 || n_cols > stride) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_cluster_medians, dim3(n_clusters), dim3(256), 0, (hipStream_t)stream, d_points, stride, n_cols, d_index, d_seg_off,
+                       d_median);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
 
 int vg_ref_transform(const float* d_src, int n, int stride, const double* d_T4x4, float* d_dst, void* stream) {
     if (n <= 0) return VG_OK;

@@ -294,6 +294,14 @@ class PseudoLabelPipeline:
               'vg_cluster_boxes')
         return box, aux
 
+    def cluster_medians(self, d_X, d_index, d_seg):
+        """Detection.cluster_mass_center (objects.py:121-123) of the packed clusters over ALL columns of d_X -> CUDA [C, cols] f32."""
+        C = d_seg.numel() - 1
+        out = torch.empty((C, d_X.shape[1]), dtype=torch.float32, device=self.device)
+        check(lib.vg_cluster_medians(ptr(d_X), d_X.stride(0), d_X.shape[1], ptr(d_index), ptr(d_seg), C, ptr(out), stream_ptr()),
+              'vg_cluster_medians')
+        return out
+
     def xy_to_host_async(self, d_X):
         """Start the D2H copy of points_ref_wo_ground[:, :2] into this worker's pinned buffer (reference box mode reads each
         cluster's xy points once on the host, vilgod_amd/boxes.py).  -> (host array view, event to wait for)."""

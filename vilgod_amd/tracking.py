@@ -260,15 +260,15 @@ def motion_vectors(centers_xy, look_ahead=10, min_far=0.5, min_step=0.3, max_ang
     return out
 
 
-def moving_boxes(points_list, directions, to_ego_list, top_k=3):
+def moving_boxes(points_list, directions, to_ego_list, top_k=3, centers3=None):
     """zero_shot_detector.py:572-659: a box per entry aligned with its direction of travel, all resized to the median size of the
     top_k entries with the most points and shifted so that the corner closest to the ego vehicle stays where it was."""
     from scipy.spatial.transform import Rotation as R
     boxes, corner_list = [], []
-    for pts_all, d in zip(points_list, directions):
+    for j, (pts_all, d) in enumerate(zip(points_list, directions)):
         angle = np.arctan2(d[1], d[0])
         rot = R.from_euler('z', angle, degrees=False).as_matrix()
-        center = np.median(pts_all[..., :3], axis=0)
+        center = np.median(pts_all[..., :3], axis=0) if centers3 is None else np.asarray(centers3[j], dtype=pts_all.dtype)
         proj = np.dot(pts_all[..., :3] - center, rot)
         min_x, max_x = proj[:, 0].min(), proj[:, 0].max()
         min_y, max_y = proj[:, 1].min(), proj[:, 1].max()
@@ -322,15 +322,16 @@ def _entry_set(tab, t, i, field, value):
         getattr(tab, field)[t.source[i]] = value
 
 
-def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=None, static_box_of=None):
+def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=None, static_box_of=None, median_of=None):
     """The track branch of fit_bounding_boxes_simple for every valid track, in track order: boxes and `static_track` flags of
     the entries (into `tab` for real detections, into the track for its clones) and `track.static`.
     points_of(key) -> cluster points [n,>=3]; static_of(key) -> Detection.static (the entropy flag); to_ego_of(fnr) -> 4x4;
     rectangle(xy) -> (corners, rz, area), or static_box_of(key) -> the finished static box (the GPU kernel's, vg_cluster_boxes)."""
     sbox = (lambda k, p: np.array(static_box_of(k), dtype=np.float64)) if static_box_of is not None else (lambda k, p: static_box(p, rectangle))
+    need_pts = static_box_of is None                     # the finished static boxes make the points of static tracks unnecessary
     for t in tracker.tracks_valid:
         n = len(t)
-        pts = [points_of(k) for k in t.source]
+        pts = [points_of(k) for k in t.source] if need_pts else [None] * n
         t.clone_box = [None] * n
         t.clone_static_track = [None] * n
         t.clone_valid = [True] * n
@@ -338,10 +339,20 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=Non
             for i in range(n):
                 _entry_set(tab, t, i, 'box', sbox(t.source[i], pts[i]))
             continue
-        centers = np.array([np.median(p[..., :2], axis=0) for p in pts])
+        # median_of(key) -> np.median(cluster points, axis=0) (the medians track_clusters already has: vg_cluster_medians)
+        if median_of is not None:
+            med = [median_of(k) for k in t.source]
+            centers = np.array([m[:2] for m in med])
+        else:
+            if not need_pts:
+                pts = [points_of(k) for k in t.source]
+            med = None
+            centers = np.array([np.median(p[..., :2], axis=0) for p in pts])
         dirs = motion_vectors(centers)
         if dirs:
-            boxes = moving_boxes(pts, dirs, [to_ego_of(f) for f in t.frames])
+            if pts[0] is None:
+                pts = [points_of(k) for k in t.source]
+            boxes = moving_boxes(pts, dirs, [to_ego_of(f) for f in t.frames], centers3=[m[:3] for m in med] if med is not None else None)
             for i in range(n):
                 _entry_set(tab, t, i, 'box', boxes[i])
                 _entry_set(tab, t, i, 'static_track', False)

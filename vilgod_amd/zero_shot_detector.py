@@ -414,6 +414,7 @@ class ZeroShotDetector:
             self._fit_boxes_tracked(valid_only)
             self.sync_lidar_frames()
             return
+        jobs = []
         for fnr in self.my_frames:
             fs = self.lidar_frame_list[fnr]
             if fs.n_detections == 0 or (fs.boxes is not None and not kwargs.get('force', False)):
@@ -427,17 +428,23 @@ class ZeroShotDetector:
             if len(rows) == 0:
                 continue
             _, X = self._ref_and_nonground(fnr)
-            fs.boxes[rows] = self._fit_rows(fnr, rows, X)
+            jobs.append((fs, rows, self._fit_rows(fnr, rows, X, wait=False)))
+        for fs, rows, fut in jobs:
+            fs.boxes[rows] = fut.result()
         self.sync_lidar_frames()
 
-    def _fit_rows(self, fnr, rows, X):
-        """Static-branch boxes of clusters `rows` of frame fnr (pipeline.fit_boxes: reference or fast mode)."""
+    def _fit_rows(self, fnr, rows, X, wait=True):
+        """Static-branch boxes of clusters `rows` of frame fnr (pipeline.fit_boxes: reference or fast mode); wait=False returns an
+        object with .result() (reference mode: the host part runs in a helper process meanwhile)."""
+        from .boxes import _Done
         fs = self.lidar_frame_list[fnr]
         parts = [fs.cluster_index(c) for c in rows]
         index = np.concatenate(parts).astype(np.int32)
         seg = np.r_[0, np.cumsum([len(p) for p in parts])].astype(np.int32)
-        xy = self._host_X[fnr] if (self.pipe.box_mode == 'reference' and fnr in self._host_X) else None
-        return self.pipe.fit_boxes(X, index, seg, xy_host=xy)
+        if self.pipe.box_mode != 'reference':
+            return self.pipe.fit_boxes(X, index, seg) if wait else _Done(self.pipe.fit_boxes(X, index, seg))
+        fut = self.pipe.fit_boxes_async(X, index, seg, xy_host=self._points_host(fnr))
+        return fut.result() if wait else fut
 
     def evaluate_sequence(self, modes=('detection_3d',), logger=None, **kwargs):
         key = kwargs.get('classification_key', 'clip')
@@ -482,15 +489,24 @@ class ZeroShotDetector:
         self.tracker = Tracker(mode=g('mode', 'cluster_center'), max_distance=(assign['max_distance'] if isinstance(assign, dict) else assign.max_distance),
                                min_length=g('min_length', 5), max_missed=g('max_missed', 3))
         self._tab = None
-        med, cnt = {}, {}
+        # Detection.cluster_mass_center (objects.py:121-123) of every detection the tracker sees: one kernel launch per frame
+        # (vg_cluster_medians, exact np.median semantics), queued for all frames before the first result is read back
+        med, cnt, pending = {}, {}, []
         for fs in self.lidar_frame_list:
             rows = np.flatnonzero(fs.valid) if valid_only else np.arange(fs.n_detections)
+            if len(rows):
+                X = self._ref_and_nonground(fs.fnr)[1]
+                d_index, d_seg = self._cluster_lists(fs.fnr, rows)
+                pending.append((fs, rows, self.pipe.cluster_medians(X, d_index, d_seg)))
+            else:
+                pending.append((fs, rows, None))
+        self._med = med
+        for fs, rows, d_med in pending:
             keys = [(fs.fnr, int(r)) for r in rows]
             if keys:
-                X = self._points_host(fs.fnr)
-                for k in keys:
-                    p = X[fs.cluster_index(k[1])]
-                    med[k], cnt[k] = np.median(p, axis=0), len(p)                  # Detection.cluster_mass_center (objects.py:121-123)
+                m = d_med.cpu().numpy()
+                for j, k in enumerate(keys):
+                    med[k], cnt[k] = m[j], int(fs.seg_off[k[1] + 1] - fs.seg_off[k[1]])
             centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
             self.tracker.next(fs.fnr, keys, centers, [cnt[k] for k in keys], lambda k: (med[k], cnt[k]))
         self.tracker.finish()
@@ -509,17 +525,22 @@ class ZeroShotDetector:
             for fnr, row in t.source:
                 tracked.setdefault(fnr, set()).add(row)
         gpu_box = {}
-        for fnr, rows in tracked.items():
+        jobs = []
+        for fnr, rows in tracked.items():                # every frame's request goes out before the first answer is awaited
             rows = sorted(rows)
             _, X = self._ref_and_nonground(fnr)
-            for r, b in zip(rows, self._fit_rows(fnr, rows, X)):
+            jobs.append((fnr, rows, self._fit_rows(fnr, rows, X, wait=False)))
+        for fnr, rows, fut in jobs:
+            for r, b in zip(rows, fut.result()):
                 gpu_box[(fnr, r)] = b
         tab = DetectionTable()
         for fs in self.lidar_frame_list:
             for r in range(fs.n_detections):
                 tab.valid[(fs.fnr, r)] = bool(fs.valid[r])
+        med = getattr(self, '_med', None) or {}
         fit_track_boxes(self.tracker, tab, self._cluster_points_host, lambda k: bool(self.lidar_frame_list[k[0]].static[k[1]]),
-                        lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__)
+                        lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__,
+                        median_of=(med.__getitem__ if med else None))
         self._tab = tab
         self._write_back_tracked()
 
