@@ -88,35 +88,60 @@ def reference_boxes_packed(xy_packed, seg, zmin, zmax):
 # packed xy points (~0.3 MB) travel over a pipe, the frame's worker thread collects the boxes after it has queued the frame's
 # classification.
 class BoxWorkerPool:
+    """n helper processes, each driven by one dispatcher thread that takes requests from a shared queue, so `submit` never blocks
+    and any number of requests may be outstanding (a stage may queue every frame of a sequence before it reads the first answer)."""
+
     def __init__(self, n_procs):
         import os
         import queue
         import subprocess
         import sys
+        import threading
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
         env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
-        self.procs = [subprocess.Popen([sys.executable, '-m', 'vilgod_amd.box_worker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                       env=env, cwd=root) for _ in range(int(n_procs))]
-        self.idle = queue.Queue()
-        for p in self.procs:
-            self.idle.put(p)
+        self.requests = queue.Queue()
+        self.procs, self.threads = [], []
+        for _ in range(int(n_procs)):
+            p = subprocess.Popen([sys.executable, '-m', 'vilgod_amd.box_worker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
+            t = threading.Thread(target=self._serve, args=(p,), daemon=True)
+            t.start()
+            self.procs.append(p)
+            self.threads.append(t)
 
-    def submit(self, *req):
+    def _serve(self, p):
         import pickle
         import struct
-        p = self.idle.get()                      # blocks while every helper is busy
-        blob = pickle.dumps(req, protocol=pickle.HIGHEST_PROTOCOL)
-        try:
-            p.stdin.write(struct.pack('<q', len(blob)))
-            p.stdin.write(blob)
-            p.stdin.flush()
-        except Exception:
-            self.idle.put(p)
-            raise
-        return _Pending(self, p)
+        while True:
+            item = self.requests.get()
+            if item is None:
+                return
+            fut, req = item
+            try:
+                blob = pickle.dumps(req, protocol=pickle.HIGHEST_PROTOCOL)
+                p.stdin.write(struct.pack('<q', len(blob)))
+                p.stdin.write(blob)
+                p.stdin.flush()
+                head = p.stdout.read(8)
+                if len(head) < 8:
+                    raise RuntimeError('box helper process ended unexpectedly')
+                (n,) = struct.unpack('<q', head)
+                status, val = pickle.loads(p.stdout.read(n))
+                if status != 'ok':
+                    raise RuntimeError(f'box helper process: {val}')
+                fut.set_result(val)
+            except BaseException as e:      # noqa: BLE001  (delivered to the caller of .result())
+                fut.set_exception(e)
+
+    def submit(self, *req):
+        from concurrent.futures import Future
+        fut = Future()
+        self.requests.put((fut, req))
+        return fut
 
     def close(self):
+        for _ in self.threads:
+            self.requests.put(None)
         for p in self.procs:
             try:
                 p.stdin.close()
@@ -127,30 +152,7 @@ class BoxWorkerPool:
                 p.wait(timeout=5)
             except Exception:           # noqa: BLE001
                 p.kill()
-        self.procs = []
-
-
-class _Pending:
-    def __init__(self, pool, proc):
-        self.pool, self.proc, self._v = pool, proc, None
-
-    def result(self):
-        import pickle
-        import struct
-        if self.proc is not None:
-            p, self.proc = self.proc, None
-            try:
-                head = p.stdout.read(8)
-                if len(head) < 8:
-                    raise RuntimeError('box helper process ended unexpectedly')
-                (n,) = struct.unpack('<q', head)
-                status, val = pickle.loads(p.stdout.read(n))
-            finally:
-                self.pool.idle.put(p)
-            if status != 'ok':
-                raise RuntimeError(f'box helper process: {val}')
-            self._v = val
-        return self._v
+        self.procs, self.threads = [], []
 
 
 class _Done:
