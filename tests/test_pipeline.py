@@ -181,11 +181,11 @@ def test_f16_pipeline_agrees_with_f32_pipeline_on_150k_frames(cuda):
         n_views += len(flip); n_view_flips += int(flip.sum())
         n_clusters += len(rows); n_name_flips += int(names_differ.sum())
         assert names_differ.sum() <= max(1, int(has_flip.sum())) + 1
-        same = ~names_differ
-        keep_a = np.array([str(ea['name'][r]) in p16.class_names for r in rows])
-        keep_b = np.array([str(eb['name'][r]) in p32.class_names for r in rows])
-        if (keep_a == keep_b).all() and same.all():
+        # clusters without a flipped view: same name, final score (mean probability of the winning views) within the bound
+        quiet = ~has_flip & ~names_differ
+        fa_, fb_ = np.asarray(ea['final'])[rows].astype(np.float64), np.asarray(eb['final'])[rows].astype(np.float64)
+        assert np.abs(fa_[quiet] - fb_[quiet]).max() <= 2e-3
+        if not names_differ.any():
             assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
-            assert np.abs(ra['score'] - rb['score']).max() <= 2e-3
     print(f'f16 vs f32 pipeline, 3 x 150k frames: max |dp| {worst:.2e}; top-1 flips {n_view_flips}/{n_views} views '
           f'(all inside the fp32 margin bound), final-name flips {n_name_flips}/{n_clusters} clusters')

@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ p
         s2 += v[i];
     }
     if (h1) {
-        // ln_1 of the first block on the row just produced (the fused path has no separate LayerNorm launches)
+        // ln_1 of the first block on the row just produced: one LayerNorm launch (and its read of the stream) less per encode
         const float mean2 = vg_wave_sum(s2) / (float)W;
         float q2 = 0.f;
         for (int i = 0; i < per; ++i) {
@@ -1012,7 +1012,6 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 #define VG_PROF_MAX 4096
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
-    bool ln_fused = false;           // dtype 1, fp32 stream, width % 256 == 0: LayerNorms fused into the producing kernels (VG_VIT_NO_LNFUSE=1 disables)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1227,20 +1226,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict_
 //   by group 0 in its LOAD_{j+1} (3-deep ring -> at least one interval of lead).
 //   The second k32 sub-step's fragments are read during the first sub-step's MFMAs into the registers those have
 //   just consumed.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that ends its MMA segment.
-//   LNF (EPI_BIAS_RESID only): the LayerNorm that follows the residual update (ln_2 after out_proj, the next block's ln_1 after
-//   c_proj; model.py:190-191) is fused in.  A workgroup then owns a whole 256-row tile of the residual stream: it walks the
-//   N / 256 column tiles of that row tile one after the other (the order the L2 chunking preferred anyway), and when the last one
-//   is written it normalises its 256 rows -- re-read from L2 where its own stores just put them, same arithmetic as k_layernorm --
-//   into the fp16 operand of the next GEMM.  That removes the separate LayerNorm launch (one per residual GEMM) and its 197 MB
-//   re-read of the fp32 stream from HBM.  Grid = M / 256 workgroups (251 for 325 crops: one round on 256 CUs).
-template <int EPI, bool TRACE = false, bool PERSIST = false, bool LNF = false>
+template <int EPI, bool TRACE = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
-                                                          long long* __restrict__ trace = nullptr,
-                                                          const float* __restrict__ ln_w = nullptr, const float* __restrict__ ln_b = nullptr,
-                                                          f16* __restrict__ ln_out = nullptr, int m_valid = 0) {
-    static_assert(!LNF || (EPI == EPI_BIAS_RESID && !PERSIST), "LNF: fp32 residual epilogue, own tile loop");
+                                                          long long* __restrict__ trace = nullptr) {
     constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;
     constexpr int XBUF = 32768, WBASE = 2 * XBUF, WBUF = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1255,14 +1245,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     const int xq = nt_all >> 3, xr_ = nt_all & 7, xcd = blockIdx.x & 7;
     const int xbase = (xcd < xr_) ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq;
     const int xcnt = xq + (xcd < xr_ ? 1 : 0);
-    const int ti_end = LNF ? N / BN : (PERSIST ? xcnt : 1);
-    for (int ti = PERSIST ? (int)(blockIdx.x >> 3) : 0; ti < ti_end; ti += PERSIST ? (int)(gridDim.x >> 3) : 1) {
+    for (int ti = PERSIST ? (int)(blockIdx.x >> 3) : 0; ti < (PERSIST ? xcnt : 1); ti += PERSIST ? (int)(gridDim.x >> 3) : 1) {
     int lane = tid & 63;
-    if (PERSIST || LNF) asm volatile("" : "+v"(lane));      // per-lane offsets are re-derived per tile instead of living through the epilogue
+    if (PERSIST) asm volatile("" : "+v"(lane));      // per-lane offsets are re-derived per tile instead of living through the epilogue
     const int t = PERSIST ? xbase + ti : xcd_remap(blockIdx.x, gridDim.x);
     const int per_chunk = ntm * cw;
     const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-    const int tm = LNF ? t : tc / cw, tn = LNF ? ti : chunk * cw + (tc - tm * cw);
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // DMA pieces: 8 rows x 128 B; lane -> row l >> 3, chunk slot l & 7 (source chunk = slot ^ ((row >> 1) & 7))
@@ -1459,59 +1448,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
             }
         }
     }
-    if (PERSIST || LNF) __syncthreads();   // the epilogue's LDS image is read before the next tile's first pieces land
-    }
-    if (LNF) {
-        // ---- LayerNorm of this workgroup's 256 rows (fp32 statistics, model.py:157-163), k_layernorm's arithmetic --------------
-        // The barrier above (with its memory fence: every wave's stores are complete) makes the rows written by the other waves of
-        // this workgroup visible here: one CU, one vector L1.  Wave w normalises rows [32 w, +32) in batches of 8 rows whose
-        // loads go out together (a row-after-row loop would pay an L2 round trip per row).
-        const int lane = tid & 63;
-        const int nv = N >> 8;                                         // float4 per lane, <= 4 (N <= 1024, N % 256 == 0)
-        const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
-        float4 w4[4], b4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nv) { w4[i] = *(const float4*)(ln_w + (i * 64 + lane) * 4); b4[i] = *(const float4*)(ln_b + (i * 64 + lane) * 4); }
-#pragma unroll 1
-        for (int bt = 0; bt < 4; ++bt) {
-            float4 v[8][4];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = m0 + wave * 32 + bt * 8 + q;
-                const float* src = resid + (size_t)(row < M ? row : M - 1) * ldc;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nv) v[q][i] = *(const float4*)(src + (i * 64 + lane) * 4);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = m0 + wave * 32 + bt * 8 + q;
-                float s_ = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nv) s_ += (v[q][i].x + v[q][i].y) + (v[q][i].z + v[q][i].w);
-                const float mean = vg_wave_sum(s_) / (float)N;
-                float q_ = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nv) {
-                        const float a = v[q][i].x - mean, b = v[q][i].y - mean, c = v[q][i].z - mean, d = v[q][i].w - mean;
-                        q_ += (a * a + b * b) + (c * c + d * d);
-                    }
-                const float rstd = rsqrtf(vg_wave_sum(q_) / (float)N + 1e-5f);
-                if (row < m_valid) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < nv) {
-                            const float o0 = (v[q][i].x - mean) * rstd * w4[i].x + b4[i].x, o1 = (v[q][i].y - mean) * rstd * w4[i].y + b4[i].y;
-                            const float o2 = (v[q][i].z - mean) * rstd * w4[i].z + b4[i].z, o3 = (v[q][i].w - mean) * rstd * w4[i].w + b4[i].w;
-                            const f16x4 h4 = {(f16)o0, (f16)o1, (f16)o2, (f16)o3};
-                            *(f16x4*)(ln_out + (size_t)row * N + (i * 64 + lane) * 4) = h4;
-                        }
-                }
-            }
-        }
+    if (PERSIST) __syncthreads();          // the epilogue's LDS image is read before the next tile's first pieces land
     }
     if (TRACE && (tid & 63) == 0 && trace) {
         long long* o = trace + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -1539,24 +1476,6 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
-// out_proj / c_proj with the following LayerNorm fused in (k_gemm_f16_pp64<EPI_BIAS_RESID, ., ., LNF>): resid (fp32 [M,N]) += X Wt^T + bias,
-// then ln_out (fp16 [m_valid,N]) = LayerNorm(resid rows) * ln_w + ln_b.  One workgroup per 256-row tile.
-static int launch_gemm_pp64_ln(const void* X, const void* Wt, const float* bias, float* resid, int M, int N, int K, const float* ln_w,
-                               const float* ln_b, void* ln_out, int m_valid, hipStream_t st) {
-    if (M % 256 || N % 256 || N > 1024 || K % 64 || K / 64 < 2 || !ln_w || !ln_b || !ln_out) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp64<EPI_BIAS_RESID, false, false, true>;
-    const int lds = 5 * 32768;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(M / 256), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, (void*)nullptr, resid, M, N, K, N,
-                       N / 256, (long long*)nullptr, ln_w, ln_b, (f16*)ln_out, m_valid);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
-
 template <int EPI, bool TRACE = false, bool PERSIST = false>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr) {
@@ -1579,7 +1498,7 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
         grid = (grid + 7) / 8 * 8;                 // slot s of XCD x = block 8 s + x
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, cwt, trace, (const float*)nullptr, (const float*)nullptr, (f16*)nullptr, 0);
+                       ldc, cwt, trace);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
@@ -1693,7 +1612,6 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
     v->out_dim = out_dim; v->dtype = dtype; v->T = T;
     v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
-    v->ln_fused = dtype == 1 && !v->resid_h && width % 256 == 0 && !getenv("VG_VIT_NO_LNFUSE") && !getenv("VG_GEMM_V4");
     *out = v;
     return VG_OK;
 }
@@ -1799,34 +1717,23 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     int rc = launch_gemm<EPI_NONE_F32>(v, patches, need("conv1.weight"), nullptr, pe, nullptr, (int)Pp, W, (int)Kp, st);
     if (rc) return rc;
     const bool rh = v->resid_h;
+    bool ln1_done = false;
     f16* xh = (f16*)x;                // the residual stream lives in the same workspace region, as fp16 when `rh`
     if (rh)
         hipLaunchKernelGGL((k_embed_lnpre<f16>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
                            (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
                            (const float*)need("ln_pre.bias"), xh, (int)M, T, W, (int)Mp);
     else {
-        const bool lnf0 = v->ln_fused && L > 0;
-        const float* lw1 = lnf0 ? (const float*)need("transformer.resblocks.0.ln_1.weight") : nullptr;
-        const float* lb1 = lnf0 ? (const float*)need("transformer.resblocks.0.ln_1.bias") : nullptr;
-        if (lnf0 && (!lw1 || !lb1)) return VG_ERR_ARG;
+        // fp16 tower: ln_1 of block 0 is computed by the same kernel (writes h next to x)
+        ln1_done = v->dtype == 1 && L > 0;
+        const float* lw1 = ln1_done ? (const float*)need("transformer.resblocks.0.ln_1.weight") : nullptr;
+        const float* lb1 = ln1_done ? (const float*)need("transformer.resblocks.0.ln_1.bias") : nullptr;
+        if (ln1_done && (!lw1 || !lb1)) return VG_ERR_ARG;
         hipLaunchKernelGGL((k_embed_lnpre<float>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
                            (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
-                           (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp, lw1, lb1, lnf0 ? (f16*)h : (f16*)nullptr);
+                           (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp, lw1, lb1, ln1_done ? (f16*)h : (f16*)nullptr);
     }
     VG_LAUNCH_CHECK();
-    // a residual GEMM with the following LayerNorm fused in; same event-pair bookkeeping as launch_gemm
-    auto gemm_resid_ln = [&](const void* Xop, const void* Wop, const float* bias, int K, const float* lnw, const float* lnb) -> int {
-        const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
-        if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
-        const int r = launch_gemm_pp64_ln(Xop, Wop, bias, x, (int)Mp, W, K, lnw, lnb, h, (int)M, st);
-        if (prof) {
-            (void)hipEventRecord(v->prof_ev[2 * v->prof_n + 1], st);
-            v->prof_kind[v->prof_n] = 1;
-            v->prof_flops[v->prof_n++] = 2.0 * (double)Mp * (double)W * (double)K;
-        }
-        return r;
-    };
-    const bool lnf = v->ln_fused;
     for (int l = 0; l < L; ++l) {
         std::string p = "transformer.resblocks." + std::to_string(l) + ".";
         const char* names[] = {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
@@ -1840,8 +1747,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                 return VG_ERR_ARG;
             }
         }
-        if (lnf) {
-            // h already holds ln_1(x): written by k_embed_lnpre (block 0) or by the previous block's c_proj epilogue
+        if (l == 0 && ln1_done) {
+            // h already holds ln_1(x) of block 0 (k_embed_lnpre)
         } else if (rh)
             hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[0], (const float*)wp[1], (f16*)h, (int)M, W, 1);
         else if (v->dtype == 1)
@@ -1872,13 +1779,10 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             hipLaunchKernelGGL(k_attention_f32, dim3(n_crops * H), dim3(256), lds, st, (const float*)qkv, (float*)h, T, W, H);
         }
         VG_LAUNCH_CHECK();
-        rc = lnf ? gemm_resid_ln(h, wp[4], (const float*)wp[5], W, (const float*)wp[6], (const float*)wp[7])       // out_proj + ln_2 (h is read as the A operand
-                                                                                                             // of every column tile before the LayerNorm phase overwrites it)
-             : rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
-                  : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
+        rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
+                : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
         if (rc) return rc;
-        if (lnf) {
-        } else if (rh)
+        if (rh)
             hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
         else if (v->dtype == 1)
             hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
@@ -1887,16 +1791,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         VG_LAUNCH_CHECK();
         rc = launch_gemm<EPI_BIAS_GELU>(v, h, wp[8], (const float*)wp[9], mlp, nullptr, (int)Mp, 4 * W, W, st);
         if (rc) return rc;
-        const float* nlw = nullptr, *nlb = nullptr;
-        if (lnf && l + 1 < L) {
-            const std::string pn = "transformer.resblocks." + std::to_string(l + 1) + ".";
-            nlw = (const float*)need(pn + "ln_1.weight");
-            nlb = (const float*)need(pn + "ln_1.bias");
-            if (!nlw || !nlb) return VG_ERR_ARG;
-        }
-        rc = nlw ? gemm_resid_ln(mlp, wp[10], (const float*)wp[11], 4 * W, nlw, nlb)                            // c_proj + the next block's ln_1
-             : rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
-                  : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
+        rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
+                : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
         if (rc) return rc;
     }
     if (rh)
