@@ -27,6 +27,7 @@ The JSON line also carries
                 bounded sample of the metric's workload on the host cores of the same box (rank 0, N=1 only)
 and, as information beside the metric (N=1 only; each block reports its own failure instead of costing the metric line):
   box_modes            the same frames with box_mode 'fast' (GPU hull, all edges) next to the default 'reference' mode
+  hipgraph_loop        the same frames with the ViT as plain stream launches next to the default captured hipGraph per crop count
   views6, dense200k    BASELINE configs 3 (6 rendered views) and 5 (200k points, ~120 objects) shapes
   default_config_mode  the reference's default stage order -- entropy scores + two-frame clustering -- as a library call
   cli_mode             tools/preprocess_data.py itself: the default 9-stage list on a 199-frame 150k-point synthetic sequence
@@ -142,6 +143,7 @@ def main():
     ap.add_argument('--box-mode', default='reference', choices=['reference', 'fast'])
     ap.add_argument('--ground-handoff', default='chain', choices=['chain', 'replay'],
                     help='N > 1: how rank r obtains the Patchwork++ state at the start of its frame block (both inside the timed region)')
+    ap.add_argument('--no-vit-graph', action='store_true', help='plain stream launches for the ViT instead of the captured hipGraph per crop count')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the information blocks beside the metric (box_modes, views6, dense200k, cli_mode)')
     ap.add_argument('--cli-frames', type=int, default=199, help='frames of the synthetic sequence of the cli_mode block')
@@ -173,7 +175,7 @@ def main():
     from vilgod_amd import synthetic, dist as vdist
     from vilgod_amd.pipeline import PseudoLabelPipeline
     pipe = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=args.views, max_points=args.points + 1024,
-                               clip_model_path='/nonexistent', box_mode=args.box_mode)
+                               clip_model_path='/nonexistent', box_mode=args.box_mode, vit_graph=not args.no_vit_graph)
     K, W = args.steps, max(args.warmup, args.inflight if args.inflight > 1 else 0)       # warm-up covers the worker handles
     # ONE sequence of world * K timed frames (+ a warm-up stretch in front), contiguous block of K frames per rank, smooth
     # trajectory; four distinct point clouds per rank are cycled, resident in HBM
@@ -324,9 +326,10 @@ def main():
             except Exception as e:          # noqa: BLE001
                 out[name] = {'error': f'{type(e).__name__}: {e}'}
 
-        def other_shape(points, objects, views, steps, box_mode=None):
+        def other_shape(points, objects, views, steps, box_mode=None, vit_graph=None):
             p2 = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=views, max_points=points + 1024, clip_model_path='/nonexistent',
-                                     clip=pipe.clip, box_mode=box_mode or args.box_mode)
+                                     clip=pipe.clip, box_mode=box_mode or args.box_mode,
+                                     vit_graph=(not args.no_vit_graph) if vit_graph is None else vit_graph)
             fr = frames if points == args.points and objects == args.objects else \
                 [p2.upload(synthetic.make_frame(501 + i, points, n_objects=objects)) for i in range(n_distinct)]
             p2.new_sequence()
@@ -357,6 +360,20 @@ def main():
                                 "host qhull on the worker threads), 'fast' = GPU hull + rectangle over all edges; a box differs when its "
                                 'footprint area differs by more than 2e-4 relative'}
             block('box_modes', box_modes)
+
+            def hipgraph_loop():
+                on = not args.no_vit_graph
+                dt, res = other_shape(args.points, args.objects, args.views, K, vit_graph=not on)
+                same = all(np.array_equal(a[1]['name'], b[1]['name']) and np.array_equal(a[2].cpu().numpy(), b[2].cpu().numpy()) for a, b in zip(outs, res))
+                stats = [w._graph_cls.stats() for w in (pipe._workers or []) if getattr(w, '_graph_cls', None) is not None]
+                return {'captured': {'value': round(value if on else K / dt, 3), 'unit': 'frames/s'},
+                        'plain_launches': {'value': round(K / dt if on else value, 3), 'unit': 'frames/s'},
+                        'identical_scores_and_names': bool(same),
+                        'graphs_captured': sum(s_['graphs_captured'] for s_ in stats), 'graph_launches': sum(s_['graph_launches'] for s_ in stats),
+                        'note': 'captured = the ViT encode + scores of a frame (~150 kernels) replayed as one hipGraph per distinct crop count, per '
+                                'worker; ground / clustering / rendering have frame-dependent launch dimensions and the hierarchy is built on '
+                                'the host, so they stay stream launches around the graph (BASELINE config 5)'}
+            block('hipgraph_loop', hipgraph_loop)
 
             def shape_block(points, objects, views, cfg_name):
                 def fn():

@@ -104,6 +104,20 @@ int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* 
  * Exposed so that the kernel can be unit-tested against a plain fp32 attention. */
 int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, void* stream);
 
+/* ---- captured classification: the hipGraph loop of BASELINE config 5 ------------------------------------------------
+ * vg_vit_encode + vg_clip_scores of one frame (the reference's per-chunk model.encode_image + softmax, clip_utils.py:37-61) as ONE
+ * hipGraph per distinct crop count: captured on the first frame that has that many crops, replayed for every later one
+ * (~150 kernel launches become one graph launch).  A cache belongs to ONE worker: one stream and one set of persistent buffers
+ * (every pointer is part of the key).  The data-dependent stages of a frame (ground, clustering, rendering: their launch
+ * dimensions change with every frame, and the hierarchy is built on the host) stay plain stream launches around the graph.
+ * `stream` must be a created stream (not NULL).  While vg_vit_profile is on, the call falls back to plain launches. */
+typedef struct vg_graph_cache vg_graph_cache;
+int vg_graph_cache_create(vg_graph_cache** out);
+void vg_graph_cache_destroy(vg_graph_cache* c);
+int vg_graph_cache_stats(const vg_graph_cache* c, int64_t* h_captured, int64_t* h_replayed);
+int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
+                          const float* d_text, int dim, int n_classes, float* d_probs, int32_t* d_top1, float* d_top1_score, void* stream);
+
 /* clip_utils.py:42-61: probs = softmax(100 * normalise(feat) @ text.T) (d_text rows already unit
  * norm, clip_utils.py:26), top-1 class id and probability per crop.  n_classes <= 64. */
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
@@ -185,7 +199,9 @@ void vg_cluster_destroy(vg_cluster* h);
  * k = min_samples (= min_cluster_size in the reference's configuration; k <= 15): core distance = distance to the
  * k-th nearest OTHER point.  Outputs (device): d_core2 [n] f64 squared core distances in input order (may be NULL);
  * d_mst_lo/hi [n-1] int32 input indices (lo < hi); d_mst_w2 [n-1] f64 SQUARED weights, ascending.
- * Synchronises `stream` once per Boruvka round (4-byte counter read).  h_rounds (host, may be NULL): rounds used. */
+ * Termination is decided on the device (every kernel of a round returns at once when the tree was complete before the round);
+ * the host queues the first six rounds without reading anything back and synchronises `stream` once per batch (one 4-byte
+ * counter per round): typically one or two synchronisations per call.  h_rounds (host, may be NULL): rounds needed. */
 int vg_cluster_mst(vg_cluster* h, const float* d_points, int n, int stride, int k, double* d_core2, int32_t* d_mst_lo,
                    int32_t* d_mst_hi, double* d_mst_w2, int32_t* h_rounds, void* stream);
 /* The same over the first `dim` (3, 4 or 5) columns: dim = 5 is the two-frame clustering input

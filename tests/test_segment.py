@@ -261,7 +261,7 @@ def test_hip_cluster_medians_equal_numpy(cuda):
     from vilgod_amd.pipeline import PseudoLabelPipeline
     rng = np.random.default_rng(4)
     sizes = [1, 2, 3, 10, 11, 64, 257, 1000, 4097, 9000]
-    X = rng.normal(size=(sum(sizes) + 500, 5)).astype(np.float32) * [30, 30, 2, 0.3, 0]
+    X = (rng.normal(size=(sum(sizes) + 500, 5)) * [30, 30, 2, 0.3, 0]).astype(np.float32)
     X[:2000, 0] = np.round(X[:2000, 0])                       # ties
     perm = rng.permutation(len(X))
     idxs, o = [], 0

@@ -219,3 +219,29 @@ def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
     srt = np.sort(p_want.numpy(), axis=1)
     sure = (srt[:, -1] - srt[:, -2]) > 4e-3
     assert np.array_equal(top1[sure], vo.top1(p_want)[0][sure])
+
+
+@pytest.mark.gpu
+def test_hip_captured_classification_equals_plain_launches(cuda):
+    """BASELINE config 5's hipGraph loop: vg_vit_classify_graph (one captured graph per crop count, replayed) returns bit for bit
+    what the plain launches of vg_vit_encode + vg_clip_scores return, for new crop counts (capture) and repeated ones (replay),
+    on a worker stream with persistent buffers."""
+    from vilgod_amd.clip_wrapper import VitEncoder, GraphClassifier, clip_scores
+    wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
+    text = cw.synthetic_text_features(0, 24, 512).to(cuda)
+    enc = VitEncoder(wd, dtype='f16', device=cuda)
+    plain = enc.view()
+    g = GraphClassifier(enc, text, max_crops=16)
+    gen = torch.Generator().manual_seed(5)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        for n in [5, 9, 5, 16, 9, 5, 20]:                     # 20 > capacity: buffers grow, graphs are rebuilt
+            rows = (n * 196 + 255) // 256 * 256
+            p = (torch.randn(rows, 768, generator=gen) * 0.8).half().to(cuda)
+            g.patch_buffer(n)[:rows].copy_(p)
+            probs, top1, score = [t.clone() for t in g.classify(n)]
+            want = clip_scores(plain.encode_patches(p, n), text)
+            stream.synchronize()
+            assert torch.equal(probs, want[0]) and torch.equal(top1, want[1]) and torch.equal(score, want[2]), n
+    st = g.stats()
+    assert st['graphs_captured'] >= 1 and st['graph_launches'] >= st['graphs_captured']

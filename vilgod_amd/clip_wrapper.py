@@ -101,6 +101,62 @@ def _encode_patches(self, patches, n, stream=None):
 VitEncoder.encode_patches = _encode_patches
 
 
+class GraphClassifier:
+    """One worker's captured classification (include/vilgod_hip.h vg_vit_classify_graph): persistent patch / workspace / feature /
+    score buffers and a cache of one hipGraph per distinct crop count.  The renderer writes the frame's patch rows into
+    `patch_buffer(n)`; `classify(n)` replays (or, the first time a crop count shows up, captures) the graph of the ViT encode +
+    scores on the current stream and returns views of the persistent outputs -- valid until the worker's next frame."""
+
+    def __init__(self, encoder, text_features, max_crops=512):
+        assert encoder.dtype == 'f16' and encoder.cfg['patch'] == 16 and encoder.cfg['resolution'] == 224
+        self.enc, self.text = encoder, text_features
+        self.device = encoder.device
+        self._cache = ctypes.c_void_p()
+        check(lib.vg_graph_cache_create(ctypes.byref(self._cache)), 'vg_graph_cache_create')
+        self.cap = 0
+        self._alloc(max_crops)
+
+    def _alloc(self, n):
+        """(Re)allocate every buffer a graph node points to; graphs of the old buffers are dropped."""
+        if self.cap:
+            lib.vg_graph_cache_destroy(self._cache)
+            self._cache = ctypes.c_void_p()
+            check(lib.vg_graph_cache_create(ctypes.byref(self._cache)), 'vg_graph_cache_create')
+        self.cap = int(n)
+        rows = (self.cap * 196 + 255) // 256 * 256
+        K = self.text.shape[0]
+        self.patches = torch.zeros((rows, 768), dtype=torch.float16, device=self.device)
+        self.ws = torch.zeros(int(lib.vg_vit_workspace_bytes(self.enc._h, self.cap)), dtype=torch.uint8, device=self.device)
+        self.feat = torch.empty((self.cap, self.enc.cfg['output_dim']), dtype=torch.float32, device=self.device)
+        self.probs = torch.empty((self.cap, K), dtype=torch.float32, device=self.device)
+        self.top1 = torch.empty((self.cap,), dtype=torch.int32, device=self.device)
+        self.score = torch.empty((self.cap,), dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        c = getattr(self, '_cache', None)
+        if c is not None and lib is not None:
+            lib.vg_graph_cache_destroy(c)
+            self._cache = None
+
+    def patch_buffer(self, n):
+        if n > self.cap:
+            torch.cuda.current_stream(self.device).synchronize()
+            self._alloc(max(n, int(self.cap * 1.5)))
+        return self.patches
+
+    def classify(self, n):
+        """-> (probs [n,K], top1 [n], score [n]) views of the persistent outputs."""
+        check(lib.vg_vit_classify_graph(self.enc._h, self._cache, ptr(self.patches), 2, n, ptr(self.ws), ptr(self.feat), ptr(self.text),
+                                        self.feat.shape[1], self.text.shape[0], ptr(self.probs), ptr(self.top1), ptr(self.score),
+                                        stream_ptr()), 'vg_vit_classify_graph')
+        return self.probs[:n], self.top1[:n], self.score[:n]
+
+    def stats(self):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib.vg_graph_cache_stats(self._cache, ctypes.byref(a), ctypes.byref(b)), 'vg_graph_cache_stats')
+        return {'graphs_captured': a.value, 'graph_launches': b.value}
+
+
 def clip_scores(feat, text_features, stream=None):
     """-> (probs [n,K] f32, top1 [n] int32, top1_score [n] f32), clip_utils.py:42-61."""
     n, dim = feat.shape

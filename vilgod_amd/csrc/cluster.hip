@@ -38,6 +38,7 @@
 #define CL_LMAX 6                     // coarsest Morton-contiguous level (25.6 m cubes): 8 x 8 x 1 roots
 #define CL_PUR_LEVELS 4               // purity tables for levels 0..3 (0.4 .. 3.2 m); levels 4..6 were measured: no gain
 #define CL_LEAF 48                    // nodes with at most this many points are scanned instead of subdivided
+#define CL_FIRST_BATCH 6      // Boruvka rounds queued before the first host read of the edge counter
 #define CL_STACK 64
 #define CL_K 16                       // neighbours kept (k-th other point = entry k, entry 0 is the point itself)
 
@@ -373,6 +374,7 @@ __global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ cou
                             double* __restrict__ pt_lb) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { comp[i] = i; pt_b[i] = -1; pt_lb[i] = 0.0; }
+    if (i == 0) counter[1] = 0;
     if (i == 0) counter[0] = 0;
 }
 
@@ -381,7 +383,8 @@ __global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ cou
 // points that do have to search again (their candidate was absorbed) prune against a tight bound from the first node on.
 // Without this every late round -- few, large components -- started all its traversals unbounded (3-4 ms per round).
 __global__ void k_cl_b_seed(int n, const int* __restrict__ comp, int* __restrict__ pt_b,
-                            const unsigned long long* __restrict__ pt_w, unsigned long long* __restrict__ best_w) {
+                            const unsigned long long* __restrict__ pt_w, unsigned long long* __restrict__ best_w, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int b = pt_b[a];
@@ -393,7 +396,8 @@ __global__ void k_cl_b_seed(int n, const int* __restrict__ comp, int* __restrict
 
 __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned long long* __restrict__ best_w,
                                   unsigned long long* __restrict__ best_d, unsigned long long* __restrict__ best_e,
-                                  int* __restrict__ sel_a) {
+                                  int* __restrict__ sel_a, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     best_w[i] = CL_NONE;
@@ -409,7 +413,8 @@ __device__ __forceinline__ size_t cl_pur_off(int l) {   // offset of level l ins
 }
 
 __global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ comp,
-                              int* __restrict__ cell_comp) {
+                              int* __restrict__ cell_comp, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned int c = code_s[i];
@@ -423,7 +428,8 @@ __global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, co
 
 // level l >= 1 from level l-1: thread per OCCUPIED level-l cell (first point of the cell)
 __global__ void k_cl_b_purity_up(int n, int l, const unsigned int* __restrict__ code_s, const int* __restrict__ cs,
-                                 int* __restrict__ cell_comp) {
+                                 int* __restrict__ cell_comp, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned int key = code_s[i] >> (3 * l);
@@ -457,7 +463,8 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      unsigned long long* __restrict__ pt_w,
                                                      unsigned long long* __restrict__ pt_d,
                                                      unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b,
-                                                     double* __restrict__ pt_lb, int* __restrict__ dbg_scan) {
+                                                     double* __restrict__ pt_lb, int* __restrict__ dbg_scan, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     __shared__ unsigned int stack[CL_STACK * 256];
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
@@ -595,7 +602,8 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
 // per component: smallest w (atomicMin in the search), then smallest d2 among those, then smallest id key among those
 __global__ void k_cl_b_select_d(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
                                 const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_d,
-                                unsigned long long* __restrict__ best_d) {
+                                unsigned long long* __restrict__ best_d, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
@@ -604,7 +612,8 @@ __global__ void k_cl_b_select_d(int n, const int* __restrict__ comp, const unsig
 __global__ void k_cl_b_select(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
                               const unsigned long long* __restrict__ best_d, const unsigned long long* __restrict__ pt_w,
                               const unsigned long long* __restrict__ pt_d, const unsigned long long* __restrict__ pt_key,
-                              unsigned long long* __restrict__ best_e) {
+                              unsigned long long* __restrict__ best_e, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
@@ -614,7 +623,8 @@ __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned 
                             const unsigned long long* __restrict__ best_d, const unsigned long long* __restrict__ best_e,
                             const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_d,
                             const unsigned long long* __restrict__ pt_key, const int* __restrict__ pt_b,
-                            int* __restrict__ sel_a, int* __restrict__ sel_b) {
+                            int* __restrict__ sel_a, int* __restrict__ sel_b, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
@@ -624,7 +634,8 @@ __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned 
     }
 }
 __global__ void k_cl_b_link(int n, const int* __restrict__ comp, const int* __restrict__ sel_a,
-                            const int* __restrict__ sel_b, int* __restrict__ parent) {
+                            const int* __restrict__ sel_b, int* __restrict__ parent, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     if (comp[c] != c) return;
@@ -635,7 +646,8 @@ __global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __re
                             const int* __restrict__ sel_a, const int* __restrict__ sel_b,
                             const unsigned long long* __restrict__ best_w, const int* __restrict__ perm,
                             int* __restrict__ parent2, int* __restrict__ counter, int* __restrict__ mst_a,
-                            int* __restrict__ mst_b, unsigned long long* __restrict__ mst_w) {
+                            int* __restrict__ mst_b, unsigned long long* __restrict__ mst_w, const int* __restrict__ flags) {
+    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     if (comp[c] != c) return;
@@ -653,8 +665,10 @@ __global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __re
     mst_w[k] = best_w[c];
 }
 
-__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2) {
+__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2, int* __restrict__ flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) flags[1] = flags[0] >= n - 1;    // read by every kernel of the NEXT round (stream order): rounds are queued in
+                                                // batches without a host read in between, a round after the last one is a no-op
     if (i >= n) return;
     int r = comp[i];
     while (parent2[r] != r) r = parent2[r];
@@ -878,7 +892,7 @@ template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
     hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                        h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                       h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg);
+                       h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter);
 }
 
 extern "C" {
@@ -961,47 +975,63 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
     VG_LAUNCH_CHECK();
     // ---- Boruvka ----
     hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b, h->d_pt_lb);
-    int rounds = 0, edges = 0;
-    while (edges < n - 1) {
-        if (++rounds > 64) {
-            fprintf(stderr, "[vilgod_hip] vg_cluster_mst: Boruvka did not converge (%d of %d edges)\n", edges, n - 1);
-            return VG_ERR_HIP;
-        }
-        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a);
-        if (rounds > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w);
-        hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp);
+    // Rounds are queued in batches WITHOUT a host read in between: every round's kernels start with `if (flags[1]) return`,
+    // and k_cl_b_compress sets flags[1] once the n - 1 edges are out, so a round queued after the last needed one costs a
+    // dozen empty launches.  The edge count of every round is copied to its own pinned slot; the host reads them once per batch
+    // (first batch: CL_FIRST_BATCH rounds -- 150k-point frames need 6-8 -- then one round at a time).
+    int rounds = 0, edges = 0, needed = 0;
+    int* const flags = h->d_counter;
+    auto one_round = [&](int r) {
+        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags);
+        if (r > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
+        hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);
         for (int l = 1; l < CL_PUR_LEVELS; ++l)
-            hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp);
+            hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp, flags);
         if (dim == 3) cl_launch_search<3>(h, n, st);
         else if (dim == 4) cl_launch_search<4>(h, n, st);
         else cl_launch_search<5>(h, n, st);
-        hipLaunchKernelGGL(k_cl_b_select_d, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_best_d);
+        hipLaunchKernelGGL(k_cl_b_select_d, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_best_d, flags);
         hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_best_e);
+                           h->d_pt_key, h->d_best_e, flags);
         hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_pt_w,
-                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b);
-        hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent);
+                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b, flags);
+        hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent, flags);
         hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent, h->d_sel_a, h->d_sel_b, h->d_best_w,
-                           h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w);
-        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2);
-        VG_CHECK(hipMemcpyAsync(h->h_counter, h->d_counter, 4, hipMemcpyDeviceToHost, st));
+                           h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, flags);
+        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags);
+        return hipMemcpyAsync(h->h_counter + ((r - 1) & 15), h->d_counter, 4, hipMemcpyDeviceToHost, st);
+    };
+    while (edges < n - 1) {
+        const int batch = (rounds == 0 && !h->d_dbg) ? CL_FIRST_BATCH : 1;
+        const int first = rounds + 1;
+        for (int b = 0; b < batch; ++b) {
+            if (++rounds > 64) {
+                fprintf(stderr, "[vilgod_hip] vg_cluster_mst: Boruvka did not converge (%d of %d edges)\n", edges, n - 1);
+                return VG_ERR_HIP;
+            }
+            VG_CHECK(one_round(rounds));
+        }
         VG_CHECK(hipStreamSynchronize(st));
-        int e = h->h_counter[0];
-        if (h->d_dbg) {
-            std::vector<int> sc(n);
-            (void)hipMemcpy(sc.data(), h->d_dbg, 4 * (size_t)n, hipMemcpyDeviceToHost);
-            std::sort(sc.begin(), sc.end());
-            long long tot = 0; int active = 0;
-            for (int v : sc) { tot += v; active += v > 0; }
-            fprintf(stderr, "[cluster dbg] round %d: edges %d -> %d, searching threads %d, scanned points: total %lld, median %d, p99 %d, p99.9 %d, max %d\n",
-                    rounds, edges, e, active, tot, sc[n / 2], sc[(size_t)n * 99 / 100], sc[(size_t)n * 999 / 1000], sc[n - 1]);
+        for (int r = first; r <= rounds; ++r) {
+            const int e = h->h_counter[(r - 1) & 15];
+            if (h->d_dbg) {
+                std::vector<int> sc(n);
+                (void)hipMemcpy(sc.data(), h->d_dbg, 4 * (size_t)n, hipMemcpyDeviceToHost);
+                std::sort(sc.begin(), sc.end());
+                long long tot = 0; int active = 0;
+                for (int v : sc) { tot += v; active += v > 0; }
+                fprintf(stderr, "[cluster dbg] round %d: edges %d -> %d, searching threads %d, scanned points: total %lld, median %d, p99 %d, p99.9 %d, max %d\n",
+                        r, edges, e, active, tot, sc[n / 2], sc[(size_t)n * 99 / 100], sc[(size_t)n * 999 / 1000], sc[n - 1]);
+            }
+            if (e == edges && !needed) {
+                fprintf(stderr, "[vilgod_hip] vg_cluster_mst: no progress in round %d (%d of %d edges)\n", r, e, n - 1);
+                return VG_ERR_HIP;
+            }
+            edges = e;
+            if (edges >= n - 1 && !needed) needed = r;
         }
-        if (e == edges) {
-            fprintf(stderr, "[vilgod_hip] vg_cluster_mst: no progress in round %d (%d of %d edges)\n", rounds, e, n - 1);
-            return VG_ERR_HIP;
-        }
-        edges = e;
     }
+    rounds = needed;
     if (h_rounds) *h_rounds = rounds;
     // ---- sort edges by weight ----
     const int m = n - 1;

@@ -1937,6 +1937,83 @@ int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_
 }
 
 int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
+                   int32_t* d_top1, float* d_top1_score, void* stream);
+
+/* ---- captured classification (SURVEY 7 step 7 / BASELINE config 5: hipGraph-captured loop) -----------------------------------
+ * The launch-heavy, shape-stable part of a frame -- the ~150 kernels of vg_vit_encode + vg_clip_scores -- as ONE hipGraph per
+ * distinct crop count, captured on first use and replayed afterwards.  The cache belongs to one worker (one stream, one set of
+ * persistent buffers: patches, workspace, features, scores): the key is the crop count plus every pointer baked into the nodes. */
+struct vg_graph_key {
+    int n_crops, input_kind, dim, n_classes;
+    const void *crops, *ws, *feat, *text, *probs, *top1, *score;
+    bool operator<(const vg_graph_key& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+struct vg_graph_cache {
+    std::map<vg_graph_key, hipGraphExec_t> graphs;
+    long captured = 0, replayed = 0;
+};
+
+int vg_graph_cache_create(vg_graph_cache** out) {
+    if (!out) return VG_ERR_ARG;
+    *out = new vg_graph_cache();
+    return VG_OK;
+}
+
+void vg_graph_cache_destroy(vg_graph_cache* c) {
+    if (!c) return;
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    delete c;
+}
+
+int vg_graph_cache_stats(const vg_graph_cache* c, int64_t* h_captured, int64_t* h_replayed) {
+    if (!c) return VG_ERR_ARG;
+    if (h_captured) *h_captured = c->captured;
+    if (h_replayed) *h_replayed = c->replayed;
+    return VG_OK;
+}
+
+int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
+                          const float* d_text, int dim, int n_classes, float* d_probs, int32_t* d_top1, float* d_top1_score, void* stream) {
+    if (!v || !c || n_crops <= 0 || !stream) return VG_ERR_ARG;          // capture needs a real (non-default) stream
+    // the first encode of a process runs as plain launches: it sets the kernels' dynamic-LDS attributes (hipFuncSetAttribute), which
+    // must not happen inside a capture
+    static bool warmed = false;
+    if (v->prof_on || !warmed) {                                        // event pairs cannot live in a graph: plain launches while profiling
+        warmed = true;
+        const int rc = vg_vit_encode(v, d_crops, input_kind, n_crops, d_workspace, d_feat, stream);
+        return rc ? rc : vg_clip_scores(d_feat, n_crops, dim, d_text, n_classes, d_probs, d_top1, d_top1_score, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    vg_graph_key key;
+    memset(&key, 0, sizeof(key));
+    key.n_crops = n_crops; key.input_kind = input_kind; key.dim = dim; key.n_classes = n_classes;
+    key.crops = d_crops; key.ws = d_workspace; key.feat = d_feat; key.text = d_text; key.probs = d_probs; key.top1 = d_top1; key.score = d_top1_score;
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        // thread-local capture mode: the other workers keep launching on their streams meanwhile
+        hipGraph_t graph = nullptr;
+        VG_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int rc = vg_vit_encode(v, d_crops, input_kind, n_crops, d_workspace, d_feat, stream);
+        if (!rc) rc = vg_clip_scores(d_feat, n_crops, dim, d_text, n_classes, d_probs, d_top1, d_top1_score, stream);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc || e != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            fprintf(stderr, "[vilgod_hip] vg_vit_classify_graph: capture failed (rc %d, %s)\n", rc, hipGetErrorString(e));
+            return rc ? rc : VG_ERR_HIP;
+        }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        VG_CHECK(e);
+        it = c->graphs.emplace(key, exec).first;
+        c->captured++;
+    }
+    VG_CHECK(hipGraphLaunch(it->second, st));
+    c->replayed++;
+    return VG_OK;
+}
+
+int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int n_classes, float* d_probs,
                    int32_t* d_top1, float* d_top1_score, void* stream) {
     if (n <= 0) return VG_OK;
     if (!d_feat || !d_text || !d_probs || !d_top1 || !d_top1_score || n_classes <= 0 || n_classes > 64) return VG_ERR_ARG;

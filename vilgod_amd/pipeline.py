@@ -61,7 +61,7 @@ def _get(cfg, key, default=None):
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
                  clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
-                 box_mode='reference', box_workers=4):
+                 box_mode='reference', box_workers=4, vit_graph=True):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -94,6 +94,9 @@ class PseudoLabelPipeline:
             raise ValueError("box_mode: 'reference' (the reference's boxes: qhull vertex order, closing edge dropped) or 'fast' "
                              "(GPU hull + rectangle over all edges)")
         self.box_mode = box_mode
+        # hipGraph-captured classification (BASELINE config 5): one graph per distinct crop count, per worker (clip_wrapper.GraphClassifier)
+        self.vit_graph = bool(vit_graph)
+        self._graph_cls = None
         self.box_workers = int(box_workers)      # helper processes for the host part of the reference box mode (0 = in the frame's thread)
         self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
@@ -113,6 +116,7 @@ class PseudoLabelPipeline:
         w.clip = self.clip.view()                # shared read-only weights, own workspace
         w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         w._xy_pinned = None
+        w._graph_cls = None
         w.timings = {}
         w.stream = torch.cuda.Stream(device=self.device)
         from concurrent.futures import ThreadPoolExecutor
@@ -278,8 +282,17 @@ class PseudoLabelPipeline:
         enc = self.clip.encoder
         if self.vit_dtype == 'f16' and enc.cfg['patch'] == 16 and enc.cfg['resolution'] == 224:
             # the renderer writes the patch-embedding GEMM's A operand directly (no CHW crops, no im2col pass)
+            from .clip_wrapper import clip_scores, GraphClassifier
+            if self.vit_graph and n > 0 and torch.cuda.current_stream(self.device).cuda_stream != 0:
+                # captured loop: the ViT encode + scores replay as one hipGraph (per crop count) on this worker's persistent buffers;
+                # the outputs are cloned because the buffers are rewritten by the worker's next frame
+                if self._graph_cls is None:
+                    self._graph_cls = GraphClassifier(enc, self.clip.text_features, max_crops=max(512, n))
+                g = self._graph_cls
+                self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16', out_buf=g.patch_buffer(n))
+                probs, top1, score = g.classify(n)
+                return probs.clone(), top1.clone(), score.clone()
             patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16')
-            from .clip_wrapper import clip_scores
             return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
         crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='f16' if self.vit_dtype == 'f16' else 'f32')
         return self.clip.predict_probs(crops)

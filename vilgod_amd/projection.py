@@ -75,7 +75,7 @@ class RealisticProjection:
         self._d_timg = torch.from_numpy(np.ascontiguousarray(t_img)).to(self.device)
 
     # -- frame-level fused path -----------------------------------------------------------------
-    def render_frame(self, points, index, seg_off, transform_to_ego, out='f16', stream=None):
+    def render_frame(self, points, index, seg_off, transform_to_ego, out='f16', stream=None, out_buf=None):
         """points: [N,>=3] float32 CUDA tensor (ref frame, `points_ref_wo_ground`);
         index: [Ptot] int32 packed cluster point indices (cluster after cluster) or None;
         seg_off: [C+1] int32 CUDA; transform_to_ego: 4x4 float64 (numpy or tensor).
@@ -93,9 +93,14 @@ class RealisticProjection:
         elif kind == OUT_F16:
             result = torch.empty((n, 3, 224, 224), dtype=torch.float16, device=dev)
         elif kind == OUT_PATCH16:
-            # ViT-B/16 patch rows; rows padded to the GEMM's 256-row tile (padding rows are never written: zeros)
+            # ViT-B/16 patch rows; rows padded to the GEMM's 256-row tile (padding rows are never written: zeros, or -- in a
+            # caller-owned persistent buffer `out_buf` -- finite rows of an earlier frame; GEMM rows are independent)
             rows = (n * 196 + 255) // 256 * 256
-            result = torch.zeros((rows, 768), dtype=torch.float16, device=dev)
+            if out_buf is not None:
+                assert out_buf.dtype == torch.float16 and out_buf.shape[1] == 768 and out_buf.shape[0] >= rows
+                result = out_buf
+            else:
+                result = torch.zeros((rows, 768), dtype=torch.float16, device=dev)
         else:
             result = torch.empty((n, 110, 110), dtype=torch.float32, device=dev)
         if n_clusters == 0 or ptot == 0:
