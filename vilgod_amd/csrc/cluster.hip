@@ -291,10 +291,11 @@ template <int DIM>
 __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                  const ClGrid* __restrict__ gp, const int* __restrict__ cs,
                                                  const unsigned int* __restrict__ cell_e, int k,
-                                                 double* __restrict__ core2) {
+                                                 double* __restrict__ core2, int* __restrict__ dbg_scan) {
     __shared__ unsigned int stack[CL_STACK * 256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    int scanned = 0;                                  // VG_CLUSTER_DEBUG: pair distances evaluated by this point
     unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[i];
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             if (j0 == j1) continue;
             if (DIM >= 4 && l < CL_PUR_LEVELS && nb2 + cl_e_gap2(cell_e[cl_pur_off_fwd(l) + (c0 >> (3 * l))], qe) >= h[k]) continue;
             if (l == 0 || j1 - j0 <= CL_LEAF) {
+                scanned += j1 - j0;
                 for (int jb = j0; jb < j1; jb += 4) {                       // four independent loads per trip
                     float4 pj[4];
 #pragma unroll
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
         }
     }
     core2[i] = h[k];
+    if (dbg_scan) dbg_scan[i] = scanned;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -886,7 +889,18 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
 template <int DIM>
 static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
     hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, h->d_cell_e, k, h->d_core2);
+                       h->d_cell_start, h->d_cell_e, k, h->d_core2, h->d_dbg);
+    if (h->d_dbg) {
+        // VG_CLUSTER_DEBUG=1: pairs evaluated / pairs needed: the exact answer needs n * k distances
+        std::vector<int> sc(n);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(sc.data(), h->d_dbg, 4 * (size_t)n, hipMemcpyDeviceToHost);
+        long long tot = 0;
+        for (int v : sc) tot += v;
+        std::sort(sc.begin(), sc.end());
+        fprintf(stderr, "[cluster dbg] core distances: n %d, k %d, pair distances evaluated %lld = %.1f x the %lld needed (n*k); per point median %d, p99 %d, max %d\n",
+                n, k, tot, (double)tot / ((double)n * k), (long long)n * k, sc[n / 2], sc[(size_t)n * 99 / 100], sc[n - 1]);
+    }
 }
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {

@@ -315,9 +315,13 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
         }
         __syncthreads();
         // Conv3d (1,3,3) zero pad, FMA chain in row-major tap order; running max over depth.
+        // (the thread id is made opaque per slice: left visible, the compiler hoists the 12 pixels' row / column / border terms out of
+        // the slice loop and keeps them live across the whole kernel -- 46 spilled registers, their traffic doubled the bytes written)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int k = 0; k < ACC_PER_THREAD; ++k) {
-            int q = tid + k * RT;
+            int q = tq + k * RT;
             if (q < GO * GO) {
                 int i = q / GO, j = q - i * GO;
                 float s[9];
@@ -395,7 +399,12 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
             iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
             u[e] = (unsigned char)iv;
         }
-        if (a.out_kind == 0) {
+        if (a.out_kind == 4) {
+            // patch rows: stage the quantised image in LDS (the 112 x 112 float slice buffer is free now and holds exactly
+            // 224 x 224 bytes); the stores happen below in OUTPUT order so that they leave as whole 128-byte lines
+            *(unsigned int*)((unsigned char*)S + i * OUT + j0) = (unsigned int)u[0] | ((unsigned int)u[1] << 8) | ((unsigned int)u[2] << 16) |
+                                                                 ((unsigned int)u[3] << 24);
+        } else if (a.out_kind == 0) {
             unsigned char* o8 = (unsigned char*)a.out + (crop * OUT * OUT + (size_t)i * OUT + j0) * 3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -411,19 +420,6 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
                                         a.lut[ch * 256 + u[3]]);
                 *(float4*)(of + (size_t)ch * OUT * OUT) = f4;
             }
-        } else if (a.out_kind == 4) {
-            // 4 consecutive j stay inside one 16-wide patch row (j0 % 4 == 0): one 8-byte store per channel
-            const int py = i >> 4, pi = i & 15, px = j0 >> 4, pj = j0 & 15;
-            __half* oh = (__half*)a.out + ((crop * 196 + (size_t)(py * 14 + px)) * 768 + pi * 16 + pj);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                __half2 h01 = __floats2half2_rn(a.lut[ch * 256 + u[0]], a.lut[ch * 256 + u[1]]);
-                __half2 h23 = __floats2half2_rn(a.lut[ch * 256 + u[2]], a.lut[ch * 256 + u[3]]);
-                uint2 pk;
-                pk.x = *(unsigned int*)&h01;
-                pk.y = *(unsigned int*)&h23;
-                *(uint2*)(oh + ch * 256) = pk;
-            }
         } else {
             __half* oh = (__half*)a.out + crop * 3 * OUT * OUT + (size_t)i * OUT + j0;
 #pragma unroll
@@ -435,6 +431,28 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
                 pk.y = *(unsigned int*)&h23;
                 *(uint2*)(oh + (size_t)ch * OUT * OUT) = pk;
             }
+        }
+    }
+    if (a.out_kind == 4) {
+        // fp16 patch rows [crop*196 + py*14 + px][ch*256 + pi*16 + pj] (the conv1 GEMM's A operand).  Work item = 4 pixels
+        // = 8 output bytes, enumerated in output order: 192 items per patch row (3 channels x 16 pixel rows x 4), so the 64
+        // lanes of a wave write 512 contiguous bytes -- four whole 128-byte lines -- instead of 32-byte pieces of 16 lines
+        // (written per pixel row, the pieces reached HBM as partial lines: 200 MB moved for 98 MB of rows, r01 PMC).
+        __syncthreads();
+        const unsigned char* U = (const unsigned char*)S;
+        __half* ob = (__half*)a.out + crop * 196 * 768;
+        for (int q = tid; q < 196 * 192; q += RT) {
+            const int p = q / 192, rem = q - p * 192;
+            const int ch = rem >> 6, pi = (rem >> 2) & 15, pj4 = rem & 3;
+            const int py = p / 14, px = p - py * 14;
+            const unsigned int u4 = *(const unsigned int*)(U + (py * 16 + pi) * OUT + px * 16 + pj4 * 4);
+            const float* lut = a.lut + ch * 256;
+            __half2 h01 = __floats2half2_rn(lut[u4 & 255u], lut[(u4 >> 8) & 255u]);
+            __half2 h23 = __floats2half2_rn(lut[(u4 >> 16) & 255u], lut[u4 >> 24]);
+            uint2 pk;
+            pk.x = *(unsigned int*)&h01;
+            pk.y = *(unsigned int*)&h23;
+            *(uint2*)(ob + (size_t)p * 768 + rem * 4) = pk;
         }
     }
 }
