@@ -1012,8 +1012,6 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 #define VG_PROF_MAX 4096
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
-    bool ln_fused = false;           // dtype 1, fp32 stream, width % 256 == 0: ln_2 / the next block's ln_1 are computed by the residual GEMMs
-                                     // (k_gemm_f16_pp64 LNA); VG_VIT_NO_LNFUSE=1 keeps the separate LayerNorm launches
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1228,23 +1226,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict_
 //   by group 0 in its LOAD_{j+1} (3-deep ring -> at least one interval of lead).
 //   The second k32 sub-step's fragments are read during the first sub-step's MFMAs into the registers those have
 //   just consumed.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that ends its MMA segment.
-//   LNA (EPI_BIAS_RESID only): the LayerNorm that follows the residual update (ln_2 after out_proj, the next block's ln_1 after
-//   c_proj; model.py:190-191) is done by the LAST of the N / 256 workgroups that update one 256-row tile of the stream -- the tile
-//   order keeps those column tiles next to each other in time, so nobody waits.  Hand-off (cdna_hip_programming.md Guideline 16,
-//   the write-through form): every workgroup stores its part of the stream with sc1 (write-through) 16-byte stores, every wave
-//   drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to the row tile's counter (agent scope); the
-//   workgroup whose add returns N / 256 - 1 re-reads the 256 x N rows with sc1 loads (nothing of them is read any other way),
-//   normalises them with k_layernorm's arithmetic and writes the fp16 operand of the next GEMM.  This replaces the separate
-//   LayerNorm launch and its 197 MB read of the stream per residual GEMM.  Correct for ANY placement of the workgroups.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int EPI, bool TRACE = false, bool PERSIST = false, bool LNA = false>
+template <int EPI, bool TRACE = false, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
-                                                          long long* __restrict__ trace = nullptr, int* __restrict__ ln_cnt = nullptr,
-                                                          const float* __restrict__ ln_w = nullptr, const float* __restrict__ ln_b = nullptr,
-                                                          f16* __restrict__ ln_out = nullptr, int m_valid = 0) {
-    static_assert(!LNA || (EPI == EPI_BIAS_RESID && !PERSIST), "LNA: fp32 residual epilogue");
+                                                          long long* __restrict__ trace = nullptr) {
     constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;
     constexpr int XBUF = 32768, WBASE = 2 * XBUF, WBUF = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1416,8 +1402,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
             }
         }
     } else {
-        __amdgpu_buffer_rsrc_t xrs;
-        if (LNA) xrs = __builtin_amdgcn_make_buffer_rsrc((void*)resid, 0, (int)((size_t)M * ldc * 4), 0x00020000);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half) __syncthreads();
@@ -1456,75 +1440,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
                     const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
                     if (EPI == EPI_BIAS_RESID) {
                         v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
-                        if (LNA) {      // write-through: the row tile's last workgroup reads these bytes back with sc1 loads
-                            const u32x4 raw = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                            __builtin_amdgcn_raw_buffer_store_b128(raw, xrs, (int)(off * 4), 0, 16);
-                        } else
-                            *(float4*)(resid + off) = v;
+                        *(float4*)(resid + off) = v;
                     } else {
                         *(float4*)((float*)Cout + off) = v;
-                    }
-                }
-            }
-        }
-        if (LNA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // EVERY storing wave drains its write-through stores
-            __syncthreads();                                           // (also: nobody reads the epilogue's LDS image any more)
-            int* const lastw = (int*)smem;                             // the one LDS array: no second __shared__ object
-            if (tid == 0) {
-                const int old_ = __hip_atomic_fetch_add(ln_cnt + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last_ = old_ == N / BN - 1;
-                if (last_) __hip_atomic_store(ln_cnt + tm, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                *lastw = last_;
-            }
-            __syncthreads();
-            if (*lastw) {
-                // ---- LayerNorm of the 256 rows (fp32 statistics, model.py:157-163), k_layernorm's arithmetic; wave w: rows [32 w, +32)
-                const int nv = N >> 8;                                 // float4 per lane, <= 4
-                float4 w4[4], b4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < nv) { w4[i] = *(const float4*)(ln_w + (i * 64 + lane) * 4); b4[i] = *(const float4*)(ln_b + (i * 64 + lane) * 4); }
-                constexpr int LNB = 4;                                 // rows per batch: their loads go out together
-#pragma unroll 1
-                for (int bt = 0; bt < 32 / LNB; ++bt) {
-                    float4 v[LNB][4];
-#pragma unroll
-                    for (int q = 0; q < LNB; ++q) {
-                        const int row = m0 + wave * 32 + bt * LNB + q;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i < nv) {
-                                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(((size_t)row * ldc + (i * 64 + lane) * 4) * 4), 0, 16);
-                                v[q][i] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w));
-                            }
-                    }
-#pragma unroll
-                    for (int q = 0; q < LNB; ++q) {
-                        const int row = m0 + wave * 32 + bt * LNB + q;
-                        float s_ = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i < nv) s_ += (v[q][i].x + v[q][i].y) + (v[q][i].z + v[q][i].w);
-                        const float mean = vg_wave_sum(s_) / (float)N;
-                        float q_ = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i < nv) {
-                                const float a = v[q][i].x - mean, b = v[q][i].y - mean, c = v[q][i].z - mean, d = v[q][i].w - mean;
-                                q_ += (a * a + b * b) + (c * c + d * d);
-                            }
-                        const float rstd = rsqrtf(vg_wave_sum(q_) / (float)N + 1e-5f);
-                        if (row < m_valid) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (i < nv) {
-                                    const float o0 = (v[q][i].x - mean) * rstd * w4[i].x + b4[i].x, o1 = (v[q][i].y - mean) * rstd * w4[i].y + b4[i].y;
-                                    const float o2 = (v[q][i].z - mean) * rstd * w4[i].z + b4[i].z, o3 = (v[q][i].w - mean) * rstd * w4[i].w + b4[i].w;
-                                    const f16x4 h4 = {(f16)o0, (f16)o1, (f16)o2, (f16)o3};
-                                    *(f16x4*)(ln_out + (size_t)row * N + (i * 64 + lane) * 4) = h4;
-                                }
-                        }
                     }
                 }
             }
@@ -1558,26 +1476,6 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
-// out_proj / c_proj with the following LayerNorm fused in (k_gemm_f16_pp64<EPI_BIAS_RESID, ., ., LNA>): resid (fp32 [M,N]) += X Wt^T + bias,
-// then ln_out (fp16 [m_valid,N]) = LayerNorm(resid rows) * ln_w + ln_b by each row tile's last workgroup.  d_cnt: M / 256 zeroed counters.
-static int launch_gemm_pp64_ln(const void* X, const void* Wt, const float* bias, float* resid, int M, int N, int K, int* d_cnt,
-                               const float* ln_w, const float* ln_b, void* ln_out, int m_valid, hipStream_t st) {
-    if (M % 256 || N % 256 || N > 1024 || K % 64 || K / 64 < 2 || !d_cnt || !ln_w || !ln_b || !ln_out || (size_t)M * N * 4 >= 0x7fffffffu)
-        return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp64<EPI_BIAS_RESID, false, false, true>;
-    const int lds = 5 * 32768;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    const int ntn = N / 256;
-    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, (void*)nullptr, resid, M, N, K, N,
-                       gemm_chunk_tiles_256(ntn), (long long*)nullptr, d_cnt, ln_w, ln_b, (f16*)ln_out, m_valid);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
-
 template <int EPI, bool TRACE = false, bool PERSIST = false>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr) {
@@ -1600,7 +1498,7 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
         grid = (grid + 7) / 8 * 8;                 // slot s of XCD x = block 8 s + x
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, cwt, trace, (int*)nullptr, (const float*)nullptr, (const float*)nullptr, (f16*)nullptr, 0);
+                       ldc, cwt, trace);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
@@ -1716,7 +1614,6 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
     v->out_dim = out_dim; v->dtype = dtype; v->T = T;
     v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
-    v->ln_fused = dtype == 1 && !v->resid_h && width % 256 == 0 && !getenv("VG_VIT_NO_LNFUSE") && !getenv("VG_GEMM_V4");
     *out = v;
     return VG_OK;
 }
@@ -1765,8 +1662,7 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops) {
                 + Mp * (3 * W + 256) * es   // qkv (padded row stride)
                 + Mp * 4 * W * es     // mlp
                 + Pp * Kp * es        // patches
-                + Pp * W * 4          // patch-embed output (f32)
-                + 8192;               // arrival counters of the fused LayerNorm (one int per 256-row tile)
+                + Pp * W * 4;         // patch-embed output (f32)
     return b + 1024;
 }
 
@@ -1789,10 +1685,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     void* qkv = ws;                   ws += Mp * (3 * W + 256) * es;
     void* mlp = ws;                   ws += Mp * 4 * W * es;
     void* patches = ws;               ws += Pp * Kp * es;
-    float* pe = (float*)ws;           ws += Pp * W * 4;
-    int* ln_cnt = (int*)ws;           // Mp / 256 arrival counters (<= 2048)
-    const bool lnf = v->ln_fused && Mp / 256 <= 2048 && (size_t)Mp * W * 4 < 0x7fffffffu;
-    if (lnf) VG_CHECK(hipMemsetAsync(ln_cnt, 0, 8192, st));       // every call: a stale count would skip or double a LayerNorm
+    float* pe = (float*)ws;
 
     auto need = [&](const std::string& n) -> void* {
         auto it = v->w.find(n);
@@ -1843,18 +1736,6 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                            (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp, lw1, lb1, ln1_done ? (f16*)h : (f16*)nullptr);
     }
     VG_LAUNCH_CHECK();
-    // a residual GEMM with the following LayerNorm fused in; same event-pair bookkeeping as launch_gemm
-    auto gemm_resid_ln = [&](const void* Xop, const void* Wop, const float* bias, int K, const float* lnw, const float* lnb) -> int {
-        const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
-        if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
-        const int r = launch_gemm_pp64_ln(Xop, Wop, bias, x, (int)Mp, W, K, ln_cnt, lnw, lnb, h, (int)M, st);
-        if (prof) {
-            (void)hipEventRecord(v->prof_ev[2 * v->prof_n + 1], st);
-            v->prof_kind[v->prof_n] = 1;
-            v->prof_flops[v->prof_n++] = 2.0 * (double)Mp * (double)W * (double)K;
-        }
-        return r;
-    };
     for (int l = 0; l < L; ++l) {
         std::string p = "transformer.resblocks." + std::to_string(l) + ".";
         const char* names[] = {"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
@@ -1868,8 +1749,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                 return VG_ERR_ARG;
             }
         }
-        if ((l == 0 && ln1_done) || (l > 0 && lnf)) {
-            // h already holds ln_1(x): written by k_embed_lnpre (block 0) or by the previous block's c_proj (fused LayerNorm)
+        if (l == 0 && ln1_done) {
+            // h already holds ln_1(x) of block 0 (k_embed_lnpre)
         } else if (rh)
             hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[0], (const float*)wp[1], (f16*)h, (int)M, W, 1);
         else if (v->dtype == 1)
@@ -1900,14 +1781,10 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             hipLaunchKernelGGL(k_attention_f32, dim3(n_crops * H), dim3(256), lds, st, (const float*)qkv, (float*)h, T, W, H);
         }
         VG_LAUNCH_CHECK();
-        // out_proj (+ ln_2 when fused: h is the A operand of every column tile of a row tile and is overwritten only after the
-        // last of them has finished its K loop -- the LayerNorm runs behind the arrival counter)
-        rc = lnf ? gemm_resid_ln(h, wp[4], (const float*)wp[5], W, (const float*)wp[6], (const float*)wp[7])
-             : rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
-                  : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
+        rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
+                : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
         if (rc) return rc;
-        if (lnf) {
-        } else if (rh)
+        if (rh)
             hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
         else if (v->dtype == 1)
             hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
@@ -1916,16 +1793,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         VG_LAUNCH_CHECK();
         rc = launch_gemm<EPI_BIAS_GELU>(v, h, wp[8], (const float*)wp[9], mlp, nullptr, (int)Mp, 4 * W, W, st);
         if (rc) return rc;
-        const float* nlw = nullptr, *nlb = nullptr;
-        if (lnf && l + 1 < L) {
-            const std::string pn = "transformer.resblocks." + std::to_string(l + 1) + ".";
-            nlw = (const float*)need(pn + "ln_1.weight");
-            nlb = (const float*)need(pn + "ln_1.bias");
-            if (!nlw || !nlb) return VG_ERR_ARG;
-        }
-        rc = nlw ? gemm_resid_ln(mlp, wp[10], (const float*)wp[11], 4 * W, nlw, nlb)                           // c_proj + the next block's ln_1
-             : rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
-                  : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
+        rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
+                : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
         if (rc) return rc;
     }
     if (rh)
