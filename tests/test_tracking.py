@@ -132,3 +132,55 @@ def test_small_pieces():
     ang = tracking.dominant_angles([0.10, 0.11, 0.12 + np.pi, 1.5, 3.0 + 2 * np.pi])
     assert len(ang) == 3 and abs(np.mean(ang) - 0.11) < 1e-9
     assert tracking.motion_vectors(np.zeros((6, 2), np.float32)) == []                        # a cluster that never moves: static path
+
+
+@pytest.mark.gpu
+def test_hip_tracked_stages_match_reference(gold, scene):
+    """N2 through the PRODUCT's GPU pieces: the cluster medians the tracker associates on come from vg_cluster_medians, the static
+    boxes of tracked clusters from PseudoLabelPipeline.fit_boxes (box_mode='reference': z extent kernel + qhull vertex order in a
+    helper process), then tracking.fit_track_boxes / propagate_labels as zero_shot_detector wires them -- against the vectors the
+    reference's own Tracker / Track / fit_bounding_boxes_simple / propagate_labels produced (track_golden.pkl)."""
+    import torch
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    frames, poses, X = scene
+    cuda = torch.device('cuda:0')
+    pipe = PseudoLabelPipeline(device=cuda, max_points=max(len(x) for x in X) + 16, clip_model_path='/nonexistent', box_mode='reference')
+    med, cnt, sbox, pts, stat = {}, {}, {}, {}, {}
+    tab = tracking.DetectionTable()
+    tr = tracking.Tracker(mode='cluster_center', max_distance=1.0, min_length=5, max_missed=3)
+    for fnr, (dets, flags) in enumerate(zip(gold['clusters'], gold['static'])):
+        keys = [(fnr, cid) for cid, _ in dets]
+        if dets:
+            index = np.concatenate([np.asarray(idx) for _, idx in dets]).astype(np.int32)
+            seg = np.r_[0, np.cumsum([len(idx) for _, idx in dets])].astype(np.int32)
+            d_X = torch.from_numpy(X[fnr]).to(cuda)
+            m = pipe.cluster_medians(d_X, torch.from_numpy(index).to(cuda), torch.from_numpy(seg).to(cuda)).cpu().numpy()
+            boxes = pipe.fit_boxes(d_X, index, seg)
+            for j, ((cid, idx), st) in enumerate(zip(dets, flags)):
+                k = (fnr, cid)
+                assert np.array_equal(m[j], np.median(X[fnr][idx], axis=0))
+                med[k], cnt[k], sbox[k], pts[k], stat[k] = m[j], len(idx), boxes[j], X[fnr][idx], st
+                tab.valid[k] = True
+        centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
+        tr.next(fnr, keys, centers, [cnt[k] for k in keys], lambda k: (med[k], cnt[k]))
+    tr.finish()
+    assert len(tr.tracks) == len(gold['tracks'])
+    for t, g in zip(tr.tracks, gold['tracks']):
+        assert t.frames == g['frames'] and [(bool(p), k[0], k[1]) for p, k in zip(t.prediction, t.source)] == g['entries']
+    to_ego = lambda f: np.linalg.inv(poses[f]) @ poses[0]
+    tracking.fit_track_boxes(tr, tab, pts.__getitem__, stat.__getitem__, to_ego, static_box_of=sbox.__getitem__, median_of=med.__getitem__)
+    for t, g in zip(tr.tracks, gold['tracks']):
+        assert t.static == g['track_static_fit']
+        assert np.allclose(entry_boxes(tab, t), g['boxes_fit'], rtol=0, atol=2e-5)
+    for fnr, (dets, cls) in enumerate(zip(gold['clusters'], gold['cls_in'])):
+        for (cid, _), (name, score) in zip(dets, cls):
+            tab.name[(fnr, cid)], tab.score[(fnr, cid)] = name, np.float32(score)
+    tracking.propagate_labels(tr, tab, lambda k: cnt[k], ['Vehicle', 'Pedestrian', 'Cyclist'], min_length=5)
+    for t, g in zip(tr.tracks, gold['tracks']):
+        assert (t.static, t.valid, t.class_label) == (g['track_static'], g['track_valid'], g['class_label'])
+        assert np.allclose(entry_boxes(tab, t), g['boxes_final'], rtol=0, atol=2e-5)
+    for fnr, (dets, fin) in enumerate(zip(gold['clusters'], gold['final'])):
+        for (cid, _), f in zip(dets, fin):
+            k = (fnr, cid)
+            assert tab.valid[k] == f['valid'] and tab.name[k] == f['name'] and tab.static_track.get(k) == f['static_track']
+            assert (f['box'] is None and k not in tab.box) or np.allclose(tab.box[k], f['box'], rtol=0, atol=2e-5)
