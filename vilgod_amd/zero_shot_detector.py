@@ -64,6 +64,7 @@ class ZeroShotDetector:
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
         self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
         self._host_X = {}                                # fnr -> points_ref_wo_ground on the host (tracking stages are host logic)
+        self._box_prefetch = {}                          # fnr -> (rows, future of their static boxes), filled by `classification`
         self.init_lidar_frames()
         try:
             self.sync_lidar_frames(mode='load')
@@ -378,6 +379,12 @@ class ZeroShotDetector:
         fine_names = np.array(p.class_list, dtype=object)
         todo = [f for f in self.my_frames if self.lidar_frame_list[f].n_detections > 0
                 and (key not in self.lidar_frame_list[f].cls or force)]
+        active = list(self.cfg.pipeline_active)
+        prefetch_boxes = (p.box_mode == 'reference' and 'fit_bounding_boxes_simple' in active
+                          and active.index('fit_bounding_boxes_simple') > active.index('classification'))
+        if prefetch_boxes:
+            for f in todo:
+                self._points_host(f)                     # host copy of points_ref_wo_ground, fetched on the caller's thread
 
         def body(pw, fnr):
             fs = self.lidar_frame_list[fnr]
@@ -387,6 +394,10 @@ class ZeroShotDetector:
                 return
             X = self._dev[fnr]['X']
             d_index, d_seg = self._cluster_lists(fnr, rows)
+            if prefetch_boxes:
+                # the static rectangles of the same clusters (box_mode='reference': a helper process per request) are computed while
+                # the GPU encodes the crops; fit_bounding_boxes_simple collects them (they do not depend on the classes)
+                self._box_prefetch[fnr] = ([int(r) for r in rows], self._fit_rows(fnr, rows, X, wait=False))
             probs, top1, score = pw.classify(X, d_index, d_seg, fs.transform_to_ego)
             self._scores[fnr] = probs
             fine = top1.cpu().numpy().reshape(len(rows), V)
@@ -428,10 +439,25 @@ class ZeroShotDetector:
             if len(rows) == 0:
                 continue
             _, X = self._ref_and_nonground(fnr)
-            jobs.append((fs, rows, self._fit_rows(fnr, rows, X, wait=False)))
+            jobs.append((fs, rows, self._boxes_of_rows(fnr, rows, X)))
         for fs, rows, fut in jobs:
             fs.boxes[rows] = fut.result()
         self.sync_lidar_frames()
+
+    def _boxes_of_rows(self, fnr, rows, X):
+        """-> object with .result() -> [len(rows),7]: from the request `classification` already sent for this frame when it covers
+        the rows, else a new request."""
+        pre = self._box_prefetch.get(fnr)
+        if pre is not None:
+            pos = {r: i for i, r in enumerate(pre[0])}
+            if all(int(r) in pos for r in rows):
+                fut, sel = pre[1], [pos[int(r)] for r in rows]
+
+                class _Sel:
+                    def result(self_inner):
+                        return np.asarray(fut.result())[sel]
+                return _Sel()
+        return self._fit_rows(fnr, rows, X, wait=False)
 
     def _fit_rows(self, fnr, rows, X, wait=True):
         """Static-branch boxes of clusters `rows` of frame fnr (pipeline.fit_boxes: reference or fast mode); wait=False returns an
@@ -529,7 +555,7 @@ class ZeroShotDetector:
         for fnr, rows in tracked.items():                # every frame's request goes out before the first answer is awaited
             rows = sorted(rows)
             _, X = self._ref_and_nonground(fnr)
-            jobs.append((fnr, rows, self._fit_rows(fnr, rows, X, wait=False)))
+            jobs.append((fnr, rows, self._boxes_of_rows(fnr, rows, X)))
         for fnr, rows, fut in jobs:
             for r, b in zip(rows, fut.result()):
                 gpu_box[(fnr, r)] = b
