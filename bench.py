@@ -249,8 +249,31 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), out
 
+    def comm_warmup():
+        """Every communication path of the timed region once before it (RCCL builds its point-to-point and collective
+        communicators lazily, seconds on first use): the state hand-off down the rank chain, the two all-gathers, the all-reduce."""
+        if dist is None:
+            return
+        from vilgod_amd._lib import lib as _l
+        cdev = 'cpu' if dist.get_backend() == 'gloo' else dev
+        buf = torch.zeros(int(_l.vg_ground_state_bytes()), dtype=torch.uint8, device=cdev)
+        if rank > 0:
+            dist.recv(buf, src=rank - 1)
+        if rank < world - 1:
+            dist.send(buf, dst=rank + 1)
+        one = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_gather([torch.zeros_like(one) for _ in range(world)], one)
+        if dist.get_backend() != 'gloo':
+            dist.all_gather_into_tensor(torch.empty((world * 8, 24), device=dev), torch.zeros((8, 24), device=dev))
+        else:
+            dist.all_gather([torch.zeros(8, 24) for _ in range(world)], torch.zeros(8, 24))
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=cdev), op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        dist.barrier()
+
     pipe.new_sequence()
     run_steps(pipe, 0, W, 0)                                   # warm-up, also builds the worker handles
+    comm_warmup()
     stage = {}
     elapsed, outs = timed_block(pipe)
     crops = sum(p.shape[0] for _, _, p in outs)
