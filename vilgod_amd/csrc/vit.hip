@@ -699,7 +699,9 @@ __global__ __launch_bounds__(256) void k_layernorm(const TI* __restrict__ x, con
 #define AT_LDS_BYTES ((AT_MAXT * AT_KLD + 64 * 228 + 7 * 32 * AT_KLD) * 2)   // 93,696 B
 #define AT_VLD 228     // V^T rows: 224 + 4 halves (456 B: 32 rows of a fragment read hit 32 different banks; the 8 x 8 transposed
                        // writes of a wave land 2-way conflicted)
-template <bool TRACE = false>
+// NKB: number of 32-key blocks, ceil(T / 32), as a compile-time constant (7 for ViT-B/16's 197 tokens): with a run-time count every
+// key block sits behind its own branch (14 scheduling regions per item); with the constant the item is straight-line code.
+template <bool TRACE = false, int NKB = 7>
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T,
                                                        int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr) {
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;      // TRACE: cycles per phase, summed over this wave's items
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     const int r31 = lane & 31, hh = lane >> 5;
     const int q0 = wave * 32;
     const int q = q0 + r31;
-    const int nkb = (T + 31) / 32;
+    constexpr int nkb = NKB;                                          // == (T + 31) / 32, checked by the launcher
     static_assert(AT_MAXT * 8 == 4 * 448, "staging split");
     // PERSISTENT workgroups (182 VGPRs and 62 KB of LDS allow one 7-wave workgroup per CU, so nothing else would hide
     // an item's load latency): item = (crop, head); the NEXT item's Q / K / V rows are fetched into registers while
@@ -818,14 +820,25 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     const float c2 = 0.125f * 1.4426950408889634f;
     const float mc = -mx * c2;
     float sum = 0.f;
+    // keys of the LAST block that exist: register group g (4 registers) holds keys 8g .. 8g+7 of the block (both lane halves), so
+    // a group with 8g >= tail is -inf throughout -> p = 0 without an exp (197 tokens: 12 of the block's 16 registers)
+    const int tail = T - 32 * (nkb - 1);
 #pragma unroll
     for (int kb = 0; kb < 7; ++kb) {
         if (kb < nkb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, mc));      // raw v_exp_f32: exp2(-inf) = 0
-                sacc[kb][r] = p;
-                sum += p;
+            for (int g = 0; g < 4; ++g) {
+                if (kb < nkb - 1 || 8 * g < tail) {
+#pragma unroll
+                    for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, mc));      // raw v_exp_f32: exp2(-inf) = 0
+                        sacc[kb][r] = p;
+                        sum += p;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 4 * g; r < 4 * g + 4; ++r) sacc[kb][r] = 0.f;
+                }
             }
         }
     }
@@ -843,6 +856,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         if (kb < nkb) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
+                if (kb == nkb - 1 && 16 * s >= tail) continue;         // k-step of keys that do not exist: P = 0 there, adds exact zeros
                 f16x8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kb][8 * s + j];
@@ -1603,6 +1617,23 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
     return VG_OK;
 }
 
+template <bool TRACE>
+static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st) {
+    const int nkb = (T + 31) / 32;
+    if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
+    const dim3 grid(items < 256 ? items : 256), block(448);
+#define VG_ATT(N)                                                                                                                  \
+    case N: {                                                                                                                      \
+        static bool attr_ = false;                                                                                                 \
+        if (!attr_) { VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<TRACE, N>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES)); attr_ = true; } \
+        hipLaunchKernelGGL((k_attention_f16<TRACE, N>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);   \
+        break; }
+    switch (nkb) { VG_ATT(1) VG_ATT(2) VG_ATT(3) VG_ATT(4) VG_ATT(5) VG_ATT(6) VG_ATT(7) }
+#undef VG_ATT
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
 extern "C" {
 
 int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int resolution, int out_dim, int dtype) {
@@ -1762,14 +1793,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         if (rc) return rc;
         if (v->dtype == 1) {
             {
-                const int items = n_crops * H;
-                static bool at_attr = false;
-                if (!at_attr) {
-                    VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
-                    at_attr = true;
-                }
-                hipLaunchKernelGGL((k_attention_f16<false>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)qkv, (f16*)h,
-                                   T, W, H, qkv_ld, items, (long long*)nullptr);
+                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st);
+                if (rc) return rc;
             }
         } else {
             size_t lds = ((size_t)T * 65 + (size_t)T * 64 + 4 * (size_t)T) * sizeof(float);
@@ -1811,13 +1836,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
  * nn.MultiheadAttention); exposed so that the kernel can be unit-tested against a plain fp32 attention. */
 int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, void* stream) {
     if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
-    const int items = n_crops * heads;
-    hipStream_t st = (hipStream_t)stream;
-    VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
-    hipLaunchKernelGGL((k_attention_f16<false>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)d_qkv, (f16*)d_out,
-                       T, W, heads, ld, items, (long long*)nullptr);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
+    return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, n_crops * heads, nullptr, (hipStream_t)stream);
 }
 
 #ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces
@@ -1871,16 +1890,8 @@ int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W
     if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
     const int items = n_crops * heads;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipFuncSetAttribute((const void*)k_attention_f16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)k_attention_f16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES);
-    if (d_trace)
-        hipLaunchKernelGGL((k_attention_f16<true>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)d_qkv, (f16*)d_out,
-                           T, W, heads, ld, items, (long long*)d_trace);
-    else
-        hipLaunchKernelGGL((k_attention_f16<false>), dim3(items < 256 ? items : 256), dim3(448), AT_LDS_BYTES, st, (const f16*)d_qkv, (f16*)d_out,
-                           T, W, heads, ld, items, (long long*)nullptr);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
+    if (d_trace) return launch_attention<true>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, items, (long long*)d_trace, st);
+    return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, items, nullptr, st);
 }
 
 #endif  // VG_DEV
