@@ -701,9 +701,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const TI* __restrict__ x, con
                        // writes of a wave land 2-way conflicted)
 // NKB: number of 32-key blocks, ceil(T / 32), as a compile-time constant (7 for ViT-B/16's 197 tokens): with a run-time count every
 // key block sits behind its own branch (14 scheduling regions per item); with the constant the item is straight-line code.
-template <bool TRACE = false, int NKB = 7>
-__global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T,
+// TT: the token count as a constant too (197 for ViT-B/16: row clamps and key masks become per-thread constants), 0 = run-time T.
+template <bool TRACE = false, int NKB = 7, int TT = 0>
+__global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
                                                        int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr) {
+    const int T = TT ? TT : T_arg;
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;      // TRACE: cycles per phase, summed over this wave's items
 #define AT_STAMP(i) if (TRACE) { const long long c_ = clock64(); tr[i] += c_ - tc; tc = c_; }
     extern __shared__ __attribute__((aligned(16))) char at_smem[];       // AT_LDS_BYTES: K rows | V^T rows | one 32-row tile per wave
@@ -1628,6 +1630,13 @@ static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, i
         if (!attr_) { VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<TRACE, N>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES)); attr_ = true; } \
         hipLaunchKernelGGL((k_attention_f16<TRACE, N>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);   \
         break; }
+    if (T == 197 && !TRACE) {                  // ViT-B/16
+        static bool attr_ = false;
+        if (!attr_) { VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<false, 7, 197>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES)); attr_ = true; }
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);
+        VG_LAUNCH_CHECK();
+        return VG_OK;
+    }
     switch (nkb) { VG_ATT(1) VG_ATT(2) VG_ATT(3) VG_ATT(4) VG_ATT(5) VG_ATT(6) VG_ATT(7) }
 #undef VG_ATT
     VG_LAUNCH_CHECK();
