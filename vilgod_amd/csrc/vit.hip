@@ -580,6 +580,71 @@ __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ p
     }
     const int crop = row / T, t = row - crop * T;
     const float* src = (t == 0) ? cls : patch_out + ((size_t)crop * (T - 1) + (t - 1)) * W;
+    if ((W & 255) == 0 && W <= 1024) {
+        // vectorised path (every shipped width): float4 per lane like k_layernorm -- 1 KB per wave instruction instead of 256 B
+        const int nv = W >> 8;
+        float4 v4[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 a = *(const float4*)(src + c), b = *(const float4*)(pos + (size_t)t * W + c);
+                v4[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                s += (v4[i].x + v4[i].y) + (v4[i].z + v4[i].w);
+            }
+        const float mean = vg_wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nv) {
+                const float a = v4[i].x - mean, b = v4[i].y - mean, c = v4[i].z - mean, d = v4[i].w - mean;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        const float rstd = rsqrtf(vg_wave_sum(q) / (float)W + 1e-5f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nv) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 w4 = *(const float4*)(lw + c), b4 = *(const float4*)(lb + c);
+                float o[4] = {(v4[i].x - mean) * rstd * w4.x + b4.x, (v4[i].y - mean) * rstd * w4.y + b4.y,
+                              (v4[i].z - mean) * rstd * w4.z + b4.z, (v4[i].w - mean) * rstd * w4.w + b4.w};
+                TO* dst = x + (size_t)row * W + c;
+                if (sizeof(TO) == 2) {
+                    const f16x4 h4 = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+                    *(f16x4*)dst = h4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (float)h4[e];           // what a separate LayerNorm kernel would read back
+                } else {
+                    *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+                }
+                v4[i] = make_float4(o[0], o[1], o[2], o[3]);
+                s2 += (o[0] + o[1]) + (o[2] + o[3]);
+            }
+        if (h1) {
+            // ln_1 of the first block on the row just produced, k_layernorm's arithmetic (bit-identical to the separate launch)
+            const float mean2 = vg_wave_sum(s2) / (float)W;
+            float q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nv) {
+                    const float a = v4[i].x - mean2, b = v4[i].y - mean2, c = v4[i].z - mean2, d = v4[i].w - mean2;
+                    q2 += (a * a + b * b) + (c * c + d * d);
+                }
+            const float rstd2 = rsqrtf(vg_wave_sum(q2) / (float)W + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nv) {
+                    const int c = (i * 64 + lane) * 4;
+                    const float4 w4 = *(const float4*)(lw1 + c), b4 = *(const float4*)(lb1 + c);
+                    const f16x4 h4 = {(f16)((v4[i].x - mean2) * rstd2 * w4.x + b4.x), (f16)((v4[i].y - mean2) * rstd2 * w4.y + b4.y),
+                                      (f16)((v4[i].z - mean2) * rstd2 * w4.z + b4.z), (f16)((v4[i].w - mean2) * rstd2 * w4.w + b4.w)};
+                    *(f16x4*)(h1 + (size_t)row * W + c) = h4;
+                }
+        }
+        return;
+    }
     float v[16];
     const int per = W / 64;   // W multiple of 64, <= 1024
     float s = 0.f;
@@ -982,7 +1047,9 @@ __global__ __launch_bounds__(256) void k_head(const TI* __restrict__ x, const fl
     __syncthreads();
     for (int j = tid; j < D; j += 256) {
         float a = 0.f;
-        for (int i = 0; i < W; ++i) a = fmaf(sm[i], proj[(size_t)i * D + j], a);
+#pragma unroll 16                                  // 16 independent loads of the projection column in flight per trip (the chain
+        for (int i = 0; i < W; ++i)               // a = fma(.., a) stays in order: same sum as before)
+            a = fmaf(sm[i], proj[(size_t)i * D + j], a);
         feat[(size_t)crop * D + j] = a;
     }
 }
