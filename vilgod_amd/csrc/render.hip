@@ -43,20 +43,22 @@ __global__ void k_gather_ego(const float* __restrict__ pts, int stride, const in
 
 // ---------------------------------------------------------------------------------------------
 // k-th smallest (0-based) of the `axis` coordinate over one cluster: 4-pass byte radix select.
+// Called by a 256-thread GROUP of the workgroup (`t` = thread index inside the group) with the group's own hist / sh arrays; every
+// group of the workgroup makes the same number of calls, so the workgroup barriers inside line up.
 __device__ float radix_select(const float* __restrict__ v, int n, int axis, int k, uint32_t* hist,
-                              uint32_t* sh) {
+                              uint32_t* sh, int t) {
     uint32_t prefix = 0;
     for (int pass = 3; pass >= 0; --pass) {
-        for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+        hist[t] = 0;
         __syncthreads();
         int shift = pass * 8;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int i = t; i < n; i += 256) {
             uint32_t key = vg_fkey(v[(size_t)i * 3 + axis]);
             bool match = (pass == 3) || ((key >> (shift + 8)) == prefix);
             if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (t == 0) {
             uint32_t cum = 0;
             int b = 0;
             for (; b < 256; ++b) {
@@ -76,28 +78,30 @@ __device__ float radix_select(const float* __restrict__ v, int n, int axis, int 
 
 // out_med[c] = median xyz (float32, np.median semantics); out_rot[c] = {m00,m01,m10,m11,m22,angle} of
 // scipy Rotation.from_euler('z', -atan2(med_y, med_x)).as_matrix() in float64.
-__global__ __launch_bounds__(256) void k_cluster_median(const float* __restrict__ ego,
+// 768 threads: the three axes are selected at the same time, one 256-thread group each (a third of the dependent passes).
+__global__ __launch_bounds__(768) void k_cluster_median(const float* __restrict__ ego,
                                                         const int* __restrict__ seg_off,
                                                         float* __restrict__ out_med,
                                                         double* __restrict__ out_rot) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh[2];
+    __shared__ uint32_t hist[3][256];
+    __shared__ uint32_t sh[3][2];
     __shared__ float med[3];
     int c = blockIdx.x;
     int p0 = seg_off[c], n = seg_off[c + 1] - p0;
     const float* v = ego + (size_t)p0 * 3;
-    for (int a = 0; a < 3; ++a) {
+    {
+        const int a = threadIdx.x >> 8, t = threadIdx.x & 255;
         float m = 0.f;
-        if (n > 0) {
-            float hi = radix_select(v, n, a, n / 2, hist, sh);
+        if (n > 0) {                                                  // n is uniform: every group takes the same branches
+            float hi = radix_select(v, n, a, n / 2, hist[a], sh[a], t);
             if (n & 1) {
                 m = hi;
             } else {
-                float lo = radix_select(v, n, a, n / 2 - 1, hist, sh);
+                float lo = radix_select(v, n, a, n / 2 - 1, hist[a], sh[a], t);
                 m = (lo + hi) / 2.0f;  // np.mean of the two middle float32 values
             }
         }
-        if (threadIdx.x == 0) med[a] = m;
+        if (t == 0) med[a] = m;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -474,7 +478,7 @@ int vg_cluster_median(const float* d_ego, const int32_t* d_seg_off, int n_cluste
                       double* d_rot, void* stream) {
     if (n_clusters <= 0) return VG_OK;
     if (!d_ego || !d_seg_off || !d_median || !d_rot) return VG_ERR_ARG;
-    hipLaunchKernelGGL(k_cluster_median, dim3(n_clusters), dim3(256), 0, (hipStream_t)stream, d_ego, d_seg_off,
+    hipLaunchKernelGGL(k_cluster_median, dim3(n_clusters), dim3(768), 0, (hipStream_t)stream, d_ego, d_seg_off,
                        d_median, d_rot);
     VG_LAUNCH_CHECK();
     return VG_OK;

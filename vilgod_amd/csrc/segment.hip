@@ -56,7 +56,9 @@ __global__ __launch_bounds__(256) void k_plane_hyp(const float* __restrict__ pts
                                                    double* __restrict__ plane_out, int* __restrict__ count_out) {
     __shared__ double pl[4];
     __shared__ int cnt[4];
-    const int it = blockIdx.x;
+    // grid = (iterations, PLANE_SPLIT): the inlier count of a hypothesis is summed over PLANE_SPLIT blocks (integer atomics into the
+    // zeroed count array: exact, order-free) -- 100 blocks alone leave more than half of the 256 CUs idle for ~140 us
+    const int it = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
     if (threadIdx.x == 0) {
         int s[3];
         vg_sample3(seed, it, n, s);
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_plane_hyp(const float* __restrict__ pts
     const double a = pl[0], b = pl[1], c = pl[2], d = pl[3];
     const double inv = sqrt((a * a + b * b) + c * c);
     int local = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = part * 256 + threadIdx.x; i < n; i += 256 * nparts) {
         const float* p = pts + (size_t)(idx ? idx[i] : i) * stride;
         double dist = ((((a * (double)p[0] + b * (double)p[1]) + c * (double)p[2]) + d)) / inv;
         if (fabs(dist) <= thresh) local++;
@@ -87,8 +89,9 @@ __global__ __launch_bounds__(256) void k_plane_hyp(const float* __restrict__ pts
     if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = local;
     __syncthreads();
     if (threadIdx.x == 0) {
-        count_out[it] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        for (int k = 0; k < 4; ++k) plane_out[it * 4 + k] = pl[k];
+        atomicAdd(&count_out[it], cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+        if (part == 0)
+            for (int k = 0; k < 4; ++k) plane_out[it * 4 + k] = pl[k];
     }
 }
 
@@ -493,7 +496,8 @@ int vg_plane_ransac(const float* d_points, int stride, const int32_t* d_index, i
     hipStream_t st = (hipStream_t)stream;
     double* planes = (double*)d_work;
     int* counts = (int*)((char*)d_work + (size_t)iters * 32);
-    hipLaunchKernelGGL(k_plane_hyp, dim3(iters), dim3(256), 0, st, d_points, stride, d_index, n, thresh,
+    VG_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)iters, st));
+    hipLaunchKernelGGL(k_plane_hyp, dim3(iters, 4), dim3(256), 0, st, d_points, stride, d_index, n, thresh,
                        (unsigned long long)seed, planes, counts);
     hipLaunchKernelGGL(k_plane_best, dim3(1), dim3(64), 0, st, planes, counts, iters, d_plane4, d_count);
     hipLaunchKernelGGL(k_plane_inliers, dim3(vg_div_up(n, 256)), dim3(256), 0, st, d_points, stride, d_index, n, d_plane4, thresh, d_flags);
