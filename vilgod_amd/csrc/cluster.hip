@@ -114,12 +114,19 @@ __global__ void k_cl_bbox(const float* __restrict__ pts, int n, int stride, ClGr
         mn[a] = vg_wave_min(mn[a]);
         mx[a] = vg_wave_max(mx[a]);
     }
+    // one set of atomics per BLOCK (64 blocks): 7.4 k atomics of 1 236 waves on the same cache line took 87 us
+    __shared__ float red[4][6];
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&g->kmin[a], vg_fkey(mn[a]));
-            atomicMax(&g->kmax[a], vg_fkey(mx[a]));
-        }
+        for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = mn[a]; red[threadIdx.x >> 6][3 + a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = red[0][a], hi = red[0][3 + a];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, red[w][a]); hi = fmaxf(hi, red[w][3 + a]); }
+        atomicMin(&g->kmin[a], vg_fkey(lo));
+        atomicMax(&g->kmax[a], vg_fkey(hi));
+    }
 }
 
 __global__ void k_cl_grid(ClGrid* g) {
@@ -868,7 +875,7 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
     memset(&g0, 0, sizeof(g0));
     for (int a = 0; a < 3; ++a) { g0.kmin[a] = 0xFFFFFFFFu; g0.kmax[a] = 0u; }
     VG_CHECK(hipMemcpyAsync(h->d_grid, &g0, sizeof(g0), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_cl_bbox, dim3(std::min(nb, 1024)), dim3(256), 0, st, d_points, n, stride, h->d_grid);
+    hipLaunchKernelGGL(k_cl_bbox, dim3(std::min(nb, 64)), dim3(256), 0, st, d_points, n, stride, h->d_grid);
     hipLaunchKernelGGL(k_cl_grid, dim3(1), dim3(64), 0, st, h->d_grid);
     hipLaunchKernelGGL(k_cl_codes, dim3(nb), dim3(256), 0, st, d_points, n, stride, h->d_grid, h->d_code, h->d_perm_in);
     size_t tb = h->temp_bytes;

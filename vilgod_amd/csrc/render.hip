@@ -58,15 +58,22 @@ __device__ float radix_select(const float* __restrict__ v, int n, int axis, int 
             if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (t == 0) {
-            uint32_t cum = 0;
-            int b = 0;
-            for (; b < 256; ++b) {
-                if (cum + hist[b] > (uint32_t)k) break;
-                cum += hist[b];
+        // the bin that holds rank k: exclusive prefix of the 256 counts by wave scans (a serial walk by one thread cost ~16 k cycles
+        // per pass); exactly one thread finds excl <= k < excl + count
+        {
+            const uint32_t cnt = hist[t];
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o);
+                if ((t & 63) >= o) inc += up;
             }
-            sh[0] = (uint32_t)b;
-            sh[1] = cum;
+            if ((t & 63) == 63) sh[2 + (t >> 6)] = inc;                // wave totals
+            __syncthreads();
+            uint32_t base = 0;
+            for (int w = 0; w < (t >> 6); ++w) base += sh[2 + w];
+            const uint32_t excl = base + inc - cnt;
+            if (excl <= (uint32_t)k && (uint32_t)k < excl + cnt) { sh[0] = (uint32_t)t; sh[1] = excl; }
         }
         __syncthreads();
         prefix = (prefix << 8) | sh[0];
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(768) void k_cluster_median(const float* __restrict_
                                                         float* __restrict__ out_med,
                                                         double* __restrict__ out_rot) {
     __shared__ uint32_t hist[3][256];
-    __shared__ uint32_t sh[3][2];
+    __shared__ uint32_t sh[3][6];            // per axis group: bin, rank offset, four wave totals
     __shared__ float med[3];
     int c = blockIdx.x;
     int p0 = seg_off[c], n = seg_off[c + 1] - p0;

@@ -431,15 +431,21 @@ __device__ float vg_select_gather(const float* __restrict__ pts, int stride, int
             if (pass == 3 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t cum = 0;
-            int b = 0;
-            for (; b < 256; ++b) {
-                if (cum + hist[b] > (uint32_t)k) break;
-                cum += hist[b];
+        {   // the bin that holds rank k: exclusive prefix of the 256 counts by wave scans; exactly one thread finds it
+            const int t = threadIdx.x;
+            const uint32_t cnt = hist[t];
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o);
+                if ((t & 63) >= o) inc += up;
             }
-            sh[0] = (uint32_t)b;
-            sh[1] = cum;
+            if ((t & 63) == 63) sh[2 + (t >> 6)] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int w = 0; w < (t >> 6); ++w) base += sh[2 + w];
+            const uint32_t excl = base + inc - cnt;
+            if (excl <= (uint32_t)k && (uint32_t)k < excl + cnt) { sh[0] = (uint32_t)t; sh[1] = excl; }
         }
         __syncthreads();
         prefix = (prefix << 8) | sh[0];
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256) void k_cluster_medians(const float* __restrict
                                                          const int* __restrict__ index, const int* __restrict__ seg_off,
                                                          float* __restrict__ out) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t sh[2];
+    __shared__ uint32_t sh[6];
     const int c = blockIdx.x;
     const int p0 = seg_off[c], n = seg_off[c + 1] - p0;
     for (int col = 0; col < n_cols; ++col) {
