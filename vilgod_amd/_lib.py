@@ -14,7 +14,7 @@ import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), 'include', 'vilgod_hip.h')
-LIB_PATH = os.path.join(HERE, 'libvilgod_hip.so')
+LIB_PATH = os.environ.get('VILGOD_HIP_LIB') or os.path.join(HERE, 'libvilgod_hip.so')       # override: A/B runs of two builds on one box
 
 _SCALARS = {
     'int': ctypes.c_int, 'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint32_t': ctypes.c_uint32,

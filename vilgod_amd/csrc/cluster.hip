@@ -39,7 +39,8 @@
 #define CL_PUR_LEVELS 4               // purity tables for levels 0..3 (0.4 .. 3.2 m); levels 4..6 were measured: no gain
 #define CL_LEAF 48                    // nodes with at most this many points are scanned instead of subdivided
 #define CL_FIRST_BATCH 6      // Boruvka rounds queued before the first host read of the edge counter
-#define CL_STACK 64
+#define CL_STACK 44      // DFS stack entries per thread (LDS): the walk never holds more than 1 + 7 * CL_LMAX = 43 nodes (a pop precedes every push of
+                         // <= 8 children, level-0 nodes are never expanded); 44 KB per 256-thread block -> three blocks per CU instead of two
 #define CL_K 16                       // neighbours kept (k-th other point = entry k, entry 0 is the point itself)
 
 struct ClGrid {
