@@ -7,7 +7,7 @@ Pinned against the reference itself: tests/golden/make_golden.py runs the
 reference's own `mv_utils.RealisticProjection.get_img`,
 `pointcloud_utils.transform_cluster_points_to_origin` and the resize/quantise
 lines of `ZeroShotDetector.classification` (stub-imported from /root/reference
-in the build container) and tests/test_oracle_render.py checks this restatement
+in the build container) and tests/test_render.py checks this restatement
 against those frozen outputs bit for bit.
 
 Reference lines restated (paths relative to /root/reference):
