@@ -246,3 +246,44 @@ def test_hip_captured_classification_equals_plain_launches(cuda):
     st = g.stats()
     assert st['graphs_captured'] >= 1 and st['graph_launches'] >= st['graphs_captured']
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('form', ['state_dict', 'torchscript'])
+def test_hip_clipwrapper_loads_a_checkpoint_end_to_end(cuda, tmp_path, form):
+    """ClipWrapper's real-checkpoint path (clip_utils.py:19-26, clip.py:94-141) on the GPU with a FABRICATED checkpoint of the real
+    ViT-B/16 shape: the published file is a TorchScript archive holding fp16 tensors under `visual.*` next to the text tower;
+    both that form and a plain state dict must load, the cached text features next to the checkpoint must be used, and the scores
+    must equal those of an encoder built directly from the same tensors.  (The real ViT-B-16.pt cannot be fetched here.)"""
+    from vilgod_amd.clip_wrapper import ClipWrapper, VitEncoder, clip_scores
+    from vilgod_amd.pipeline import default_preprocessor_cfg
+    wd = cw.synthetic_vit_weights(5, **cw.VIT_B16)
+    half = {k: v.half() for k, v in wd.items()}                          # the published checkpoint stores half tensors
+    sd = {**{'visual.' + k: v for k, v in half.items()}, **{k: v.half() for k, v in cw.synthetic_text_weights(2, width=64, layers=1, embed=512).items()},
+          'logit_scale': torch.tensor(4.6052)}
+    ckpt = tmp_path / 'ViT-B-16.pt'
+    if form == 'state_dict':
+        torch.save(sd, ckpt)
+    else:
+        # a TorchScript archive whose state_dict carries the dotted names: a module tree with the tensors as buffers
+        root = torch.nn.Module()
+        for k, v in sd.items():
+            parts, node = k.split('.'), root
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, torch.nn.Module())
+                node = getattr(node, p)
+            node.register_buffer(parts[-1], v)
+        torch.jit.save(torch.jit.script(root), str(ckpt))
+    cfg = default_preprocessor_cfg()['clip']
+    text = cw.synthetic_text_features(9, len(cfg['class_list']), 512)
+    np.save(str(ckpt) + '.text_features.npy', text.numpy())              # the cache ClipWrapper writes after its first run
+    clip = ClipWrapper(cfg, str(tmp_path), device=cuda, dtype='f16')
+    assert clip.weights_source == str(ckpt) and clip.encoder.cfg == dict(cw.VIT_B16)
+    x = (torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(2)) * 1.2).half().to(cuda)
+    probs, top1, score = clip.predict_probs(x)
+    ref = VitEncoder({k: v.float() for k, v in half.items()}, dtype='f16', device=cuda)
+    want = clip_scores(ref.encode(x), text.to(cuda))
+    assert torch.equal(probs, want[0]) and torch.equal(top1, want[1])
+    names, scores = clip.predict_clip_labels(x)
+    assert names == [cfg['class_list'][int(i)] for i in top1.cpu()] and len(scores) == 6
