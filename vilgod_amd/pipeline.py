@@ -97,6 +97,7 @@ class PseudoLabelPipeline:
         # hipGraph-captured classification (BASELINE config 5): one graph per distinct crop count, per worker (clip_wrapper.GraphClassifier)
         self.vit_graph = bool(vit_graph)
         self._graph_cls = None
+        self._ground_stream = None
         self.box_workers = int(box_workers)      # helper processes for the host part of the reference box mode (0 = in the frame's thread)
         self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
@@ -117,6 +118,7 @@ class PseudoLabelPipeline:
         w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         w._xy_pinned = None
         w._graph_cls = None
+        w._ground_stream = None
         w.timings = {}
         w.stream = torch.cuda.Stream(device=self.device)
         from concurrent.futures import ThreadPoolExecutor
@@ -156,7 +158,13 @@ class PseudoLabelPipeline:
         `after_ground()` is called once all ground passes are queued, before the results are awaited.
         Returns [(FrameState, result dict, probs tensor)] in frame order."""
         workers = self._ensure_workers(n_workers)
-        main = torch.cuda.current_stream(self.device)
+        # the ground passes chain the frames (and, with several ranks, the ranks: the next rank waits for the state after this block):
+        # they run on a HIGH-PRIORITY stream of their own so that their small kernels are dispatched ahead of the workers' heavy ones
+        # instead of queueing behind every GEMM tile
+        if getattr(self, '_ground_stream', None) is None:
+            self._ground_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        main = self._ground_stream
+        main.wait_stream(torch.cuda.current_stream(self.device))
 
         def run(worker, i, d_pts, mask, ev):
             with torch.cuda.stream(worker.stream):
@@ -167,16 +175,19 @@ class PseudoLabelPipeline:
             return fs, res, probs
 
         futures = []
-        for i, pts in enumerate(frames):
-            d_pts = self.upload(pts)
-            mask = self.ground(d_pts)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            w = workers[i % n_workers]
-            futures.append(w.thread.submit(run, w, i, d_pts, mask, ev))
-        if after_ground is not None:
-            after_ground()             # every ground pass of the block is queued: e.g. hand the ground state to the next rank
-        return [f.result() for f in futures]
+        with torch.cuda.stream(main):
+            for i, pts in enumerate(frames):
+                d_pts = self.upload(pts)
+                mask = self.ground(d_pts)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                w = workers[i % n_workers]
+                futures.append(w.thread.submit(run, w, i, d_pts, mask, ev))
+            if after_ground is not None:
+                after_ground()         # every ground pass of the block is queued: e.g. hand the ground state to the next rank
+        out = [f.result() for f in futures]
+        torch.cuda.current_stream(self.device).wait_stream(main)
+        return out
 
     @staticmethod
     def _parse_filters(ccfg):
