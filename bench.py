@@ -153,6 +153,10 @@ def main():
     ap.add_argument('--inflight', type=int, default=6, help='frames in flight per GPU (worker streams); 1 = strictly sequential')
     args = ap.parse_args()
 
+    import faulthandler
+    faulthandler.enable()
+    if int(os.environ.get('VG_BENCH_WATCHDOG', 0)) > 0:           # development aid: dump every thread's stack and exit if the run stalls
+        faulthandler.dump_traceback_later(int(os.environ['VG_BENCH_WATCHDOG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', 1))
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))

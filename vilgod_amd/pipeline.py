@@ -13,6 +13,8 @@ benchmark can call them one by one; `process_frame` chains them.
     boxes                          E1      csrc/segment.hip
     results                        F1      host numpy
 """
+import contextlib
+import os
 import time
 
 import numpy as np
@@ -98,6 +100,9 @@ class PseudoLabelPipeline:
         self.vit_graph = bool(vit_graph)
         self._graph_cls = None
         self._ground_stream = None
+        # frames in flight: the ViT passes of the workers take turns in arrival order (see classify); shared by the worker clones
+        import threading
+        self._vit_turn = {'lock': threading.Lock(), 'events': [], 'depth': int(os.environ.get('VILGOD_VIT_CONCURRENCY', '2'))}
         self.box_workers = int(box_workers)      # helper processes for the host part of the reference box mode (0 = in the frame's thread)
         self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
@@ -301,12 +306,38 @@ class PseudoLabelPipeline:
                     self._graph_cls = GraphClassifier(enc, self.clip.text_features, max_crops=max(512, n))
                 g = self._graph_cls
                 self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16', out_buf=g.patch_buffer(n))
-                probs, top1, score = g.classify(n)
+                with self._vit_in_turn():
+                    probs, top1, score = g.classify(n)
                 return probs.clone(), top1.clone(), score.clone()
             patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16')
-            return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
+            with self._vit_in_turn():
+                return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
         crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='f16' if self.vit_dtype == 'f16' else 'f32')
         return self.clip.predict_probs(crops)
+
+    @contextlib.contextmanager
+    def _vit_in_turn(self):
+        """Frames in flight: at most `depth` (2; env VILGOD_VIT_CONCURRENCY, 0 = unlimited) ViT passes of the worker streams run at
+        a time, in arrival order (a pass waits for the event recorded after the pass `depth` before it).  Left alone, the GPU
+        interleaves the GEMM tiles of all queued passes: every pass takes n_workers times as long, all finish together, and the
+        workers then move in lock step (all clustering, then all encoding; kernel trace: tools/analyze_fill.py) instead of one
+        frame's clustering and rendering running underneath another frame's GEMMs.  Strictly one pass at a time staggers the
+        workers but leaves the tails of a pass (LayerNorm, attention, head: few workgroups) uncovered; two cover each other.
+        Measured, 20-frame blocks: unlimited 18.55, one 18.5, two 17.9, four 18.3 ms per frame; 96-frame blocks: 16.8 for all but
+        one (17.65)."""
+        turn = self._vit_turn
+        st = torch.cuda.current_stream(self.device)
+        depth = turn['depth']
+        if depth <= 0 or st.cuda_stream == 0:
+            yield
+            return
+        with turn['lock']:
+            if len(turn['events']) >= depth:
+                st.wait_event(turn['events'][-depth])
+            yield
+            ev = torch.cuda.Event()
+            ev.record(st)
+            turn['events'] = (turn['events'] + [ev])[-depth:]
 
     # [E1]
     def boxes(self, d_X, d_index, d_seg):
