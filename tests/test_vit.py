@@ -8,6 +8,8 @@ GPU:  csrc/vit.hip through the C ABI.
                  features within 2e-2 relative L2, probabilities within 5e-2, top-1 equal wherever the oracle's
                  top-2 margin exceeds 0.1.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -219,6 +221,51 @@ def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
     srt = np.sort(p_want.numpy(), axis=1)
     sure = (srt[:, -1] - srt[:, -2]) > 4e-3
     assert np.array_equal(top1[sure], vo.top1(p_want)[0][sure])
+
+
+@pytest.mark.gpu
+def test_hip_folded_layernorm_on_trained_like_statistics(cuda):
+    """The fp16 tower folds ln_1 / ln_2 into the GEMMs around them (vit.hip k_gemm_f16_pp64 LN = 1 / 2: raw fp16 residual times
+    gamma-scaled weights, row statistics applied in the epilogue).  Algebraically the same as LayerNorm followed by the GEMM
+    (model.py:171-191), but the rounding differs, so it is checked where it could hurt: LayerNorm gains / offsets spread like a
+    trained model's (0.3 ... 2.5, +-0.8), a few residual channels two orders of magnitude above the rest (the "massive
+    activations" of trained ViTs) and a large common offset of the rows.  Reference = the fp32 tower of the same library (pinned to
+    the oracle / the reference's model.py by the tests above); the folded tower must be as close to it as the tower with separate
+    LayerNorm kernels (VG_VIT_LN_FOLD=0), within 1e-3 relative L2 / 2e-3 probability like the fp16 tower elsewhere."""
+    from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
+    rng = np.random.default_rng(5)
+    wd = cw.synthetic_vit_weights(3, **cw.VIT_B16)
+    for k in list(wd):
+        if k.endswith(('ln_1.weight', 'ln_2.weight')):
+            wd[k] = torch.from_numpy(rng.uniform(0.3, 2.5, wd[k].shape).astype(np.float32))
+        elif k.endswith(('ln_1.bias', 'ln_2.bias')):
+            wd[k] = torch.from_numpy(rng.uniform(-0.8, 0.8, wd[k].shape).astype(np.float32))
+    pos = wd['positional_embedding'].clone()
+    pos[:, [7, 300, 555]] += torch.tensor([40.0, -25.0, 60.0])          # outlier channels of the residual stream
+    pos += 1.5                                                          # rows with |mean| comparable to their spread
+    wd['positional_embedding'] = pos
+    wd['ln_pre.weight'] = torch.from_numpy(rng.uniform(0.5, 3.0, 768).astype(np.float32))
+    crops = torch.from_numpy(rng.uniform(-1.8, 2.2, (12, 3, 224, 224)).astype(np.float32)).to(cuda)
+    text = cw.synthetic_text_features(0, 24, 512).to(cuda)
+    f32 = VitEncoder(wd, dtype='f32', device=cuda).encode(crops)
+    p32 = clip_scores(f32, text)[0]
+    res = {}
+    for fold in ('1', '0'):
+        old = os.environ.get('VG_VIT_LN_FOLD')
+        os.environ['VG_VIT_LN_FOLD'] = fold                              # read by vg_vit_create
+        try:
+            enc = VitEncoder(wd, dtype='f16', device=cuda)
+        finally:
+            if old is None:
+                del os.environ['VG_VIT_LN_FOLD']
+            else:
+                os.environ['VG_VIT_LN_FOLD'] = old
+        f = enc.encode(crops)
+        p = clip_scores(f, text)[0]
+        res[fold] = (((f - f32).norm() / f32.norm()).item(), (p - p32).abs().max().item())
+        assert torch.isfinite(f).all()
+    print(f'folded LayerNorm: rel L2 {res["1"][0]:.2e} / max prob err {res["1"][1]:.2e};  separate kernels: {res["0"][0]:.2e} / {res["0"][1]:.2e}')
+    assert res['1'][0] <= max(1e-3, 1.5 * res['0'][0]) and res['1'][1] <= max(2e-3, 1.5 * res['0'][1])
 
 
 @pytest.mark.gpu

@@ -29,6 +29,8 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <atomic>
+#include <mutex>
 
 typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1105,6 +1107,14 @@ struct vg_vit {
     bool prof_init = false;
     std::map<std::string, void*> w;        // device pointers (f32 or f16 depending on role)
     std::map<std::string, size_t> numel;
+    // LayerNorm folded into the GEMMs around it (k_gemm_f16_pp64 LN = 1 / 2): fp16 tower with the fp32 residual stream and
+    // width % 256 == 0, unless VG_VIT_LN_FOLD=0.  The fp32 originals of in_proj / c_fc stay on the device (w32) so that the
+    // pre-scaled fp16 weights are rounded once, from g[k] * W[n,k]; the derived tensors live in `w` under "<name>#ln" (weights),
+    // "#c1", "#c2" and are rebuilt when any of their inputs is set again.
+    bool ln_fold = false;
+    std::atomic<bool> fold_ready{false}, warmed{false};
+    std::mutex mtx;
+    std::map<std::string, void*> w32;
 };
 
 static bool is_gemm_weight(const std::string& n) {
@@ -1309,11 +1319,32 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict_
 //   by group 0 in its LOAD_{j+1} (3-deep ring -> at least one interval of lead).
 //   The second k32 sub-step's fragments are read during the first sub-step's MFMAs into the registers those have
 //   just consumed.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that ends its MMA segment.
-template <int EPI, bool TRACE = false, bool PERSIST = false>
+//
+// LayerNorm folded into the GEMMs around it (LN = 1 / 2; ViT blocks, fp32 residual stream).  ln(x) W^T + b with
+// ln(x) = (x - mean) * rstd * g + beta is  rstd * (x (g.W)^T - mean * c1) + c2,  c1[n] = sum_k g[k] W[n,k],
+// c2[n] = b[n] + sum_k beta[k] W[n,k]:  the CONSUMER (LN = 1: in_proj, c_fc) multiplies the raw residual (as fp16) by the
+// pre-scaled weights and applies the row statistics in its epilogue; the PRODUCER (LN = 2: out_proj, c_proj, whose epilogue
+// holds the new residual row segments anyway) writes that fp16 copy and, per row and 256-column tile, (mean, sum of squared
+// deviations from it) -- the consumer merges the K / 256 partials of a row (Chan et al.), so the variance is the two-pass
+// variance, not E[x^2] - mean^2.  Saves the separate LayerNorm pass over the residual stream (295 MB per launch, 23 per frame).
+struct LnPartial { float mean, m2; };
+__device__ __forceinline__ float row256_sum(float v) {          // sum over the 64 lanes, fixed order: DPP inside rows of 16, then the four rows
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
+
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
-                                                          long long* __restrict__ trace = nullptr) {
+                                                          long long* __restrict__ trace = nullptr,
+                                                          const float* __restrict__ ln_c1 = nullptr, LnPartial* __restrict__ ln_stats = nullptr,
+                                                          f16* __restrict__ ln_x16 = nullptr) {
     constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;
     constexpr int XBUF = 32768, WBASE = 2 * XBUF, WBUF = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1371,6 +1402,17 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     const int xo0 = (grp * 128 + r15) * 128 + ((q4 ^ swz) << 4), xo1 = (grp * 128 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int wo0 = (wn * 64 + r15) * 128 + ((q4 ^ swz) << 4), wo1 = (wn * 64 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int np = K / 64;                         // host guarantees K % 64 == 0 and np >= 2
+    // folded LayerNorm, consumer side: thread t < 256 merges the K / 256 partials of tile row t into (mean, rstd) here, where the
+    // loads' latency hides behind the prologue's DMA (in the epilogue it cost ~7 us per tile), and carries two registers
+    float2 ln_row = make_float2(0.f, 0.f);
+    LnPartial pt[4] = {};
+    const int nst = K >> 8;                        // <= 4 (width <= 1024)
+    if (LN == 1 && tid < BM) {
+        const LnPartial* sp = ln_stats + (size_t)(m0 + tid) * nst;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pt[t] = t < nst ? sp[t] : LnPartial{0.f, 0.f};
+    }
+
 #define PP_BAR()                                  \
     __builtin_amdgcn_sched_barrier(0);            \
     __builtin_amdgcn_s_barrier();                 \
@@ -1378,6 +1420,16 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     issue_x(0);
     if (grp == 1) { issue_w(0, 0); issue_w(1, 0); } else issue_w(0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (LN == 1 && tid < BM) {                     // the partials were requested before the first pieces: no extra wait here
+        float ms = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ms += pt[t].mean; m2 += pt[t].m2; }
+        const float mean = ms / (float)nst;
+        float dev = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (t < nst) { const float d = pt[t].mean - mean; dev += d * d; }
+        ln_row = make_float2(mean, rsqrtf((m2 + 256.f * dev) / (float)K + 1e-5f));
+    }
     PP_BAR()
     if (grp == 1) { PP_BAR() }
     f16x8 fa[TN], fa2[TN], fb[TM];
@@ -1433,15 +1485,34 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     // ---- epilogue: the same chunk-XOR-swizzled LDS image as k_gemm_f16_pp ----
     __syncthreads();
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID_H) {
+        float ln_mean[TM], ln_rstd[TM];
+        if (LN == 1) {                      // the tile's 256 (mean, rstd) pairs go through LDS (above the 128 KB output image)
+            float2* lsm = (float2*)(smem + 131072);
+            if (tid < BM) lsm[tid] = ln_row;
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const float2 t2 = lsm[grp * 128 + mi * 16 + r15];
+                ln_mean[mi] = t2.x; ln_rstd[mi] = t2.y;
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int nloc = wn * 64 + ni * 16 + 4 * q4;
             const float4 b4 = *(const float4*)(bias + n0 + nloc);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LN == 1) c4 = *(const float4*)(ln_c1 + n0 + nloc);
             const int ch = nloc >> 3, hf = (nloc >> 2) & 1;
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 const int m = grp * 128 + mi * 16 + r15;
                 float v[4] = {acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w};
+                if (LN == 1) {
+                    v[0] = ln_rstd[mi] * (acc[ni][mi][0] - ln_mean[mi] * c4.x) + b4.x;
+                    v[1] = ln_rstd[mi] * (acc[ni][mi][1] - ln_mean[mi] * c4.y) + b4.y;
+                    v[2] = ln_rstd[mi] * (acc[ni][mi][2] - ln_mean[mi] * c4.z) + b4.z;
+                    v[3] = ln_rstd[mi] * (acc[ni][mi][3] - ln_mean[mi] * c4.w) + b4.w;
+                }
                 f16x4 h4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1524,6 +1595,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
                     if (EPI == EPI_BIAS_RESID) {
                         v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
                         *(float4*)(resid + off) = v;
+                        if (LN == 2) {
+                            // this wave holds the row's 256 columns of the tile: fp16 copy for the next GEMM + the row's partial statistics
+                            const f16x4 h4 = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                            *(f16x4*)(ln_x16 + off) = h4;
+                            const float mean = row256_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+                            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+                            const float m2 = row256_sum((a * a + b * b) + (c * c + d * d));
+                            if (j == 0) ln_stats[(size_t)(m0 + half * 128 + m) * (N >> 8) + tn] = LnPartial{mean, m2};
+                        }
                     } else {
                         *(float4*)((float*)Cout + off) = v;
                     }
@@ -1559,11 +1639,14 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
-template <int EPI, bool TRACE = false, bool PERSIST = false>
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
-                            hipStream_t st, long long* trace = nullptr) {
+                            hipStream_t st, long long* trace = nullptr, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
+                            f16* ln_x16 = nullptr) {
     if (M % 256 || N % 256 || K % 64 || K / 64 < 2) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST>;
+    if (LN == 1 && (K % 256 || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
+    if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
+    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST, LN>;
     const int lds = 5 * 32768;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1581,7 +1664,7 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
         grid = (grid + 7) / 8 * 8;                 // slot s of XCD x = block 8 s + x
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, cwt, trace);
+                       ldc, cwt, trace, ln_c1, ln_stats, ln_x16);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
@@ -1628,9 +1711,10 @@ static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void
 
 #endif  // VG_DEV
 
-template <int EPI>
+template <int EPI, int LN = 0>
 static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
-                       int N, int K, hipStream_t st, int ldc = 0) {
+                       int N, int K, hipStream_t st, int ldc = 0, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
+                       f16* ln_x16 = nullptr) {
     if (ldc == 0) ldc = N;
     vg_vit* v = const_cast<vg_vit*>(cv);
     // f16 ViT shapes (N % 256 == 0, K >= 128) take the ping-pong kernel; k_gemm_f16 serves the remaining legal shapes.
@@ -1661,13 +1745,14 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                 // tile's first pieces still wait for the previous tile's stores (one vmcnt), so only the dispatch gap is saved.
 #ifdef VG_DEV
                 static const int persist_mask = getenv("VG_GEMM_PERSIST") ? atoi(getenv("VG_GEMM_PERSIST")) : 0;
-                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                if constexpr (LN == 0 && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID)) {
                     if ((persist_mask >> EPI) & 1) return launch_gemm_pp64<EPI, false, true>(X, Wt, bias, C, resid, M, N, K, ldc, st);
                 }
 #endif
-                return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
+                return launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
             }
         }
+        if (LN != 0) return VG_ERR_ARG;            // the folded LayerNorm exists in the 256 x 256 kernel only
         int nwg = (M / GBM) * (N / GBN);
         static bool attr_set = false;
         if (!attr_set) {
@@ -1710,6 +1795,73 @@ static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, i
     return VG_OK;
 }
 
+// W'[n,k] = f16(g[k] * W[n,k]);  c1[n] = sum_k W'[n,k] (of the ROUNDED values, which is what the MFMAs will sum);
+// c2[n] = b[n] + sum_k beta[k] * W[n,k].  One workgroup per output feature n, fixed summation order.
+__global__ __launch_bounds__(256) void k_ln_fold(const float* __restrict__ W32, const float* __restrict__ g, const float* __restrict__ beta,
+                                                 const float* __restrict__ b, f16* __restrict__ Wf, float* __restrict__ c1,
+                                                 float* __restrict__ c2, int K) {
+    __shared__ double sh1[256], sh2[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const float w = W32[(size_t)n * K + k];
+        const f16 wf = (f16)(g[k] * w);
+        Wf[(size_t)n * K + k] = wf;
+        s1 += (double)(float)wf;
+        s2 += (double)beta[k] * (double)w;
+    }
+    sh1[tid] = s1; sh2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh1[tid] += sh1[tid + o]; sh2[tid] += sh2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { c1[n] = (float)sh1[0]; c2[n] = (float)((double)b[n] + sh2[0]); }
+}
+
+static void* vit_w(const vg_vit* v, const std::string& n) {
+    auto it = v->w.find(n);
+    return it == v->w.end() ? nullptr : it->second;
+}
+
+/* Builds the derived tensors of the folded LayerNorms once per handle (and again after a weight was replaced).  Called at the top
+ * of vg_vit_encode; allocates and synchronises, so the first encode of a handle must not run inside a stream capture
+ * (vg_vit_classify_graph runs it as plain launches). */
+static int vit_fold_ln(vg_vit* v, hipStream_t st) {
+    if (!v->ln_fold || v->fold_ready.load()) return VG_OK;
+    std::lock_guard<std::mutex> lock(v->mtx);
+    if (v->fold_ready.load()) return VG_OK;
+    const int W = v->width;
+    for (int l = 0; l < v->layers; ++l) {
+        const std::string p = "transformer.resblocks." + std::to_string(l) + ".";
+        const char* sets[2][4] = {{"ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias"},
+                                  {"ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias"}};
+        for (int k = 0; k < 2; ++k) {
+            const std::string wn = p + sets[k][2];
+            auto it32 = v->w32.find(wn);
+            const float* g = (const float*)vit_w(v, p + sets[k][0]);
+            const float* be = (const float*)vit_w(v, p + sets[k][1]);
+            const float* b = (const float*)vit_w(v, p + sets[k][3]);
+            if (it32 == v->w32.end() || !g || !be || !b) continue;      // vg_vit_encode reports the missing weight by name
+            const int N = (int)(v->numel[wn] / (size_t)W);
+            for (const char* suffix : {"#ln", "#c1", "#c2"}) {
+                auto old = v->w.find(wn + suffix);
+                if (old != v->w.end()) { (void)hipFree(old->second); v->w.erase(old); }
+            }
+            void *wf = nullptr, *c1 = nullptr, *c2 = nullptr;
+            VG_CHECK(hipMalloc(&wf, (size_t)N * W * 2));
+            VG_CHECK(hipMalloc(&c1, (size_t)N * 4));
+            VG_CHECK(hipMalloc(&c2, (size_t)N * 4));
+            hipLaunchKernelGGL(k_ln_fold, dim3(N), dim3(256), 0, st, (const float*)it32->second, g, be, b, (f16*)wf, (float*)c1, (float*)c2, W);
+            VG_LAUNCH_CHECK();
+            v->w[wn + "#ln"] = wf; v->w[wn + "#c1"] = c1; v->w[wn + "#c2"] = c2;
+        }
+    }
+    VG_CHECK(hipStreamSynchronize(st));          // other threads' streams may use the tensors as soon as the flag is up
+    v->fold_ready.store(true);
+    return VG_OK;
+}
+
 extern "C" {
 
 int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int resolution, int out_dim, int dtype) {
@@ -1721,6 +1873,8 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
     v->out_dim = out_dim; v->dtype = dtype; v->T = T;
     v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
+    const char* fold = getenv("VG_VIT_LN_FOLD");
+    v->ln_fold = dtype == 1 && width % 256 == 0 && !v->resid_h && !getenv("VG_GEMM_V4") && !(fold && atoi(fold) == 0);
     *out = v;
     return VG_OK;
 }
@@ -1729,6 +1883,7 @@ void vg_vit_destroy(vg_vit* v) {
     if (!v) return;
     if (v->prof_init) for (int i = 0; i < 2 * VG_PROF_MAX; ++i) (void)hipEventDestroy(v->prof_ev[i]);
     for (auto& kv : v->w) (void)hipFree(kv.second);
+    for (auto& kv : v->w32) (void)hipFree(kv.second);
     delete v;
 }
 
@@ -1737,10 +1892,22 @@ void vg_vit_destroy(vg_vit* v) {
 int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t numel) {
     if (!v || !name || !h_data || numel <= 0) return VG_ERR_ARG;
     std::string n(name);
+    std::lock_guard<std::mutex> lock(v->mtx);
     auto it = v->w.find(n);
     if (it != v->w.end()) {
         (void)hipFree(it->second);
         v->w.erase(it);
+    }
+    if (v->ln_fold && n.find("transformer.resblocks.") == 0) {
+        v->fold_ready.store(false);              // a block's tensor changed: the folded LayerNorm tensors are rebuilt at the next encode
+        if (n.find("in_proj_weight") != std::string::npos || n.find("c_fc.weight") != std::string::npos) {
+            auto o = v->w32.find(n);
+            if (o != v->w32.end()) { (void)hipFree(o->second); v->w32.erase(o); }
+            void* d32 = nullptr;
+            VG_CHECK(hipMalloc(&d32, (size_t)numel * 4));
+            VG_CHECK(hipMemcpy(d32, h_data, (size_t)numel * 4, hipMemcpyHostToDevice));
+            v->w32[n] = d32;
+        }
     }
     void* d = nullptr;
     if (v->dtype == 1 && is_gemm_weight(n)) {
@@ -1770,6 +1937,7 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops) {
                 + Mp * 4 * W * es     // mlp
                 + Pp * Kp * es        // patches
                 + Pp * W * 4;         // patch-embed output (f32)
+    if (v->ln_fold) b += Mp * W * 2 + Mp * (W / 256) * 8;      // fp16 copy of the residual + per-row partial statistics (folded LayerNorm)
     return b + 1024;
 }
 
@@ -1792,7 +1960,11 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     void* qkv = ws;                   ws += Mp * (3 * W + 256) * es;
     void* mlp = ws;                   ws += Mp * 4 * W * es;
     void* patches = ws;               ws += Pp * Kp * es;
-    float* pe = (float*)ws;
+    float* pe = (float*)ws;           ws += Pp * W * 4;
+    const bool fold = v->ln_fold;
+    f16* x16 = (f16*)ws;              if (fold) ws += Mp * W * 2;
+    LnPartial* lnst = (LnPartial*)ws;
+    if (fold) { const int frc = vit_fold_ln(v, st); if (frc) return frc; }
 
     auto need = [&](const std::string& n) -> void* {
         auto it = v->w.find(n);
@@ -1856,8 +2028,17 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                 return VG_ERR_ARG;
             }
         }
+        void *fw1 = nullptr, *fw2 = nullptr;
+        const float *f1c1 = nullptr, *f1c2 = nullptr, *f2c1 = nullptr, *f2c2 = nullptr;
+        if (fold) {
+            fw1 = need(p + "attn.in_proj_weight#ln"); f1c1 = (const float*)need(p + "attn.in_proj_weight#c1"); f1c2 = (const float*)need(p + "attn.in_proj_weight#c2");
+            fw2 = need(p + "mlp.c_fc.weight#ln");     f2c1 = (const float*)need(p + "mlp.c_fc.weight#c1");     f2c2 = (const float*)need(p + "mlp.c_fc.weight#c2");
+            if (!fw1 || !f1c1 || !f1c2 || !fw2 || !f2c1 || !f2c2) return VG_ERR_ARG;
+        }
         if (l == 0 && ln1_done) {
             // h already holds ln_1(x) of block 0 (k_embed_lnpre)
+        } else if (fold) {
+            // ln_1 rides in in_proj: raw fp16 residual (x16) and row statistics (lnst) from the previous block's c_proj epilogue
         } else if (rh)
             hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[0], (const float*)wp[1], (f16*)h, (int)M, W, 1);
         else if (v->dtype == 1)
@@ -1865,7 +2046,10 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         else
             hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[0], (const float*)wp[1], (float*)h, (int)M, W, 1);
         VG_LAUNCH_CHECK();
-        rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld);
+        if (fold && !(l == 0 && ln1_done))
+            rc = launch_gemm<EPI_BIAS, 1>(v, x16, fw1, f1c2, qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld, f1c1, lnst);
+        else
+            rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld);
         if (rc) return rc;
         if (v->dtype == 1) {
             {
@@ -1883,19 +2067,25 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         }
         VG_LAUNCH_CHECK();
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
-                : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
+           : fold ? launch_gemm<EPI_BIAS_RESID, 2>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, lnst, x16)
+                  : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
         if (rc) return rc;
-        if (rh)
+        if (fold) {
+            // ln_2 rides in c_fc
+        } else if (rh)
             hipLaunchKernelGGL((k_layernorm<f16, f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const f16*)xh, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
         else if (v->dtype == 1)
             hipLaunchKernelGGL((k_layernorm<f16>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (f16*)h, (int)M, W, 1);
         else
             hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[6], (const float*)wp[7], (float*)h, (int)M, W, 1);
         VG_LAUNCH_CHECK();
-        rc = launch_gemm<EPI_BIAS_GELU>(v, h, wp[8], (const float*)wp[9], mlp, nullptr, (int)Mp, 4 * W, W, st);
+        rc = fold ? launch_gemm<EPI_BIAS_GELU, 1>(v, x16, fw2, f2c2, mlp, nullptr, (int)Mp, 4 * W, W, st, 0, f2c1, lnst)
+                  : launch_gemm<EPI_BIAS_GELU>(v, h, wp[8], (const float*)wp[9], mlp, nullptr, (int)Mp, 4 * W, W, st);
         if (rc) return rc;
+        // the last block's c_proj has no LayerNorm consumer in a GEMM (ln_post reads the class token's fp32 row in k_head)
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
-                : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
+           : (fold && l + 1 < L) ? launch_gemm<EPI_BIAS_RESID, 2>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st, 0, nullptr, lnst, x16)
+                  : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
         if (rc) return rc;
     }
     if (rh)
@@ -2066,9 +2256,19 @@ int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int
     if (!v || !c || n_crops <= 0 || !stream) return VG_ERR_ARG;          // capture needs a real (non-default) stream
     // the first encode of a process runs as plain launches: it sets the kernels' dynamic-LDS attributes (hipFuncSetAttribute), which
     // must not happen inside a capture
-    static bool warmed = false;
-    if (v->prof_on || !warmed) {                                        // event pairs cannot live in a graph: plain launches while profiling
-        warmed = true;
+    // (per handle, and the other threads wait for it: it also builds the handle's derived tensors, vit_fold_ln)
+    if (!v->warmed.load() || (v->ln_fold && !v->fold_ready.load())) {
+        static std::mutex warm_mtx;
+        std::lock_guard<std::mutex> lock(warm_mtx);
+        if (!v->warmed.load() || (v->ln_fold && !v->fold_ready.load())) {
+            int rc = vg_vit_encode(v, d_crops, input_kind, n_crops, d_workspace, d_feat, stream);
+            if (!rc) rc = vg_clip_scores(d_feat, n_crops, dim, d_text, n_classes, d_probs, d_top1, d_top1_score, stream);
+            if (!rc) VG_CHECK(hipStreamSynchronize((hipStream_t)stream));
+            v->warmed.store(true);
+            return rc;
+        }
+    }
+    if (v->prof_on) {                                                   // event pairs cannot live in a graph: plain launches while profiling
         const int rc = vg_vit_encode(v, d_crops, input_kind, n_crops, d_workspace, d_feat, stream);
         return rc ? rc : vg_clip_scores(d_feat, n_crops, dim, d_text, n_classes, d_probs, d_top1, d_top1_score, stream);
     }
