@@ -65,8 +65,11 @@ int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clust
 typedef struct vg_vit vg_vit;
 
 /* dtype 0: float32 everywhere (parity mode vs the fp32 CPU reference)
- * dtype 1: fp16 GEMM operands/activations with fp32 accumulate, fp32 LayerNorm and fp32 residual stream
- *          (what model.py:375-396 `convert_weights` gives the reference on a GPU, or better).
+ * dtype 1: fp16 GEMM operands/activations with fp32 accumulate, fp32 LayerNorm statistics and fp32 residual stream
+ *          (what model.py:375-396 `convert_weights` gives the reference on a GPU, or better).  With width % 256 == 0 the
+ *          blocks' ln_1 / ln_2 are folded into the GEMMs around them (gamma-scaled fp16 weights built once per handle at the
+ *          first encode, which therefore allocates and synchronises and must not run inside a stream capture);
+ *          VG_VIT_LN_FOLD=0 at create time keeps separate LayerNorm kernels.
  * Constraints: width % 128 == 0, width <= 1024, heads * 64 == width, tokens <= 224. */
 int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int resolution, int out_dim, int dtype);
 void vg_vit_destroy(vg_vit* v);
