@@ -15,6 +15,7 @@ benchmark can call them one by one; `process_frame` chains them.
 """
 import contextlib
 import os
+import threading
 import time
 
 import numpy as np
@@ -171,12 +172,27 @@ class PseudoLabelPipeline:
         main = self._ground_stream
         main.wait_stream(torch.cuda.current_stream(self.device))
 
+        # filling the pipeline: the first frame of every worker starts its clustering only when the frame before it has queued its
+        # crops.  Started together, the n_workers clustering stages slow each other down and the first GEMM -- the work everything
+        # else hides behind -- begins after ~25 ms instead of ~10; a ViT pass (~15 ms) is longer than a lone front stage, so the chain
+        # never starves the encoder.  Frames after the first round are not gated.
+        ramp = os.environ.get('VILGOD_FILL_RAMP', '1') != '0' and n_workers > 1
+        front_done = [threading.Event() for _ in range(min(n_workers, len(frames)))]
+
         def run(worker, i, d_pts, mask, ev):
-            with torch.cuda.stream(worker.stream):
-                worker.stream.wait_event(ev)
-                fs, res = worker.process_frame(d_pts, poses[i], ref_pose, fnr=first_fnr + i, mask=mask)
-                probs = getattr(worker, 'last_probs', None)
-                worker.stream.synchronize()
+            gate = front_done[i] if ramp and i < len(front_done) else None
+            try:
+                if gate is not None and i > 0:
+                    front_done[i - 1].wait()
+                with torch.cuda.stream(worker.stream):
+                    worker.stream.wait_event(ev)
+                    fs, res = worker.process_frame(d_pts, poses[i], ref_pose, fnr=first_fnr + i, mask=mask,
+                                                   before_classify=gate.set if gate is not None else None)
+                    probs = getattr(worker, 'last_probs', None)
+                    worker.stream.synchronize()
+            finally:
+                if gate is not None:
+                    gate.set()                   # frames without valid clusters, errors: never leave the next worker waiting
             return fs, res, probs
 
         futures = []
@@ -435,7 +451,7 @@ class PseudoLabelPipeline:
         fs.n_nonground = d_X.shape[0]
         return fs, d_ref, d_X, gidx
 
-    def process_frame(self, points, pose, ref_pose, fnr=0, state=None, timing=False, mask=None):
+    def process_frame(self, points, pose, ref_pose, fnr=0, state=None, timing=False, mask=None, before_classify=None):
         """One frame through [A]-[F].  points: (N,>=4) float32 numpy/CUDA [x,y,z,intensity,...].
         Returns (FrameState, result dict {'boxes_lidar','name','score','moving'})."""
         t = {}
@@ -458,7 +474,7 @@ class PseudoLabelPipeline:
         t0 = tick('to_ref', t0)
         labels, probs = self.cluster(d_X)
         t0 = tick('cluster', t0)
-        return self.label(fs, d_ref, d_X, gidx, labels, probs, t=t, t0=t0, tick=tick)
+        return self.label(fs, d_ref, d_X, gidx, labels, probs, t=t, t0=t0, tick=tick, before_classify=before_classify)
 
     def process_sequence(self, frames, poses, ref_pose, entropy_args=None, n_frames=2, seed=0, first_fnr=0, n_workers=1):
         """The reference's DEFAULT stage order over a whole sequence (preprocessing.yaml:50-68):
@@ -510,7 +526,7 @@ class PseudoLabelPipeline:
         futures = [workers[i % n_workers].thread.submit(run, workers[i % n_workers], i) for i in range(len(prepared))]
         return [f.result() for f in futures]
 
-    def label(self, fs, d_ref, d_X, gidx, labels, probs, entropy=None, t=None, t0=None, tick=None):
+    def label(self, fs, d_ref, d_X, gidx, labels, probs, entropy=None, t=None, t0=None, tick=None, before_classify=None):
         """Everything after clustering: detections, static flags, filters, classification, boxes, results."""
         t = {} if t is None else t
         if tick is None:
@@ -557,6 +573,8 @@ class PseudoLabelPipeline:
             st = stats.cpu().numpy()
             xy_ev.synchronize()
             box_fut = self.fit_boxes_async(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
+        if before_classify is not None:
+            before_classify()                    # the frame's clustering / filtering is done, its crops are about to be queued
         probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
         if box_fut is None:
             box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg)
