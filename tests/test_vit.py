@@ -269,6 +269,31 @@ def test_hip_folded_layernorm_on_trained_like_statistics(cuda):
 
 
 @pytest.mark.gpu
+def test_hip_folded_layernorm_follows_a_replaced_weight(cuda):
+    """The gamma-scaled weights / c1 / c2 of the folded LayerNorms are derived once per handle; vg_vit_set_weight on any tensor of a
+    block invalidates them, the next encode rebuilds them: a handle whose ln_2 gain and c_fc bias were replaced after its first
+    encode returns bit for bit what a fresh handle with the final weights returns."""
+    import ctypes
+    from vilgod_amd._lib import lib, check
+    from vilgod_amd.clip_wrapper import VitEncoder
+    rng = np.random.default_rng(2)
+    wd = cw.synthetic_vit_weights(1, **cw.VIT_B16)
+    crops = torch.from_numpy(rng.uniform(-1.8, 2.2, (3, 3, 224, 224)).astype(np.float32)).to(cuda)
+    enc = VitEncoder(wd, dtype='f16', device=cuda)
+    f_before = enc.encode(crops).clone()
+    wd2 = dict(wd)
+    for name, lo, hi in (('transformer.resblocks.4.ln_2.weight', 0.5, 2.0), ('transformer.resblocks.4.mlp.c_fc.bias', -0.5, 0.5),
+                         ('transformer.resblocks.9.ln_1.bias', -0.5, 0.5)):
+        wd2[name] = torch.from_numpy(rng.uniform(lo, hi, tuple(wd[name].shape)).astype(np.float32))
+        t = wd2[name].contiguous()
+        check(lib.vg_vit_set_weight(enc._h, name.encode(), ctypes.c_void_p(t.data_ptr()), t.numel()), 'vg_vit_set_weight')
+    f_after = enc.encode(crops)
+    f_fresh = VitEncoder(wd2, dtype='f16', device=cuda).encode(crops)
+    assert not torch.equal(f_before, f_after)
+    assert torch.equal(f_after, f_fresh)
+
+
+@pytest.mark.gpu
 def test_hip_captured_classification_equals_plain_launches(cuda):
     """BASELINE config 5's hipGraph loop: vg_vit_classify_graph (one captured graph per crop count, replayed) returns bit for bit
     what the plain launches of vg_vit_encode + vg_clip_scores return, for new crop counts (capture) and repeated ones (replay),
