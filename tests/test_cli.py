@@ -108,6 +108,41 @@ def test_cli_single_process_and_resume(cuda, tmp_path):
         assert np.array_equal(a['name'], b['name']) and np.allclose(a['boxes_lidar'], b['boxes_lidar'])
 
 
+def _same_outputs(a, sa, b, sb):
+    for x, y in zip(a, b):
+        assert np.array_equal(x['name'], y['name']) and np.array_equal(x['moving'], y['moving'])
+        assert np.array_equal(x['boxes_lidar'], y['boxes_lidar']) and np.array_equal(x['score'], y['score'])
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x['_ground_point_indices'], y['_ground_point_indices'])
+        assert len(x['_detections']) == len(y['_detections'])
+        for d, e in zip(x['_detections'], y['_detections']):
+            assert np.array_equal(d['cluster_points_index'], e['cluster_points_index']) and d['valid'] == e['valid']
+            assert d['static'] == e['static'] and d.get('static_track') == e.get('static_track') and d['tid'] == e['tid']
+            assert ('_bounding_box' in d) == ('_bounding_box' in e) and ('_bounding_box' not in d or np.array_equal(d['_bounding_box'], e['_bounding_box']))
+            assert set(d.get('object_class', {})) == set(e.get('object_class', {}))
+            for k in d.get('object_class_predictions', {}):
+                assert np.array_equal(d['object_class_predictions'][k], e['object_class_predictions'][k])
+                assert np.array_equal(d['object_class_predictions_score'][k], e['object_class_predictions_score'][k])
+
+
+@pytest.mark.gpu
+def test_cli_fused_stage_pass_equals_stage_after_stage(cuda, tmp_path):
+    """device.fuse_stages (filter + classification of a frame ride along in spatial_clustering's frame pass) changes only WHEN the
+    work runs: both pickle families equal those of the reference's stage-after-stage order, on the default 9-stage list."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import preprocess_data
+    roots = {}
+    for fuse in (True, False):
+        roots[fuse] = str(tmp_path / f'fuse_{fuse}')
+        preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={roots[fuse]}', f'device.fuse_stages={fuse}'] + OVR)
+        stages = preprocess_data.LAST_RUN['sequences'][0]['stage_ms_per_frame']
+        assert set(DEFAULT_STAGES) <= set(stages)                   # every stage still ran in its turn
+    a, ia, sa = _load(roots[True])
+    b, ib, sb = _load(roots[False])
+    assert ia == ib and len(a) == len(b) == 6 and sum(len(fr['name']) for fr in a) > 0
+    _same_outputs(a, sa, b, sb)
+
+
 @pytest.mark.gpu
 def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
     root1, root2 = str(tmp_path / 'one'), str(tmp_path / 'two')

@@ -184,6 +184,9 @@ class ZeroShotDetector:
     def process(self):
         self.logger.info(f'Processing sequence: {self.name}')
         available = [t['name'] for t in self.cfg.pipeline]
+        self._fused = self._fusion_plan()
+        if self._fused:
+            self.logger.info(f"  per-frame work of {' + '.join(self._fused)} runs inside spatial_clustering's frame pass")
         for task_name in self.cfg.pipeline_active:
             if task_name in available and hasattr(self, task_name):
                 t0 = time.perf_counter()
@@ -202,6 +205,36 @@ class ZeroShotDetector:
             self.sync_lidar_frames(final=True)
             self.stage_ms['write_sequence_state'] = 1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1)
         self.logger.info(f'Finished processing sequence: {self.name}')
+
+    def _fusion_plan(self):
+        """Which later stages' per-frame work rides along in spatial_clustering's frame pass (device.fuse_stages, default on).
+        The reference runs stage after stage over all frames (zero_shot_detector.py:58-69); on one GPU that leaves the device idle
+        while a stage's host part runs (cluster hierarchy, votes) and the host idle while the ViT runs.  filter_detections and
+        classification of a frame read only that frame's clusters, so a worker continues with them right after it has clustered
+        the frame -- one frame's GEMMs cover another frame's clustering, as in PseudoLabelPipeline.process_sequence.  The stages
+        themselves still run in their turn and find the frames done (their own skip rules: `filtered`, `key in cls`), so a
+        stage list, a resumed run or a `force: True` behave as before; the results are the same objects either way.
+        Only stages between which nothing but track_clusters (reads `valid`, writes tracks) sits are fused, never with `force`
+        (the stage would redo the work), and not with device.sync_every_stage (per-stage files on disk)."""
+        dev = self.cfg.get('device', {}) if hasattr(self.cfg, 'get') else {}
+        active = list(self.cfg.pipeline_active)
+        if not dev.get('fuse_stages', True) or self.sync_every_stage or 'spatial_clustering' not in active:
+            return {}
+        args = {t['name']: (t['args'] or {}) for t in self.cfg.pipeline}
+        plan = {}
+        for name in active[active.index('spatial_clustering') + 1:]:
+            a = args.get(name, {})
+            if name == 'filter_detections' and not a.get('force', False):
+                plan[name] = a
+            elif name == 'track_clusters':
+                continue
+            elif name == 'classification' and not a.get('force', False) and a.get('image_size', 224) == 224 \
+                    and a.get('aggregation', 'voting') == 'voting' and ('filter_detections' in plan or not a.get('valid_only', False)):
+                plan[name] = a
+                break
+            else:
+                break
+        return plan
 
     # ---- stages ------------------------------------------------------------------------------------------
     def mask_ground_points(self, min_range, z_offset, **kwargs):
@@ -345,10 +378,30 @@ class ZeroShotDetector:
                 fs.static = static_from_entropy(ent.cpu().numpy(), fs.index, fs.seg_off,
                                                 percentile=float(ecfg['percentile']) if ecfg else 30.0,
                                                 min_percentile_pp_score=float(ecfg['min_percentile_pp_score']) if ecfg else 0.5)
+            if 'filter_detections' in fused and fs.n_detections:
+                self._filter_frame(p, fnr)
+            if cls_ctx is not None and fs.n_detections and cls_ctx['key'] not in fs.cls:
+                self._classify_frame(p, fnr, cls_ctx)
 
+        fused = getattr(self, '_fused', {})
+        cls_ctx = self._classification_context(**fused['classification']) if 'classification' in fused else None
         self._for_frames(todo, body, prepare=lambda f: (self._ref_and_nonground(f), self._entropy_full(f)))
         if todo:
             self.sync_lidar_frames()
+
+    def _filter_frame(self, p, fnr):
+        """filter_detections for one frame on pipeline handle `p` (the main one or a worker's)."""
+        fs = self.lidar_frame_list[fnr]
+        ref, X = self._ref_and_nonground(fnr)
+        if p._filters['use_plane']:
+            gidx = torch.from_numpy(np.asarray(fs.ground_point_indices)).to(p.device)
+            fs.ground_plane_model_ref = p.ground_plane(ref, gidx)             # lidar_frame.py:96-109
+        else:
+            fs.ground_plane_model_ref = np.array([0.0, 0.0, 1.0, 0.0])
+        d_index, d_seg = self._cluster_lists(fnr)
+        valid, _ = p.filter(X, d_index, d_seg, fs.ground_plane_model_ref)
+        fs.valid = valid.cpu().numpy().astype(bool)
+        fs.filtered = True
 
     def filter_detections(self, **kwargs):
         force = kwargs.get('force', False)
@@ -356,57 +409,51 @@ class ZeroShotDetector:
             fs = self.lidar_frame_list[fnr]
             if fs.n_detections == 0 or (fs.filtered and not force):
                 continue
-            ref, X = self._ref_and_nonground(fnr)
-            if self.pipe._filters['use_plane']:
-                gidx = torch.from_numpy(np.asarray(fs.ground_point_indices)).to(self.pipe.device)
-                fs.ground_plane_model_ref = self.pipe.ground_plane(ref, gidx)             # lidar_frame.py:96-109
-            else:
-                fs.ground_plane_model_ref = np.array([0.0, 0.0, 1.0, 0.0])
-            d_index, d_seg = self._cluster_lists(fnr)
-            valid, _ = self.pipe.filter(X, d_index, d_seg, fs.ground_plane_model_ref)
-            fs.valid = valid.cpu().numpy().astype(bool)
-            fs.filtered = True
+            self._filter_frame(self.pipe, fnr)
         self.sync_lidar_frames()
 
-    def classification(self, image_size=224, aggregation='voting', **kwargs):
+    def _classification_context(self, image_size=224, aggregation='voting', **kwargs):
         if image_size != 224 or aggregation != 'voting':
             raise NotImplementedError('image_size 224 and voting aggregation (preprocessing.yaml) only')
-        key = kwargs.get('key', 'clip')
-        valid_only, force = kwargs.get('valid_only', False), kwargs.get('force', False)
         p = self.pipe
-        V = p.projection.num_views
-        names = np.array(p.mapped_names, dtype=object)
-        fine_names = np.array(p.class_list, dtype=object)
-        todo = [f for f in self.my_frames if self.lidar_frame_list[f].n_detections > 0
-                and (key not in self.lidar_frame_list[f].cls or force)]
         active = list(self.cfg.pipeline_active)
-        prefetch_boxes = (p.box_mode == 'reference' and 'fit_bounding_boxes_simple' in active
-                          and active.index('fit_bounding_boxes_simple') > active.index('classification'))
-        if prefetch_boxes:
-            for f in todo:
-                self._points_host(f)                     # host copy of points_ref_wo_ground, fetched on the caller's thread
-
-        def body(pw, fnr):
-            fs = self.lidar_frame_list[fnr]
-            which = fs.valid.copy() if valid_only else np.ones(fs.n_detections, bool)
-            rows = np.flatnonzero(which)
-            if len(rows) == 0:
-                return
-            X = self._dev[fnr]['X']
-            d_index, d_seg = self._cluster_lists(fnr, rows)
-            if prefetch_boxes:
+        return {'key': kwargs.get('key', 'clip'), 'valid_only': kwargs.get('valid_only', False),
+                'names': np.array(p.mapped_names, dtype=object), 'fine_names': np.array(p.class_list, dtype=object),
                 # the static rectangles of the same clusters (box_mode='reference': a helper process per request) are computed while
                 # the GPU encodes the crops; fit_bounding_boxes_simple collects them (they do not depend on the classes)
-                self._box_prefetch[fnr] = ([int(r) for r in rows], self._fit_rows(fnr, rows, X, wait=False))
-            probs, top1, score = pw.classify(X, d_index, d_seg, fs.transform_to_ego)
-            self._scores[fnr] = probs
-            fine = top1.cpu().numpy().reshape(len(rows), V)
-            sc = score.cpu().numpy().reshape(len(rows), V).astype(np.float32)
-            mapped = p.fine_to_mapped[fine]
-            win, final = vote(mapped, sc, p.mapped_names)
-            fs.set_classes(key, which, names[mapped], fine_names[fine], sc, names[win], final)
+                'prefetch_boxes': (p.box_mode == 'reference' and 'fit_bounding_boxes_simple' in active and 'classification' in active
+                                   and active.index('fit_bounding_boxes_simple') > active.index('classification'))}
 
-        self._for_frames(todo, body, prepare=self._ref_and_nonground)
+    def _classify_frame(self, pw, fnr, ctx):
+        """classification for one frame on pipeline handle `pw`."""
+        p = self.pipe
+        V = p.projection.num_views
+        fs = self.lidar_frame_list[fnr]
+        which = fs.valid.copy() if ctx['valid_only'] else np.ones(fs.n_detections, bool)
+        rows = np.flatnonzero(which)
+        if len(rows) == 0:
+            return
+        X = self._dev[fnr]['X']
+        d_index, d_seg = self._cluster_lists(fnr, rows)
+        if ctx['prefetch_boxes']:
+            self._box_prefetch[fnr] = ([int(r) for r in rows], self._fit_rows(fnr, rows, X, wait=False))
+        probs, top1, score = pw.classify(X, d_index, d_seg, fs.transform_to_ego)
+        self._scores[fnr] = probs
+        fine = top1.cpu().numpy().reshape(len(rows), V)
+        sc = score.cpu().numpy().reshape(len(rows), V).astype(np.float32)
+        mapped = p.fine_to_mapped[fine]
+        win, final = vote(mapped, sc, p.mapped_names)
+        fs.set_classes(ctx['key'], which, ctx['names'][mapped], ctx['fine_names'][fine], sc, ctx['names'][win], final)
+
+    def classification(self, image_size=224, aggregation='voting', **kwargs):
+        ctx = self._classification_context(image_size, aggregation, **kwargs)
+        force = kwargs.get('force', False)
+        todo = [f for f in self.my_frames if self.lidar_frame_list[f].n_detections > 0
+                and (ctx['key'] not in self.lidar_frame_list[f].cls or force)]
+        if ctx['prefetch_boxes']:
+            for f in todo:
+                self._points_host(f)                     # host copy of points_ref_wo_ground, fetched on the caller's thread
+        self._for_frames(todo, lambda pw, fnr: self._classify_frame(pw, fnr, ctx), prepare=self._ref_and_nonground)
         self.sync_lidar_frames()
 
     def fit_bounding_boxes_simple(self, method, **kwargs):
