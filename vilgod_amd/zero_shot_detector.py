@@ -246,11 +246,13 @@ class ZeroShotDetector:
         handoff = dev.get('ground_handoff', 'chain') if self.world_size > 1 else 'replay'
 
         def run(frames):
-            for fnr in frames:                           # sequential and stateful
-                fs = self.lidar_frame_list[fnr]
+            masks = []
+            for fnr in frames:                           # sequential and stateful: queued in frame order on one stream
                 pts = self._points(fnr) if fnr in mine else self.pipe.upload(self.dataset.get_lidar_points(fnr))
-                mask = self.pipe.ground(pts)
-                fs.n_points = pts.shape[0]
+                masks.append((fnr, pts.shape[0], self.pipe.ground(pts)))
+            for fnr, n, mask in masks:                   # read back afterwards: no host round trip between two passes
+                fs = self.lidar_frame_list[fnr]
+                fs.n_points = n
                 fs.ground_point_indices = torch.nonzero(mask).squeeze(1).cpu().numpy()
 
         mine = set(self.my_frames)
