@@ -41,6 +41,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # one hardware queue per stream in flight (vilgod_amd/__init__.py), before the runtime starts
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -374,6 +376,11 @@ def main():
             order2 = [(i // inflight) % n_distinct for i in range(n_distinct * inflight)] + [i % n_distinct for i in range(max(inflight, 2))]
             p2.process_frames([fr[c] for c in order2], [poses[1 + (i % 4)] for i in range(len(order2))], poses[0], n_workers=inflight)
             p2.new_sequence()
+            if host_frames:
+                # one untimed block of the same length: the device-side input buffers of a block (one per frame, all queued up front)
+                # then come from torch's caching allocator instead of `steps` fresh hipMalloc calls inside the timed region
+                p2.process_frames([fr[i % n_distinct] for i in range(steps)], [poses[W + i] for i in range(steps)], poses[0], n_workers=inflight)
+                p2.new_sequence()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res = p2.process_frames([fr[i % n_distinct] for i in range(steps)], [poses[W + i] for i in range(steps)], poses[0], n_workers=inflight)

@@ -19,6 +19,8 @@ import sys
 import time
 from pathlib import Path
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')      # one hardware queue per stream in flight (vilgod_amd/__init__.py), before the runtime starts
+
 import numpy as np
 import torch
 

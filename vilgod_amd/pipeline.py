@@ -105,6 +105,9 @@ class PseudoLabelPipeline:
         import threading
         self._vit_turn = {'lock': threading.Lock(), 'events': [], 'depth': int(os.environ.get('VILGOD_VIT_CONCURRENCY', '2'))}
         self.box_workers = int(box_workers)      # helper processes for the host part of the reference box mode (0 = in the frame's thread)
+        if self.box_mode == 'reference' and self.box_workers > 0:
+            from . import boxes as _boxes
+            _boxes._pool(self.box_workers)       # the helper processes import numpy / scipy (~1 s) while the tower's weights are set up
         self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         self.timings = {}
