@@ -15,9 +15,10 @@ sequence: inside the timed region rank r receives the state after frame r*K - 1 
 vg_ground_export_state / vg_ground_set_state) or replays the ground stage over the r*K frames before its block
 (`--ground-handoff replay`).  The only data-path collective is ONE all-gather of the per-crop score matrices after the K
 frames (north_star).  Inputs are resident in HBM before the timed region starts.  Each rank keeps `--inflight` frames (default
-6) in flight on worker threads with their own streams and handles; the warm-up runs at least that many frames so that every
-worker handle exists before the timed region, and the K timed frames include filling and draining that pipeline (small K
-therefore reads a little lower: the driver's K = 20 run vs the default K = 96).
+6) in flight on worker threads with their own streams and handles.  Before the warm-up a setup pass lets every worker see each
+of the four distinct clouds once (worker handles, one captured ViT graph per crop count and worker: model set-up, like weight
+loading); the K timed frames include filling and draining the pipeline (small K therefore reads a little lower: the driver's
+K = 20 run vs the default K = 96).
 
 The JSON line also carries
   roofline      the dominant kernel (the ViT projection GEMM): algorithmic FLOPs / launch duration, measured live with HIP
@@ -27,6 +28,7 @@ The JSON line also carries
                 bounded sample of the metric's workload on the host cores of the same box (rank 0, N=1 only)
 and, as information beside the metric (N=1 only; each block reports its own failure instead of costing the metric line):
   box_modes            the same frames with box_mode 'fast' (GPU hull, all edges) next to the default 'reference' mode
+  host_input           the same frames handed over as pinned HOST buffers (the copy to HBM inside the timed region)
   hipgraph_loop        the same frames with the ViT as plain stream launches next to the default captured hipGraph per crop count
   views6, dense200k    BASELINE configs 3 (6 rendered views) and 5 (200k points, ~120 objects) shapes
   default_config_mode  the reference's default stage order -- entropy scores + two-frame clustering -- as a library call
