@@ -145,3 +145,24 @@ def test_pseudo_label_exporter_roundtrip(tmp_path):
         assert a['frame_id'] == b['frame_id'] and np.array_equal(a['annos']['name'], b['annos']['name'])
         assert np.array_equal(a['annos']['gt_boxes_lidar'], b['annos']['gt_boxes_lidar'])
         assert np.array_equal(a['annos']['score'], b['annos']['score'])
+
+
+def test_stage_fusion_plan_follows_the_stage_list():
+    """ZeroShotDetector._fusion_plan: which later stages ride along in spatial_clustering's frame pass.  Only stages separated from
+    it by nothing but track_clusters, never a stage with `force` (it would redo the work), nothing with per-stage state files."""
+    from types import SimpleNamespace
+    from vilgod_amd.zero_shot_detector import ZeroShotDetector
+    cfg_dir = os.path.join(ROOT, 'tools', 'configs')
+
+    def plan(*overrides, sync=False):
+        cfg = vconfig.load(cfg_dir, 'preprocessing', ['preprocessor=waymo'] + list(overrides))
+        return list(ZeroShotDetector._fusion_plan(SimpleNamespace(cfg=cfg, sync_every_stage=sync)))
+
+    assert plan() == ['filter_detections', 'classification']                       # the reference's default 9-stage list
+    assert plan('device.fuse_stages=False') == [] and plan(sync=True) == []
+    assert plan('pipeline.5.args.force=True') == ['filter_detections']             # classification forced: runs in its own turn
+    assert plan('pipeline.3.args.force=True') == []                                # filter forced: valid_only classification needs it first
+    single = 'pipeline_active=[mask_ground_points,spatial_clustering,filter_detections,classification,fit_bounding_boxes_simple,evaluate_sequence]'
+    assert plan(single) == ['filter_detections', 'classification']
+    assert plan('pipeline_active=[mask_ground_points,spatial_clustering,classification]') == []          # valid_only without the filter stage
+    assert plan('pipeline_active=[mask_ground_points,filter_detections,classification]') == []           # no clustering stage to ride in
