@@ -177,6 +177,38 @@ def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_sequence_sharding_equals_one_rank(cuda, tmp_path):
+    """device.shard=sequences: rank r processes sequences r, r + N, ... on its own (no exchange inside a sequence) -- both pickle
+    families of every sequence equal those of a one-rank run, and rank 0's final evaluation sees all sequences in order."""
+    ovr = [o for o in OVR if not o.startswith(('dataset.SYNTHETIC.n_sequences', 'end_sequence'))] + \
+        ['dataset.SYNTHETIC.n_sequences=2', 'end_sequence=1']
+    root1, root2 = str(tmp_path / 'one'), str(tmp_path / 'two')
+    cli = os.path.join(ROOT, 'tools', 'preprocess_data.py')
+    r = subprocess.run([sys.executable, cli, 'preprocessor=waymo', f'dataset.DATA_PATH={root1}'] + ovr, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
+    logs = [open(tmp_path / f'rank{k}.log', 'w') for k in range(2)]
+    procs = [subprocess.Popen([sys.executable, cli, 'preprocessor=waymo', f'dataset.DATA_PATH={root2}', 'device.shard=sequences'] + ovr,
+                              env=dict(env, RANK=str(k), LOCAL_RANK='0'), stdout=logs[k], stderr=subprocess.STDOUT, text=True)
+             for k in range(2)]
+    _wait_all(procs)
+    for k, p in enumerate(procs):
+        logs[k].close()
+        assert p.returncode == 0, open(tmp_path / f'rank{k}.log').read()[-3000:]
+    for seq in ('synthetic_train_0000', 'synthetic_train_0001'):
+        a, ia, sa = _load(root1, seq=seq)
+        b, ib, sb = _load(root2, seq=seq)
+        assert ia == ib and len(a) == len(b) == 6 and sum(len(fr['name']) for fr in a) > 0
+        _same_outputs(a, sa, b, sb)
+    log0 = open(tmp_path / 'rank0.log').read()
+    assert 'Evaluate all Sequences' in log0 and 'Evaluate all Sequences' not in open(tmp_path / 'rank1.log').read()
+    # the one-rank run and rank 0 of the sharded run evaluate the same 12 frames: the same summary line
+    line = [ln.split('Summary over all sequences:')[1] for ln in r.stdout.splitlines() if 'Summary over all sequences:' in ln]
+    line0 = [ln.split('Summary over all sequences:')[1] for ln in log0.splitlines() if 'Summary over all sequences:' in ln]
+    assert line and line == line0
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_on_one_gpu(cuda):
     """bench.py's N > 1 path (barriers, padded all-gather of the score matrices, max-over-ranks timing, one JSON line from
     rank 0) with two processes sharing the single GPU of the test box over gloo; the driver's multi-GPU runs use RCCL."""

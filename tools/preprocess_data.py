@@ -89,7 +89,17 @@ def main(argv=None):
     if cfg.load_detection_results and Path(cfg.result_path).exists():       # preprocess_data.py:66-70: evaluate stored results only
         with Path(cfg.result_path).open('rb') as f:
             result_data = pickle.load(f)
-    for sequence_name in dataset.next_sequence():
+    # several ranks: device.shard = frames (default; north_star's configuration: every sequence's frames in contiguous blocks over the
+    # ranks, Patchwork++ state handed down the rank chain, one all-gather of the scores per sequence) or sequences (rank r takes
+    # sequences r, r + N, ...: no exchange at all until the final evaluation -- the better choice for data sets of many sequences)
+    by_sequence = world > 1 and dev.get('shard', 'frames') == 'sequences'
+    if by_sequence:
+        result_path.mkdir(parents=True, exist_ok=True)      # every rank writes the pickles of its own sequences
+    starts = []                                             # (sequence number, offsets into detection_results / indices) of this rank's sequences
+    for seq_no, sequence_name in enumerate(dataset.next_sequence()):
+        if by_sequence and seq_no % world != rank:
+            continue
+        starts.append((seq_no, len(detection_results), len(indices)))
         if result_data is not None:
             indices.extend(dataset.sequence_indices)        # (upstream leaves this empty and falls back to dataset.index_mapping)
             continue
@@ -108,7 +118,7 @@ def main(argv=None):
         zsd.process()
         detection_results.extend(zsd.detection_3d_result_list)
         indices.extend(dataset.sequence_indices)
-        if 'evaluate_sequence' in cfg.pipeline_active and rank == 0:
+        if 'evaluate_sequence' in cfg.pipeline_active and (rank == 0 or by_sequence):
             with open(result_file, 'wb') as f:
                 pickle.dump(zsd.detection_3d_result_list, f)
             with open(indices_file, 'wb') as f:
@@ -128,6 +138,13 @@ def main(argv=None):
 
     if result_data is not None:
         detection_results = result_data
+    elif by_sequence:
+        # the per-frame result dicts of every rank's sequences, back in sequence order, for the one evaluation on rank 0
+        ends = starts[1:] + [(None, len(detection_results), len(indices))]
+        local_sequences = [(s[0], detection_results[s[1]:e[1]], indices[s[2]:e[2]]) for s, e in zip(starts, ends)]
+        merged = sorted((item for part in vdist.gather_objects(local_sequences) for item in part), key=lambda it: it[0])
+        detection_results = [d for _, det, _ in merged for d in det]
+        indices = [i for _, _, idx in merged for i in idx]
     if len(detection_results) > 0 and rank == 0:
         # tools/preprocess_data.py:112-131 of the reference: one evaluation over all sequences with the evaluate_sequence arguments
         det3d_args = [pp for pp in cfg.pipeline if pp['name'] == 'evaluate_sequence'][0]['args']

@@ -41,6 +41,8 @@ class ZeroShotDetector:
         self.lenght = dataset.sequence_length          # (sic) attribute name of the reference, :31
         self.rank, self.world_size = vdist.world()
         dev = cfg.get('device', {}) if hasattr(cfg, 'get') else {}
+        if dev.get('shard', 'frames') == 'sequences':
+            self.rank, self.world_size = 0, 1            # whole sequences per rank (tools/preprocess_data.py): nothing is exchanged inside one
         if pipeline is None:
             margs = [t for t in cfg.pipeline if t['name'] == 'mask_ground_points']
             ga = margs[0]['args'] if margs else {'min_range': 1.5, 'z_offset': 1.723}
