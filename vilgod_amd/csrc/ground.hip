@@ -26,6 +26,7 @@
 #define PW_MAX_PATCHES 1024
 #define PW_STORE_CAP 2048            // ring buffers for update_elevation_/update_flatness_ (1000 + <=54 per frame)
 #define PW_LDS_POINTS 4096           // patches up to this size are processed entirely in LDS
+#define PW_BIG_LDS_POINTS 16384      // larger patches up to this size: keys sorted in LDS by k_pw_sort_big, the rest of the patch from global memory
 #define PW_T 256
 
 struct PwGeom {                      // derived in the constructor, patchworkpp.h:116-131
@@ -105,29 +106,48 @@ __global__ void k_pw_classify(const float* __restrict__ pts, int n, int stride, 
         if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 
-__global__ void k_pw_offsets(const int* __restrict__ count, int* __restrict__ offset, int* __restrict__ cursor,
-                             int n_patches) {
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int p = 0; p < n_patches; ++p) {
-            offset[p] = acc;
-            cursor[p] = 0;
-            acc += count[p];
-        }
-        offset[n_patches] = acc;
+__global__ __launch_bounds__(64) void k_pw_offsets(const int* __restrict__ count, int* __restrict__ offset, int* __restrict__ cursor,
+                                                   int n_patches) {
+    // exclusive scan of the patch sizes by one wave: lane l takes a run of patches, the runs' totals are scanned across the lanes
+    const int lane = threadIdx.x, per = (n_patches + 63) / 64;
+    const int lo = min(lane * per, n_patches), hi = min(lo + per, n_patches);
+    int run = 0;
+    for (int p = lo; p < hi; ++p) run += count[p];
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
     }
+    int acc = incl - run;
+    for (int p = lo; p < hi; ++p) {
+        offset[p] = acc;
+        cursor[p] = 0;
+        acc += count[p];
+    }
+    if (lane == 63) offset[n_patches] = incl;
 }
 
 __global__ void k_pw_scatter(const float* __restrict__ pts, int n, int stride, double z_offset,
                              const int* __restrict__ patch_id, const int* __restrict__ offset, int* __restrict__ cursor,
                              unsigned long long* __restrict__ keys) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int pid = patch_id[i];
+    // slots are reserved per workgroup: rank inside the workgroup from an LDS counter, one global atomic per (workgroup, patch).
+    // (One global atomic per point serialised on the cursors of the dense near-range patches: 197 us per scan.)  The order inside a
+    // patch is arbitrary either way; k_pw_patch / k_pw_sort_big sort the (unique) keys.
+    __shared__ int hist[PW_MAX_PATCHES];
+    for (int b = threadIdx.x; b < PW_MAX_PATCHES; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pid = i < n ? patch_id[i] : -1;
+    int local = 0;
+    if (pid >= 0) local = atomicAdd(&hist[pid], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < PW_MAX_PATCHES; b += blockDim.x)
+        if (hist[b]) hist[b] = atomicAdd(&cursor[b], hist[b]);
+    __syncthreads();
     if (pid < 0) return;
     const float z = (float)((double)pts[(size_t)i * stride + 2] - z_offset);
-    int pos = offset[pid] + atomicAdd(&cursor[pid], 1);
-    keys[pos] = ((unsigned long long)vg_fkey(z) << 32) | (unsigned int)i;
+    keys[offset[pid] + hist[pid] + local] = ((unsigned long long)vg_fkey(z) << 32) | (unsigned int)i;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -240,24 +260,33 @@ __device__ void pw_block_sums(double v[9], int cnt, double out[9], int& out_cnt,
     out_cnt = (int)(red[9] + red[19] + red[29] + red[39]);
 }
 
-// normalised bitonic network (all comparators ascending) -> works for any n with virtual +inf padding
+// normalised bitonic network (all comparators ascending) -> works for any n with virtual +inf padding.
+// A thread walks COMPARATORS (np2 / 2 per stage), not elements: comparator c of the mirror step of block size k pairs
+// i = (c / (k/2)) k + c % (k/2) with the block's mirrored position, comparator c of a step j pairs i = (c / j) 2j + c % j with i + j;
+// i grows with c, so a thread stops at the first i >= n.
 template <typename KP>
 __device__ void pw_bitonic_sort(KP keys, int n) {
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int p = i ^ (k - 1);
-            if (p > i && p < n) {
+    int np2 = 1, lg = 0;
+    while (np2 < n) { np2 <<= 1; ++lg; }
+    const int half = np2 >> 1;
+    for (int lk = 1; lk <= lg; ++lk) {                     // k = 1 << lk
+        const int hk = 1 << (lk - 1);                      // k / 2
+        for (int c = threadIdx.x; c < half; c += blockDim.x) {
+            const int o = c & (hk - 1), base = (c >> (lk - 1)) << lk;
+            const int i = base + o, p = base + ((1 << lk) - 1 - o);
+            if (i >= n) break;
+            if (p < n) {
                 unsigned long long a = keys[i], b = keys[p];
                 if (a > b) { keys[i] = b; keys[p] = a; }
             }
         }
         __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                int p = i ^ j;
-                if (p > i && p < n) {
+        for (int lj = lk - 2; lj >= 0; --lj) {             // j = 1 << lj
+            const int j = 1 << lj;
+            for (int c = threadIdx.x; c < half; c += blockDim.x) {
+                const int i = ((c >> lj) << (lj + 1)) + (c & (j - 1)), p = i + j;
+                if (i >= n) break;
+                if (p < n) {
                     unsigned long long a = keys[i], b = keys[p];
                     if (a > b) { keys[i] = b; keys[p] = a; }
                 }
@@ -285,7 +314,7 @@ __device__ void pw_patch_body(const float* __restrict__ pts, int stride, const v
             lalive[i] = 1;
         }
     } else {
-        pw_bitonic_sort(gkeys, n);
+        if (n > PW_BIG_LDS_POINTS) pw_bitonic_sort(gkeys, n);      // up to PW_BIG_LDS_POINTS k_pw_sort_big has sorted the keys already
         __threadfence_block();
         // alive flags of big patches live in the inlier array (indexed by ORIGINAL point index): 2 = alive
         for (int i = tid; i < n; i += PW_T) inlier[(unsigned int)(gkeys[i] & 0xFFFFFFFFull)] = 2;
@@ -399,6 +428,22 @@ __device__ void pw_patch_body(const float* __restrict__ pts, int stride, const v
 #undef PW_Y
 #undef PW_ALIVE
 #undef PW_KILL
+}
+
+// Patches too large for k_pw_patch's LDS image (a handful of near-range patches per scan: 4 097 ... 9 646 points on the benchmark
+// frames) used to be sorted in global memory by their 256-thread workgroup -- 105 compare-exchange stages over L2 for 9 646 keys,
+// 0.43 ms of a 1.15 ms ground pass.  Their keys alone fit the LDS of one CU: 1024 threads sort them there first (keys are unique, so
+// the order is the same one).
+__global__ __launch_bounds__(1024) void k_pw_sort_big(const vg_ground_params* __restrict__ P, const int* __restrict__ offset,
+                                                      unsigned long long* __restrict__ keys) {
+    extern __shared__ unsigned long long pw_sk[];
+    const int pid = blockIdx.x;
+    const int o = offset[pid], n = offset[pid + 1] - o;
+    if (n <= PW_LDS_POINTS || n > PW_BIG_LDS_POINTS || n < P->num_min_pts) return;      // workgroup-uniform
+    for (int i = threadIdx.x; i < n; i += blockDim.x) pw_sk[i] = keys[o + i];
+    __syncthreads();
+    pw_bitonic_sort(pw_sk, n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) keys[o + i] = pw_sk[i];
 }
 
 __global__ __launch_bounds__(PW_T) void k_pw_patch(const float* __restrict__ pts, int stride,
@@ -694,6 +739,14 @@ int vg_ground_estimate(vg_ground* h, const float* d_points, int n, int stride, d
     hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(64), 0, st, h->d_count, h->d_offset, h->d_cursor, h->g.n_patches);
     hipLaunchKernelGGL(k_pw_scatter, dim3(nb), dim3(256), 0, st, d_points, n, stride, z_offset, h->d_patch_id,
                        h->d_offset, h->d_cursor, h->d_keys);
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            VG_CHECK(hipFuncSetAttribute((const void*)k_pw_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, PW_BIG_LDS_POINTS * 8));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_pw_sort_big, dim3(h->g.n_patches), dim3(1024), PW_BIG_LDS_POINTS * 8, st, h->d_p, h->d_offset, h->d_keys);
+    }
     // k_pw_patch reads x, y straight from d_points and z from the key (already offset)
     hipLaunchKernelGGL(k_pw_patch, dim3(h->g.n_patches), dim3(PW_T), 0, st, d_points, stride, h->d_p, h->d_g, h->d_state,
                        h->d_offset, h->d_keys, h->d_inlier, h->d_rec);
