@@ -269,6 +269,34 @@ def test_hip_folded_layernorm_on_trained_like_statistics(cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('width,heads', [(256, 4), (512, 8), (1024, 16)])
+def test_hip_folded_layernorm_other_widths(cuda, width, heads):
+    """The consumer GEMM merges K / 256 partial row statistics (1, 2 and 4 here; 3 for ViT-B/16): the folded fp16 tower agrees with
+    the tower that runs separate LayerNorm kernels and with the fp32 tower at every width the 256 x 256 kernel serves."""
+    from vilgod_amd.clip_wrapper import VitEncoder
+    rng = np.random.default_rng(width)
+    wd = cw.synthetic_vit_weights(4, width=width, layers=2, heads=heads, patch=16, resolution=64, output_dim=128)
+    crops = torch.from_numpy(rng.uniform(-1.8, 2.2, (40, 3, 64, 64)).astype(np.float32)).to(cuda)
+    f32 = VitEncoder(wd, dtype='f32', device=cuda).encode(crops)
+    res = {}
+    for fold in ('1', '0'):
+        old = os.environ.get('VG_VIT_LN_FOLD')
+        os.environ['VG_VIT_LN_FOLD'] = fold
+        try:
+            enc = VitEncoder(wd, dtype='f16', device=cuda)
+        finally:
+            if old is None:
+                del os.environ['VG_VIT_LN_FOLD']
+            else:
+                os.environ['VG_VIT_LN_FOLD'] = old
+        f = enc.encode(crops)
+        assert torch.isfinite(f).all()
+        res[fold] = ((f - f32).norm() / f32.norm()).item()
+    print(f'width {width}: folded {res["1"]:.2e}, separate {res["0"]:.2e} (relative L2 vs the fp32 tower)')
+    assert res['1'] <= max(1e-3, 1.5 * res['0'])
+
+
+@pytest.mark.gpu
 def test_hip_folded_layernorm_follows_a_replaced_weight(cuda):
     """The gamma-scaled weights / c1 / c2 of the folded LayerNorms are derived once per handle; vg_vit_set_weight on any tensor of a
     block invalidates them, the next encode rebuilds them: a handle whose ln_2 gain and c_fc bias were replaced after its first
