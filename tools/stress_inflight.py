@@ -22,5 +22,6 @@ for it in range(iters):
     out = pipe.process_frames([frames[i % 4] for i in range(K)], [poses[i + 1] for i in range(K)], poses[0], n_workers=6)
     torch.cuda.synchronize()
     faulthandler.cancel_dump_traceback_later()
-    print(f'iteration {it}: {1000 * (time.perf_counter() - t0) / K:.2f} ms per frame, {sum(len(r[1]["name"]) for r in out)} labels', flush=True)
+    print(f'iteration {it}: {1000 * (time.perf_counter() - t0) / K:.2f} ms per frame, {sum(len(r[1]["name"]) for r in out)} labels, '
+          f'{torch.cuda.memory_allocated() / 2**30:.2f} GB allocated / {torch.cuda.memory_reserved() / 2**30:.2f} GB reserved', flush=True)
 print('done')
