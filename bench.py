@@ -342,7 +342,9 @@ def main():
                 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)',
                 'traffic_source': traffic_src,
                 'method': f'HIP event pairs on the launch stream around every {DOMINANT_KERNEL} launch, sequential pass (1 frame in flight) of the same frames right after the timed region',
-                'note': 'the launches also carry the blocks\' LayerNorms (folded into the GEMM epilogues; their work is not counted in the algorithmic FLOPs)',
+                'note': 'the launches also carry the blocks\' LayerNorms (folded into the GEMM epilogues; their work is not counted in the algorithmic FLOPs). '
+                        'Like for like: with separate LayerNorm kernels (VG_VIT_LN_FOLD=0) the GEMM launches alone reach 0.31, GEMM + LayerNorm launches together 0.29 '
+                        '(13.96 + 1.27 ms per frame against 14.67 ms now, profiles/r02i vs r02l)',
                 'launches': launches, 'avg_launch_us': round(1000.0 * gemm_ms / max(launches, 1), 2),
                 'algorithmic_flops_per_launch': round(gemm_flops / max(launches, 1)),
                 'gemm_ms_per_frame': round(gemm_ms / max(n_pass, 1), 3),
