@@ -305,6 +305,35 @@ def _ref_q_discrete_white_noise(dim, dt=1., var=1., block_size=1, order_by_dim=T
     return np.array(Q) * var
 
 
+def sat_iou3d(a, b):
+    """Stand-in for pcdet's boxes_iou3d_gpu: only `iou > 0` is ever tested upstream (zero_shot_detector.py:739), so the
+    values are 1.0 where the rotated BEV rectangles overlap (separating-axis test) and the z ranges overlap, else 0."""
+    a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+
+    def corners(bx):
+        c, s = np.cos(bx[6]), np.sin(bx[6])
+        dx, dy = bx[3] / 2, bx[4] / 2
+        loc = np.array([[dx, dy], [-dx, dy], [-dx, -dy], [dx, -dy]])
+        return loc @ np.array([[c, s], [-s, c]]) + bx[:2]
+
+    def overlap(p, q):
+        for poly in (p, q):
+            for i in range(4):
+                e = poly[(i + 1) % 4] - poly[i]
+                ax = np.array([-e[1], e[0]])
+                pp, qq = p @ ax, q @ ax
+                if pp.max() <= qq.min() or qq.max() <= pp.min():
+                    return False
+        return True
+
+    res = np.zeros((len(a), len(b)), np.float32)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            zo = min(x[2] + x[5] / 2, y[2] + y[5] / 2) - max(x[2] - x[5] / 2, y[2] - y[5] / 2)
+            res[i, j] = 1.0 if zo > 0 and overlap(corners(x), corners(y)) else 0.0
+    return torch.from_numpy(res)
+
+
 def track_scene():
     """The seeded scene of the N2 goldens: a short coherent sequence, clustered per frame by the oracle."""
     from vilgod_amd import synthetic
@@ -392,34 +421,6 @@ def make_track():
             row.append((name, float(score)))
         cls_in.append(row)
     out['cls_in'] = cls_in
-
-    def sat_iou3d(a, b):
-        """Stand-in for pcdet's boxes_iou3d_gpu: only `iou > 0` is ever tested upstream (zero_shot_detector.py:739), so the
-        values are 1.0 where the rotated BEV rectangles overlap (separating-axis test) and the z ranges overlap, else 0."""
-        a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
-
-        def corners(bx):
-            c, s = np.cos(bx[6]), np.sin(bx[6])
-            dx, dy = bx[3] / 2, bx[4] / 2
-            loc = np.array([[dx, dy], [-dx, dy], [-dx, -dy], [dx, -dy]])
-            return loc @ np.array([[c, s], [-s, c]]) + bx[:2]
-
-        def overlap(p, q):
-            for poly in (p, q):
-                for i in range(4):
-                    e = poly[(i + 1) % 4] - poly[i]
-                    ax = np.array([-e[1], e[0]])
-                    pp, qq = p @ ax, q @ ax
-                    if pp.max() <= qq.min() or qq.max() <= pp.min():
-                        return False
-            return True
-
-        res = np.zeros((len(a), len(b)), np.float32)
-        for i, x in enumerate(a):
-            for j, y in enumerate(b):
-                zo = min(x[2] + x[5] / 2, y[2] + y[5] / 2) - max(x[2] - x[5] / 2, y[2] - y[5] / 2)
-                res[i, j] = 1.0 if zo > 0 and overlap(corners(x), corners(y)) else 0.0
-        return torch.from_numpy(res)
 
     zsd.iou3d_nms_utils = types.SimpleNamespace(boxes_iou3d_gpu=sat_iou3d)
     zsd.ZeroShotDetector.propagate_labels(self_, classification_key='clip')
