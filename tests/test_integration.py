@@ -124,6 +124,18 @@ def _compare(g, res, idx, state):
     return bad
 
 
+def _report(bad):
+    """Mismatches grouped by kind (frame / detection numbers replaced), with a count and the first instance of each."""
+    import re
+    groups = {}
+    for m in bad:
+        groups.setdefault(re.sub(r'\d+', '#', m.split(':')[0]) + ':' + re.sub(r'[-\d.e+]+', '#', ':'.join(m.split(':')[1:]))[:80], []).append(m)
+    lines = [f'{len(bad)} mismatches against the reference harness, {len(groups)} kinds:']
+    for k, v in groups.items():
+        lines.append(f'  x{len(v)}  {v[0][:400]}')
+    return '\n'.join(lines)
+
+
 def _run_cli(g, root, extra=()):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import preprocess_data
@@ -154,7 +166,7 @@ def test_cli_reproduces_reference_harness_pickles(cuda, tmp_path, which):
     g = _golden(which)
     res, idx, state = _run_cli(g, str(tmp_path / which))
     bad = _compare(g, res, idx, state)
-    assert not bad, f'{len(bad)} mismatches against the reference harness:\n' + '\n'.join(bad[:60])
+    assert not bad, _report(bad)
 
 
 @pytest.mark.gpu
@@ -164,4 +176,4 @@ def test_cli_reproduces_reference_harness_pickles_stage_after_stage(cuda, tmp_pa
     res, idx, state = _run_cli(g, str(tmp_path / 'staged'), extra=['device.fuse_stages=False', 'device.sync_every_stage=True',
                                                                    'device.frames_in_flight=1'])
     bad = _compare(g, res, idx, state)
-    assert not bad, f'{len(bad)} mismatches against the reference harness:\n' + '\n'.join(bad[:60])
+    assert not bad, _report(bad)

@@ -133,18 +133,33 @@ class FrameState:
         C = self.n_detections
         V = pred.shape[1] if len(pred) else 0
         e = dict(has=which.copy(), pred=np.empty((C, V), object), detailed=np.empty((C, V), object),
-                 score=np.zeros((C, V), np.float32), name=np.empty(C, object), final=np.zeros(C, np.float32))
+                 score=np.zeros((C, V), np.float32), name=np.empty(C, object), final=np.zeros(C, np.float64),
+                 final_py=np.zeros(C, bool))
+        # `final`: the vote's mean is a numpy float32 upstream (lidar_frame.py:276-283); propagate_labels may replace it by a
+        # python float constant (0.5 / 0.7 / 1.0, zero_shot_detector.py:781-812), which decides the dtype of the result dict's
+        # score array (:855) -- held here as float64 values (float32 means are exact in it) + a flag "python float"
         rows = np.flatnonzero(which)
         e['pred'][rows], e['detailed'][rows], e['score'][rows] = pred, detailed, score
         e['name'][rows], e['final'][rows] = name, final_score
         self.cls[key] = e
+
+    def final_score(self, key, c):
+        """Detection.object_class_score[key] with upstream's type: numpy float32 (vote) or python float (propagated constant)."""
+        e = self.cls[key]
+        return float(e['final'][c]) if e['final_py'][c] else np.float32(e['final'][c])
+
+    def set_final_score(self, key, c, value):
+        e = self.cls[key]
+        e['final'][c] = value
+        e['final_py'][c] = not isinstance(value, np.floating)
 
     # ---- reference-compatible (de)serialisation ---------------------------------------------------------
     def detection_dict(self, c):
         d = {'cluster_id': self.cluster_ids[c]}
         if self.boxes is not None and not np.isnan(self.boxes[c, 0]):
             d['_bounding_box'] = self.boxes[c].copy()
-        d['valid'] = bool(self.valid[c])
+        # objects.py:158-181: the filters' numpy `&` leaves a numpy bool; the constructor default is the python True (:57)
+        d['valid'] = np.bool_(self.valid[c]) if self.filtered else bool(self.valid[c])
         d['static'] = bool(self.static[c])
         d['gt_assigned'] = False
         d['cluster_points_index'] = self.cluster_index(c).astype(np.int64)
@@ -157,8 +172,8 @@ class FrameState:
         if has:
             d['object_class_predictions_detailed'] = {k: self.cls[k]['detailed'][c].astype(str) for k in has}
             d['object_class_predictions_score'] = {k: self.cls[k]['score'][c].copy() for k in has}
-            d['object_class'] = {k: str(self.cls[k]['name'][c]) for k in has}
-            d['object_class_score'] = {k: self.cls[k]['final'][c] for k in has}
+            d['object_class'] = {k: np.str_(self.cls[k]['name'][c]) for k in has}      # an element of np.unique's result, lidar_frame.py:269-283
+            d['object_class_score'] = {k: self.final_score(k, c) for k in has}
         return d
 
     @property
@@ -207,4 +222,6 @@ class FrameState:
                              np.array([r['object_class_predictions_detailed'][k] for r in rows], dtype=object),
                              np.array([r['object_class_predictions_score'][k] for r in rows], dtype=np.float32),
                              np.array([r['object_class'][k] for r in rows], dtype=object),
-                             np.array([r['object_class_score'][k] for r in rows], dtype=np.float32))
+                             np.array([r['object_class_score'][k] for r in rows], dtype=np.float64))
+            for c, r in zip(np.flatnonzero(has), rows):
+                self.cls[k]['final_py'][c] = not isinstance(r['object_class_score'][k], np.floating)

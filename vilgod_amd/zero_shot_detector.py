@@ -63,6 +63,7 @@ class ZeroShotDetector:
         self.sync_every_stage = bool(dev.get('sync_every_stage', False))
         self.stage_ms = {}                               # stage name -> ms per (own) frame of the last process()
         self._dirty = False
+        self._snapshot, self._frozen = None, False       # serialised frames as of the last stage that synchronises (propagate_labels)
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
         self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
         self._host_X = {}                                # fnr -> points_ref_wo_ground on the host (tracking stages are host logic)
@@ -163,16 +164,21 @@ class ZeroShotDetector:
         if mode == 'save':
             if self.world_size > 1 and not final:
                 return                                   # several ranks: written once per run, after the gather (process())
+            if not final:
+                self._snapshot, self._frozen = None, False   # a stage synchronised: the live state is what the file holds from here on
             if not self.sync_every_stage and not final:
                 self._dirty = True                       # one write at the end of process() instead of one per stage
                 return
+            snapshot = self._snapshot if final else None
             if self.world_size > 1:
-                self._exchange_states()
+                if not (final and self._frozen):         # (the same decision on every rank: the exchange is a collective)
+                    self._exchange_states()
                 if self.rank != 0:
                     self._dirty = False
                     return
             with open(path, 'wb') as fp:
-                pickle.dump([f.serialize for f in self.lidar_frame_list], fp, protocol=pickle.HIGHEST_PROTOCOL)
+                pickle.dump(snapshot if snapshot is not None else [f.serialize for f in self.lidar_frame_list], fp,
+                            protocol=pickle.HIGHEST_PROTOCOL)
             self._dirty = False
         elif mode == 'load':
             if path.exists():
@@ -536,7 +542,7 @@ class ZeroShotDetector:
                         if fs.valid[c] and e['has'][c] and str(e['name'][c]) in self.dataset.class_names and not np.isnan(fs.boxes[c, 0]):
                             boxes.append(fs.boxes[c])
                             names.append(str(e['name'][c]))
-                            scores.append(e['final'][c])
+                            scores.append(fs.final_score(key, c))       # numpy float32 or python float: np.array() below picks the dtype like upstream
                             moving.append(fs.static_track[c] == 0)          # static_track is not None and not static_track (:843)
                 local[fnr] = {'boxes_lidar': self.pipe.boxes_to_ego(np.array(boxes).reshape(-1, 7), fs.transform_to_ego),
                               'name': np.array(names), 'score': np.array(scores),
@@ -637,7 +643,8 @@ class ZeroShotDetector:
                     fs.static_track[r] = int(bool(st))
                 fs.valid[r] = tab.valid.get(k, bool(fs.valid[r]))
                 if key is not None and key in fs.cls and k in tab.name and fs.cls[key]['has'][r]:
-                    fs.cls[key]['name'][r], fs.cls[key]['final'][r] = tab.name[k], tab.score[k]
+                    fs.cls[key]['name'][r] = tab.name[k]
+                    fs.set_final_score(key, r, tab.score[k])
 
     def propagate_labels(self, **kwargs):
         """zero_shot_detector.py:686-824."""
@@ -652,13 +659,20 @@ class ZeroShotDetector:
             if key in fs.cls:
                 e = fs.cls[key]
                 for r in np.flatnonzero(e['has']):
-                    tab.name[(fs.fnr, int(r))], tab.score[(fs.fnr, int(r))] = str(e['name'][r]), e['final'][r]
+                    tab.name[(fs.fnr, int(r))], tab.score[(fs.fnr, int(r))] = str(e['name'][r]), fs.final_score(key, int(r))
         for t in self.tracker.tracks_valid:              # upstream would raise on a tracked detection without a class
             for i, k in enumerate(t.source):
                 if not t.prediction[i] and k not in tab.name:
                     raise RuntimeError(f'propagate_labels: detection {k} is tracked but was not classified (run classification with '
                                        'the same valid_only setting as track_clusters)')
+        # Upstream's propagate_labels changes the detections in memory and does NOT call sync_lidar_frames (:686-824 ends without
+        # it; evaluate_sequence does not either): the sequence-state pickle keeps the state the last synchronising stage left
+        # (fit_bounding_boxes_simple in the shipped list) while the result pickles carry the propagated labels.  The state is
+        # written once at the end of process() here, so it is frozen now, before the labels are propagated.
+        if (self._dirty or self.world_size > 1) and not self._frozen:
+            self._frozen = True                          # every rank holds every frame's state here (_exchange_states above)
+            if self.rank == 0:
+                self._snapshot = [f.serialize for f in self.lidar_frame_list]
         propagate_labels(self.tracker, tab, lambda k: len(self.lidar_frame_list[k[0]].cluster_index(k[1])), self.dataset.class_names,
                          min_length=kwargs.get('min_length', 5))
         self._write_back_tracked(key)
-        self.sync_lidar_frames()
