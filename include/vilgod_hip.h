@@ -40,6 +40,12 @@ int vg_gather_ego(const float* d_points, int stride, const int32_t* d_index, int
 int vg_cluster_median(const float* d_ego, const int32_t* d_seg_off, int n_clusters, float* d_median,
                       double* d_rot, void* stream);
 
+/* d_rot rows for caller-supplied float32 view angles (same layout as vg_cluster_median writes).  The reference takes
+ * `np.arctan2(center_pos[1], center_pos[0])` of the float32 medians (pointcloud_utils.py:396-397): numpy's float32 arctan2
+ * is host dependent (SVML on AVX-512 hosts, libm elsewhere), so a caller that must reproduce the reference ON ITS HOST reads
+ * d_median back, evaluates np.arctan2 there and passes the angles in (device.angle_mode=reference). */
+int vg_cluster_rot(const float* d_angle, int n_clusters, double* d_rot, void* stream);
+
 /* transform_cluster_points_to_origin (pointcloud_utils.py:399-412) in float64, rounded to float32
  * (the `.float()` of zero_shot_detector.py:394).  d_point_cluster: [n] cluster id of each packed point.
  * d_Timg3x3: Rx(pi) @ Rz(pi/2) as scipy builds it (row-major f64). */

@@ -232,7 +232,9 @@ struct Oracle {
             const float inten = pts[(size_t)i * stride + 3];
             if (p.enable_RNR) {
                 float rr = x * x + y * y;
-                double r = sqrt((double)rr);
+                // patchworkpp.cpp:388: `sqrt` of a FLOAT expression under `using namespace std` (patchworkpp.h:10) is the float
+            // overload; (float)sqrt((double)rr) is that correctly rounded float root (53 >= 2*24+2 bits: no double rounding)
+            double r = (double)(float)sqrt((double)rr);
                 double zd = z;
                 double ang = atan2(zd, r) * 180 / M_PI;
                 if (ang < p.RNR_ver_angle_thr && zd < -p.sensor_height - 0.8 && (double)inten < p.RNR_intensity_thr) continue;  // noise -> non-ground

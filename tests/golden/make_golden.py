@@ -65,6 +65,42 @@ def make_render():
     print('render_golden.npz', len(cases), 'cases')
 
 
+def make_render_small():
+    """Clusters below ~50 points (valid clusters start at 10, waymo.yaml:16-30).  torch-CPU multiplies such small inputs
+    without FMA while the HIP renderer (like a GPU BLAS) uses an FMA chain, so the view-rotated points can differ in the last
+    bit and a point may cross a ceil() boundary.  To pin everything DOWNSTREAM of that 3x3 product bit for bit, the reference's
+    own `point_transform` output is frozen per view together with the images the reference makes of it
+    -> tests/golden/render_small_golden.npz; the test renders the frozen view points through an identity view."""
+    refstubs.install()
+    from src.utils import mv_utils, pointcloud_utils
+    proj = mv_utils.RealisticProjection(refstubs.projection_cfg())
+    rng = np.random.default_rng(20250103)
+    store, hashes, n = {}, [], 0
+    for P in [10, 11, 13, 16, 23, 31, 40, 49]:
+        for az, rg in [(0.9, 6.0), (-1.7, 38.0)]:
+            c = np.array([rg * np.cos(az), rg * np.sin(az), 0.6])
+            ext = rng.uniform([0.2, 0.2, 0.3], [1.8, 0.9, 0.9])
+            pts = (rng.normal(size=(P, 3)) * ext + c).astype(np.float32)
+            origin = pointcloud_utils.transform_cluster_points_to_origin(pts)
+            t = torch.from_numpy(origin).float().unsqueeze(0)
+            v = proj.translation.shape[0]
+            view_pts = proj.point_transform(points=torch.repeat_interleave(t, v, dim=0), rot_mat=proj.rot_mat.repeat(1, 1, 1))
+            img = proj.get_img(t).detach()
+            big = torch.nn.functional.interpolate(img, size=(224, 224), mode='bilinear', align_corners=True)
+            big = big.permute(0, 3, 2, 1).detach().cpu().numpy()
+            u8 = np.stack([np.uint8(b * 255) for b in big])
+            store[f'pts_{n}'] = pts
+            store[f'viewpts_{n}'] = view_pts.numpy()
+            hashes.append([sha(img[:, 0].numpy()), sha(u8[..., 0])])
+            if n % 4 == 0:
+                store[f'img_{n}'] = img[:, 0].numpy()
+                store[f'u8_{n}'] = u8[..., 0]
+            n += 1
+    store['hashes'] = np.array(hashes)
+    np.savez_compressed(os.path.join(OUT, 'render_small_golden.npz'), **store)
+    print('render_small_golden.npz', n, 'cases')
+
+
 def make_vit():
     from vilgod_amd import clip_weights as cw
     m = refstubs.load_clip_model_py()

@@ -69,7 +69,56 @@ def test_oracle_invariants_on_synthetic():
     assert np.array_equal(opw.mask_ground_points(pts, pp2, 1.723), idx)
 
 
+def _rnr_threshold_frame():
+    """A synthetic frame plus 40 dark points placed on the -15 degree noise cone (patchworkpp.cpp:388-392) exactly where the
+    float root of x*x + y*y (what the reference's `sqrt` of a float expression is) and the double root disagree about
+    `ver_angle_in_deg < -15`.  -> (points in the sensor frame, index of the first threshold point, noise flag by the float root)."""
+    rng = np.random.default_rng(0)
+    tp = []
+    while len(tp) < 40:
+        x, y = np.float32(rng.uniform(12, 40)), np.float32(rng.uniform(-5, 5))
+        rr = np.float32(np.float32(x * x) + np.float32(y * y))
+        rf, rd = np.float64(np.sqrt(rr)), np.sqrt(np.float64(rr))
+        z0 = np.float32(-rd * np.tan(np.deg2rad(15.0)))
+        for k in range(-2, 3):
+            z = z0
+            for _ in range(abs(k)):
+                z = np.nextafter(z, np.float32(-np.inf if k < 0 else np.inf))
+            af, ad = np.arctan2(np.float64(z), rf) * 180 / np.pi, np.arctan2(np.float64(z), rd) * 180 / np.pi
+            if (af < -15.0) != (ad < -15.0):
+                tp.append((x, y, z, bool(af < -15.0)))
+                break
+    pts = synthetic.make_frame(1, 60000, n_objects=5)
+    pts[:, 2] = (pts[:, 2].astype(np.float64) - 1.723).astype(np.float32)
+    extra = np.array([[x, y, z, 0.05, 0] for x, y, z, _ in tp], np.float32)
+    return np.concatenate([pts, extra]), len(pts), np.array([t[3] for t in tp])
+
+
+def test_oracle_rnr_radius_is_the_float_root():
+    """patchworkpp.cpp:388 takes `sqrt` of a float expression (float overload).  Points that only the float root
+    calls noise must be non-ground; of the points that only the DOUBLE root would call noise, most stay ground (they lie below
+    their patch plane: signed distance test)."""
+    pts, first, noise = _rnr_threshold_frame()
+    p = opw.Parameters()
+    p.min_range = 1.5
+    g = np.zeros(len(pts), bool)
+    g[opw.mask_ground_points(pts, opw.patchworkpp(p), 0.0)] = True
+    fl = g[first:]
+    assert 10 <= noise.sum() <= 30
+    assert not fl[noise].any()
+    assert fl[~noise].sum() >= 8
+
+
 # ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_hip_ground_rnr_radius_is_the_float_root(cuda):
+    pts, first, noise = _rnr_threshold_frame()
+    gpu = _same_sequence([pts, pts], 0.0, cuda)                  # kernel == oracle, twice (adapted sensor height in pass 2)
+    m = gpu.ground_mask() if hasattr(gpu, 'ground_mask') else None
+    if m is not None:
+        assert not np.asarray(m)[first:][noise].any()
+
+
 def _same_sequence(frames, z_offset, cuda, min_range=1.5, tweak=None):
     from vilgod_amd import patchworkpp as gpw
     po, pg = opw.Parameters(), gpw.Parameters()

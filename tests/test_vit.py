@@ -217,7 +217,7 @@ def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
     rel = ((f - f_want).norm() / f_want.norm()).item()
     perr = (probs - p_want).abs().max().item()
     print(f'f16 tower on {n} rendered crops: feature rel L2 {rel:.2e}, max prob err {perr:.2e}')
-    assert rel <= 1e-3 and perr <= 2e-3
+    assert rel <= 1e-3 and perr <= 1e-3            # north_star's bound for the fp32 logits, met by the fp16 tower too (measured 4-6e-4)
     srt = np.sort(p_want.numpy(), axis=1)
     sure = (srt[:, -1] - srt[:, -2]) > 4e-3
     assert np.array_equal(top1[sure], vo.top1(p_want)[0][sure])

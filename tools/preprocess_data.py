@@ -72,7 +72,8 @@ def main(argv=None):
                                    vit_dtype=dev.get('vit_dtype', 'f16'), n_views=dev.get('n_views', 4),
                                    max_points=dev.get('max_points', 300_000), clip_model_path=cfg.paths.clip_model,
                                    min_range=ga['min_range'], z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666),
-                                   box_mode=dev.get('box_mode', 'reference'), box_workers=dev.get('box_workers', 4))
+                                   box_mode=dev.get('box_mode', 'reference'), box_workers=dev.get('box_workers', 4),
+                                   angle_mode=dev.get('angle_mode', 'reference'))
     logger.info(f'CLIP weights: {pipeline.clip.weights_source}')
 
     result_path = Path(cfg.paths.results) / cfg.results_folder / '_'.join(cfg.pipeline_active)

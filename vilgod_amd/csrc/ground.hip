@@ -81,7 +81,9 @@ __global__ void k_pw_classify(const float* __restrict__ pts, int n, int stride, 
         bool noise = false;
         if (P->enable_RNR) {
             float rr = x * x + y * y;
-            double r = sqrt((double)rr);
+            // patchworkpp.cpp:388: `sqrt` of a FLOAT expression under `using namespace std` (patchworkpp.h:10) is the float
+            // overload; (float)sqrt((double)rr) is that correctly rounded float root (53 >= 2*24+2 bits: no double rounding)
+            double r = (double)(float)sqrt((double)rr);
             double zd = z;
             double ang = atan2(zd, r) * 180 / M_PI;
             noise = ang < P->RNR_ver_angle_thr && zd < -S->sensor_height - 0.8 && (double)inten < P->RNR_intensity_thr;

@@ -130,6 +130,23 @@ __global__ __launch_bounds__(768) void k_cluster_median(const float* __restrict_
     }
 }
 
+// The rotation entries of k_cluster_median for view angles supplied by the caller (angle_mode='reference': the host's
+// own float32 np.arctan2 of the medians, which is what the reference evaluates at pointcloud_utils.py:397).
+__global__ void k_cluster_rot(const float* __restrict__ angle, int n, double* __restrict__ out_rot) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float ang = angle[c];
+    double a = -(double)ang;
+    double s = sin(a * 0.5), w = cos(a * 0.5);
+    double z2 = s * s, w2 = w * w, zw = s * w;
+    out_rot[c * 6 + 0] = -z2 + w2;
+    out_rot[c * 6 + 1] = 2.0 * (-zw);
+    out_rot[c * 6 + 2] = 2.0 * zw;
+    out_rot[c * 6 + 3] = -z2 + w2;
+    out_rot[c * 6 + 4] = z2 + w2;
+    out_rot[c * 6 + 5] = (double)ang;
+}
+
 // ---------------------------------------------------------------------------------------------
 // D1 (pointcloud_utils.py:399-412).  cluster id of point i comes from a per-point label array.
 __global__ void k_to_origin(const float* __restrict__ ego, const int* __restrict__ pt_cluster, int n,
@@ -487,6 +504,14 @@ int vg_cluster_median(const float* d_ego, const int32_t* d_seg_off, int n_cluste
     if (!d_ego || !d_seg_off || !d_median || !d_rot) return VG_ERR_ARG;
     hipLaunchKernelGGL(k_cluster_median, dim3(n_clusters), dim3(768), 0, (hipStream_t)stream, d_ego, d_seg_off,
                        d_median, d_rot);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+int vg_cluster_rot(const float* d_angle, int n_clusters, double* d_rot, void* stream) {
+    if (n_clusters <= 0) return VG_OK;
+    if (!d_angle || !d_rot) return VG_ERR_ARG;
+    hipLaunchKernelGGL(k_cluster_rot, dim3(vg_div_up(n_clusters, 64)), dim3(64), 0, (hipStream_t)stream, d_angle, n_clusters, d_rot);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }

@@ -64,7 +64,7 @@ def _get(cfg, key, default=None):
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
                  clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
-                 box_mode='reference', box_workers=4, vit_graph=True):
+                 box_mode='reference', box_workers=4, vit_graph=True, angle_mode='device'):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -81,8 +81,9 @@ class PseudoLabelPipeline:
         self.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **mcfg)
         self.prob_threshold = float(_get(ccfg, 'propability_threshold', 0.3))
         self._filters = self._parse_filters(ccfg)
+        self.angle_mode = angle_mode             # view direction angle: 'device' | 'reference' (this host's numpy; projection.py)
         self.projection = RealisticProjection(_get(cfg, 'lidar_image_projection'), device=self.device,
-                                              views=VIEWS_4 if n_views == 4 else VIEWS_6)
+                                              views=VIEWS_4 if n_views == 4 else VIEWS_6, angle_mode=angle_mode)
         clip_cfg = _get(cfg, 'clip')
         self.clip = clip if clip is not None else ClipWrapper(clip_cfg, clip_model_path, device=self.device, dtype=vit_dtype)
         self.vit_dtype = vit_dtype
@@ -122,7 +123,7 @@ class PseudoLabelPipeline:
         w = copy.copy(self)
         w.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **self._mcfg)
         w.projection = RealisticProjection(_get(self.cfg, 'lidar_image_projection'), device=self.device,
-                                           views=VIEWS_4 if self._n_views == 4 else VIEWS_6)
+                                           views=VIEWS_4 if self._n_views == 4 else VIEWS_6, angle_mode=self.angle_mode)
         w.clip = self.clip.view()                # shared read-only weights, own workspace
         w._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         w._xy_pinned = None

@@ -6,6 +6,8 @@ host (:405-409, clip.py:79-86).  Here `render_frame` renders every cluster x vie
 HIP kernels of csrc/render.hip and returns the ViT-ready crops without leaving the GPU; `get_img`
 keeps the reference's per-call interface for parity tests.
 """
+import contextlib
+
 import numpy as np
 import torch
 from scipy.spatial.transform import Rotation
@@ -47,7 +49,7 @@ def _gaussian_taps(sigma):
 
 
 class RealisticProjection:
-    def __init__(self, lidar_image_projection_cfg, device='cuda', views=None):
+    def __init__(self, lidar_image_projection_cfg, device='cuda', views=None, angle_mode='device'):
         cfg = lidar_image_projection_cfg
         get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, 'get') else (lambda k, d=None: getattr(cfg, k, d))
         self.resolution = get('resolution', 112)
@@ -60,6 +62,12 @@ class RealisticProjection:
         gk = get('gaussian_kernel', {'sigma': 3, 'zsigma': 1})
         sigma = gk['sigma'] if isinstance(gk, dict) else gk.sigma
         views = VIEWS_4 if views is None else views
+        # view direction angle of a cluster (pointcloud_utils.py:397, float32 np.arctan2 of the median): 'device' = correctly
+        # rounded on the GPU (no host round trip); 'reference' = this host's numpy evaluates it, like the reference would here
+        # (numpy's float32 arctan2 is a <= 1 ulp routine that differs between hosts -- DESIGN.md section 4)
+        if angle_mode not in ('device', 'reference'):
+            raise ValueError(f'angle_mode {angle_mode!r}: device | reference')
+        self.angle_mode = angle_mode
         self.num_views = len(views)
         self.device = torch.device(device)
         self.rot_mat = _euler_to_rotmat(views).transpose(1, 2).contiguous()          # mv_utils.py:165-166
@@ -112,6 +120,11 @@ class RealisticProjection:
         med = torch.empty((n_clusters, 3), dtype=torch.float32, device=dev)
         rot = torch.empty((n_clusters, 6), dtype=torch.float64, device=dev)
         check(lib.vg_cluster_median(ptr(ego), ptr(seg_off), n_clusters, ptr(med), ptr(rot), sp), 'vg_cluster_median')
+        if self.angle_mode == 'reference':
+            with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                m = med.cpu().numpy()                                     # [C,3] float32: one small read-back per frame
+                ang = torch.from_numpy(np.arctan2(m[:, 1], m[:, 0])).to(dev)
+            check(lib.vg_cluster_rot(ptr(ang), n_clusters, ptr(rot), sp), 'vg_cluster_rot')
         # per-point cluster id from the offsets
         ar = torch.arange(ptot, device=dev, dtype=torch.int32)
         pt_cluster = (torch.searchsorted(seg_off[1:].contiguous(), ar, right=True)).to(torch.int32)
