@@ -14,11 +14,14 @@ sequence (vilgod_amd/zero_shot_detector.py, vilgod_amd/dist.py).  Patchwork++'s 
 sequence: inside the timed region rank r receives the state after frame r*K - 1 from rank r - 1 (`--ground-handoff chain`,
 vg_ground_export_state / vg_ground_set_state) or replays the ground stage over the r*K frames before its block
 (`--ground-handoff replay`).  The only data-path collective is ONE all-gather of the per-crop score matrices after the K
-frames (north_star).  Inputs are resident in HBM before the timed region starts.  Each rank keeps `--inflight` frames (default
-6) in flight on worker threads with their own streams and handles.  Before the warm-up a setup pass lets every worker see each
-of the four distinct clouds once (worker handles, one captured ViT graph per crop count and worker: model set-up, like weight
-loading); the K timed frames include filling and draining the pipeline (small K therefore reads a little lower: the driver's
-K = 20 run vs the default K = 96).
+frames (north_star).  The run is a real stream: every one of the W + K frames of a rank is a DISTINCT seeded synthetic cloud (no
+cycling -- a new crop count almost every frame), handed over as a pinned HOST buffer (SURVEY 8d's clock: "raw points resident in
+host pinned memory" to "result dict on the host"; the copy to HBM is queued inside the timed region; `--input resident` uploads
+the K clouds before the clock starts instead and is reported as the `resident_input` block).  Each rank keeps `--inflight` frames
+(default 6) in flight on worker threads with their own streams and handles.  The ViT runs as plain stream launches (default) or
+as captured hipGraphs per crop-count bucket (`--vit-graph`; captures then happen INSIDE the timed region and are counted in
+`config.graphs_captured`).  The K timed frames include filling and draining the pipeline (small K therefore reads a little
+lower: the driver's K = 20 run vs the default K = 96).
 
 The JSON line also carries
   roofline      the dominant kernel (the ViT projection GEMM): algorithmic FLOPs / launch duration, measured live with HIP
@@ -28,8 +31,8 @@ The JSON line also carries
                 bounded sample of the metric's workload on the host cores of the same box (rank 0, N=1 only)
 and, as information beside the metric (N=1 only; each block reports its own failure instead of costing the metric line):
   box_modes            the same frames with box_mode 'fast' (GPU hull, all edges) next to the default 'reference' mode
-  host_input           the same frames handed over as pinned HOST buffers (the copy to HBM inside the timed region)
-  hipgraph_loop        the same frames with the ViT as plain stream launches next to the default captured hipGraph per crop count
+  resident_input       the same frames uploaded to HBM before the clock starts (what rounds 1-2 quoted as the metric)
+  hipgraph_loop        the same frames with the ViT as captured hipGraphs (per crop-count bucket, LRU-bounded) next to the default plain launches
   views6, dense200k    BASELINE configs 3 (6 rendered views) and 5 (200k points, ~120 objects) shapes
   default_config_mode  the reference's default stage order -- entropy scores + two-frame clustering -- as a library call
   cli_mode             tools/preprocess_data.py itself: the default 9-stage list on a 199-frame 150k-point synthetic sequence
@@ -147,7 +150,10 @@ def main():
     ap.add_argument('--box-mode', default='reference', choices=['reference', 'fast'])
     ap.add_argument('--ground-handoff', default='chain', choices=['chain', 'replay'],
                     help='N > 1: how rank r obtains the Patchwork++ state at the start of its frame block (both inside the timed region)')
-    ap.add_argument('--no-vit-graph', action='store_true', help='plain stream launches for the ViT instead of the captured hipGraph per crop count')
+    ap.add_argument('--vit-graph', action='store_true', help='captured hipGraphs (one per crop-count bucket and worker, LRU-bounded) for the ViT instead of plain stream launches')
+    ap.add_argument('--input', default='host', choices=['host', 'resident'],
+                    help='host: every frame is handed over as a pinned host buffer, H2D inside the timed region (SURVEY 8d); resident: uploaded before the clock starts')
+    ap.add_argument('--angle-mode', default='device', choices=['device', 'reference'], help='view angle of a cluster: on the GPU, or by this host\'s numpy (projection.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the information blocks beside the metric (box_modes, views6, dense200k, cli_mode)')
     ap.add_argument('--cli-frames', type=int, default=199, help='frames of the synthetic sequence of the cli_mode block')
@@ -183,31 +189,34 @@ def main():
     from vilgod_amd import synthetic, dist as vdist
     from vilgod_amd.pipeline import PseudoLabelPipeline
     pipe = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=args.views, max_points=args.points + 1024,
-                               clip_model_path='/nonexistent', box_mode=args.box_mode, vit_graph=not args.no_vit_graph)
+                               clip_model_path='/nonexistent', box_mode=args.box_mode, vit_graph=args.vit_graph, angle_mode=args.angle_mode)
     K, W = args.steps, max(args.warmup, args.inflight if args.inflight > 1 else 0)       # warm-up covers the worker handles
     # ONE sequence of world * K timed frames (+ a warm-up stretch in front), contiguous block of K frames per rank, smooth
-    # trajectory; four distinct point clouds per rank are cycled, resident in HBM
-    n_distinct = 4
+    # trajectory; every frame of the stream is a distinct seeded cloud (pinned host memory; `--input resident`: in HBM)
     poses = synthetic.make_poses(W + world * K + 8, seed=0)
-    frames = [pipe.upload(synthetic.make_frame(1 + rank * 100 + i, args.points, n_objects=args.objects)) for i in range(n_distinct)]
+    host_frames = [torch.from_numpy(synthetic.make_frame(1 + rank * 100_000 + i, args.points, n_objects=args.objects)).pin_memory()
+                   for i in range(W + K)]
+    frames = [f.to(dev) for f in host_frames] if args.input == 'resident' else host_frames
     torch.cuda.synchronize()
     inflight = 1 if args.stage_times else max(1, args.inflight)
     stage = {}
 
-    def run_steps(p, first_pose, count, first_fnr, after_ground=None):
-        """`count` frames whose poses start at index `first_pose`; returns [(FrameState, result, probs)]."""
+    def run_steps(p, first_pose, count, first_fnr, after_ground=None, first_frame=0, src=None):
+        """`count` frames whose poses start at index `first_pose` and whose clouds start at `first_frame` of the stream;
+        returns [(FrameState, result, probs)]."""
+        src = frames if src is None else src
         idx = list(range(count))
         if inflight == 1:
             out = []
             for i in idx:
-                fs, res = p.process_frame(frames[i % n_distinct], poses[first_pose + i], poses[0], fnr=first_fnr + i, timing=args.stage_times)
+                fs, res = p.process_frame(p.upload(src[first_frame + i]), poses[first_pose + i], poses[0], fnr=first_fnr + i, timing=args.stage_times)
                 out.append((fs, res, p.last_probs))
                 for k, v in p.timings.items():
                     stage[k] = stage.get(k, 0.0) + v
             if after_ground is not None:
                 after_ground()
             return out
-        return p.process_frames([frames[i % n_distinct] for i in idx], [poses[first_pose + i] for i in idx], poses[0],
+        return p.process_frames([src[first_frame + i] for i in idx], [poses[first_pose + i] for i in idx], poses[0],
                                 n_workers=inflight, first_fnr=first_fnr, after_ground=after_ground)
 
     def timed_block(p):
@@ -220,16 +229,16 @@ def main():
         p.new_sequence()
         out = []
         if world > 1 and args.ground_handoff == 'replay':
-            for i in range(rank * K):                    # the frames before this rank's block: ground stage only
-                p.ground(frames[i % n_distinct])
-            out = run_steps(p, W + rank * K, K, rank * K)
+            for i in range(rank * K):                    # the frames before this rank's block: ground stage only (the other ranks'
+                p.ground(p.upload(frames[W + i % K]))    # clouds are not held here: this rank's own stand in, same cost)
+            out = run_steps(p, W + rank * K, K, rank * K, first_frame=W)
         elif world > 1:
             # chain: the block's ground passes are queued first on the caller's stream (process_frames does that), the state after
             # them is exported and sent on while the workers are already busy with the block's frames
             vdist.recv_ground_state(p.ground_model, dev)
-            out = run_steps(p, W + rank * K, K, rank * K, after_ground=lambda: vdist.send_ground_state(p.ground_model, dev))
+            out = run_steps(p, W + rank * K, K, rank * K, after_ground=lambda: vdist.send_ground_state(p.ground_model, dev), first_frame=W)
         else:
-            out = run_steps(p, W, K, 0)
+            out = run_steps(p, W, K, 0, first_frame=W)
         score_mats = [probs for _, _, probs in out]
         # the one collective of the path: all-gather of the per-crop score matrices (padded to a common length)
         scores = torch.cat(score_mats) if score_mats else torch.zeros((0, 24), device=dev)
@@ -280,17 +289,17 @@ def main():
         dist.barrier()
 
     pipe.new_sequence()
-    if inflight > 1 and not args.no_vit_graph:
-        # one-time setup, like building the worker handles: every worker sees each of the distinct point clouds once, so that the
-        # hipGraph of its ViT (one per crop count and worker) is captured BEFORE the warm-up and the timed steps (the
-        # metric excludes model load and graph capture); frame i goes to worker i % inflight
-        order = [(i // inflight) % n_distinct for i in range(n_distinct * inflight)]
-        pipe.process_frames([frames[c] for c in order], [poses[1 + (i % 4)] for i in range(len(order))], poses[0], n_workers=inflight)
-        pipe.new_sequence()
     run_steps(pipe, 0, W, 0)                                   # warm-up, also builds the worker handles
     comm_warmup()
     stage = {}
+    def graph_stats(p):
+        st = [w._graph_cls.stats() for w in (p._workers or []) + [p] if getattr(w, '_graph_cls', None) is not None]
+        return {k: sum(s_[k] for s_ in st) for k in ('graphs_captured', 'graph_launches', 'graphs_evicted', 'graphs_live')} if st else \
+            {'graphs_captured': 0, 'graph_launches': 0, 'graphs_evicted': 0, 'graphs_live': 0}
+
+    g_before = graph_stats(pipe)
     elapsed, outs = timed_block(pipe)
+    g_after = graph_stats(pipe)
     crops = sum(p.shape[0] for _, _, p in outs)
     clusters = sum(fs.n_detections for fs, _, _ in outs)
     labelled = sum(len(res['name']) for _, res, _ in outs)
@@ -303,7 +312,7 @@ def main():
     if not args.no_roofline_pass:
         pipe.clip.encoder.profile(True)
         for i in range(n_pass):
-            pipe.process_frame(frames[i % n_distinct], poses[i + 1], poses[0], fnr=i)
+            pipe.process_frame(pipe.upload(frames[W + i]), poses[i + 1], poses[0], fnr=i)
         launches, gemm_ms, gemm_flops = pipe.clip.encoder.profile_read(kind=1)        # the dominant kernel alone
         all_launches, all_ms, all_flops = pipe.clip.encoder.profile_read(kind=-1)
         pipe.clip.encoder.profile(False)
@@ -330,6 +339,12 @@ def main():
                              f'{world}-way in contiguous blocks' + (f', ground state by {args.ground_handoff}' if world > 1 else '') +
                              ', one all-gather of the score matrices'),
                 'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,
+                'distinct_frames': len({id(f) for f in frames[W:W + K]}), 'distinct_crop_counts': len({int(p.shape[0]) for _, _, p in outs}),
+                'input': ('pinned host buffers, H2D copy inside the timed region' if args.input == 'host' else 'resident in HBM before the timed region'),
+                'vit_launch': 'captured hipGraphs per crop-count bucket' if args.vit_graph else 'plain stream launches',
+                'graphs_captured': g_after['graphs_captured'] - g_before['graphs_captured'],
+                'graph_launches': g_after['graph_launches'] - g_before['graph_launches'],
+                'angle_mode': args.angle_mode,
                 'clusters_per_frame': round(clusters / max(K, 1), 1),
                 'crops_per_frame': round(crops / max(K, 1), 1),
                 'labelled_per_frame': round(labelled / max(K, 1), 1),
@@ -367,29 +382,28 @@ def main():
             except Exception as e:          # noqa: BLE001
                 out[name] = {'error': f'{type(e).__name__}: {e}'}
 
-        def other_shape(points, objects, views, steps, box_mode=None, vit_graph=None, host_frames=False):
+        def other_shape(points, objects, views, steps, box_mode=None, vit_graph=None, resident=None, angle_mode=None):
+            """The metric's run on a second pipeline object (same tower) with one knob changed, or on another frame shape: `steps`
+            distinct clouds after a warm-up stretch of distinct clouds, same input mode as the metric unless `resident` says otherwise."""
             p2 = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=views, max_points=points + 1024, clip_model_path='/nonexistent',
                                      clip=pipe.clip, box_mode=box_mode or args.box_mode,
-                                     vit_graph=(not args.no_vit_graph) if vit_graph is None else vit_graph)
-            fr = frames if points == args.points and objects == args.objects else \
-                [p2.upload(synthetic.make_frame(501 + i, points, n_objects=objects)) for i in range(n_distinct)]
-            if host_frames:
-                fr = [f.cpu().pin_memory() for f in fr]          # the boundary hands over host buffers: H2D inside the timed region
+                                     vit_graph=args.vit_graph if vit_graph is None else vit_graph, angle_mode=angle_mode or args.angle_mode)
+            if points == args.points and objects == args.objects:
+                fr = host_frames
+            else:
+                fr = [torch.from_numpy(synthetic.make_frame(501 + i, points, n_objects=objects)).pin_memory() for i in range(W + steps)]
+            if (args.input == 'resident') if resident is None else resident:
+                fr = [f.to(dev) for f in fr]
             p2.new_sequence()
-            # the same preparation as the metric's run: every worker sees each distinct cloud once (graph capture), then a warm-up stretch
-            order2 = [(i // inflight) % n_distinct for i in range(n_distinct * inflight)] + [i % n_distinct for i in range(max(inflight, 2))]
-            p2.process_frames([fr[c] for c in order2], [poses[1 + (i % 4)] for i in range(len(order2))], poses[0], n_workers=inflight)
+            p2.process_frames(fr[:W], [poses[i] for i in range(W)], poses[0], n_workers=inflight)      # warm-up: worker handles
             p2.new_sequence()
-            if host_frames:
-                # one untimed block of the same length: the device-side input buffers of a block (one per frame, all queued up front)
-                # then come from torch's caching allocator instead of `steps` fresh hipMalloc calls inside the timed region
-                p2.process_frames([fr[i % n_distinct] for i in range(steps)], [poses[W + i] for i in range(steps)], poses[0], n_workers=inflight)
-                p2.new_sequence()
             torch.cuda.synchronize()
+            g0 = graph_stats(p2)
             t0 = time.perf_counter()
-            res = p2.process_frames([fr[i % n_distinct] for i in range(steps)], [poses[W + i] for i in range(steps)], poses[0], n_workers=inflight)
+            res = p2.process_frames(fr[W:W + steps], [poses[W + i] for i in range(steps)], poses[0], n_workers=inflight)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            other_shape.graphs = {k: v - g0[k] for k, v in graph_stats(p2).items()}
             return dt, res
 
         if extras:
@@ -412,17 +426,19 @@ def main():
             block('box_modes', box_modes)
 
             def hipgraph_loop():
-                on = not args.no_vit_graph
+                on = args.vit_graph
                 dt, res = other_shape(args.points, args.objects, args.views, K, vit_graph=not on)
                 same = all(np.array_equal(a[1]['name'], b[1]['name']) and np.array_equal(a[2].cpu().numpy(), b[2].cpu().numpy()) for a, b in zip(outs, res))
-                stats = [w._graph_cls.stats() for w in (pipe._workers or []) if getattr(w, '_graph_cls', None) is not None]
+                gs = other_shape.graphs if not on else {k: g_after[k] - g_before[k] for k in g_after}
                 return {'captured': {'value': round(value if on else K / dt, 3), 'unit': 'frames/s'},
                         'plain_launches': {'value': round(K / dt if on else value, 3), 'unit': 'frames/s'},
                         'identical_scores_and_names': bool(same),
-                        'graphs_captured': sum(s_['graphs_captured'] for s_ in stats), 'graph_launches': sum(s_['graph_launches'] for s_ in stats),
-                        'note': 'captured = the ViT encode + scores of a frame (~150 kernels) replayed as one hipGraph per distinct crop count, per '
-                                'worker; ground / clustering / rendering have frame-dependent launch dimensions and the hierarchy is built on '
-                                'the host, so they stay stream launches around the graph (BASELINE config 5)'}
+                        'graphs_captured_in_timed_region': gs['graphs_captured'], 'graph_launches': gs['graph_launches'],
+                        'graphs_evicted': gs['graphs_evicted'], 'distinct_crop_counts': len({int(r[2].shape[0]) for r in res}),
+                        'note': 'captured = the ViT encode + scores of a frame (~150 kernels) replayed as one hipGraph per crop-count bucket (crops '
+                                'rounded up to a multiple of 8, padding crops never read), per worker, at most 32 graphs kept (LRU); the captures of '
+                                'this distinct-frame stream happen inside the timed region.  Ground / clustering / rendering have frame-dependent '
+                                'launch dimensions and the hierarchy is built on the host, so they stay stream launches around the graph (BASELINE config 5)'}
             block('hipgraph_loop', hipgraph_loop)
 
             def shape_block(points, objects, views, cfg_name):
@@ -432,14 +448,29 @@ def main():
                             'clusters_per_frame': round(sum(r[0].n_detections for r in res) / K, 1),
                             'crops_per_frame': round(sum(r[2].shape[0] for r in res) / K, 1), 'workload': cfg_name}
                 return fn
-            def host_input():
-                dt, res = other_shape(args.points, args.objects, args.views, K, host_frames=True)
+            def resident_input():
+                dt, res = other_shape(args.points, args.objects, args.views, K, resident=(args.input == 'host'))
                 same = all(np.array_equal(a[1]['name'], b[1]['name']) for a, b in zip(outs, res))
-                return {'value': round(K / dt, 3), 'unit': 'frames/s', 'bytes_per_frame': int(frames[0].numel() * frames[0].element_size()),
-                        'same_names_as_resident_run': bool(same),
-                        'note': 'the same steps with every frame handed over as a pinned HOST buffer (the copy to HBM inside the timed region); '
-                                '`value` above is quoted with the frames resident in HBM'}
-            block('host_input', host_input)
+                return {'value': round(K / dt, 3), 'unit': 'frames/s', 'bytes_per_frame': int(host_frames[0].numel() * host_frames[0].element_size()),
+                        'same_names_as_metric_run': bool(same),
+                        'note': ('the same steps with every frame uploaded to HBM before the clock starts' if args.input == 'host' else
+                                 'the same steps with every frame handed over as a pinned HOST buffer (the copy to HBM inside the timed region)')}
+            block('resident_input' if args.input == 'host' else 'host_input', resident_input)
+
+            def angle_modes():
+                other = 'reference' if args.angle_mode == 'device' else 'device'
+                dt, res = other_shape(args.points, args.objects, args.views, K, angle_mode=other)
+                n = flips = 0
+                for a, b in zip(outs, res):
+                    if np.array_equal(a[0].valid, b[0].valid) and pipe.cls_key in a[0].cls and pipe.cls_key in b[0].cls:
+                        rows = np.flatnonzero(a[0].valid)
+                        n += len(rows)
+                        flips += int(sum(str(a[0].cls[pipe.cls_key]['name'][r]) != str(b[0].cls[pipe.cls_key]['name'][r]) for r in rows))
+                return {args.angle_mode: {'value': round(value, 3), 'unit': 'frames/s'}, other: {'value': round(K / dt, 3), 'unit': 'frames/s'},
+                        'clusters_compared': n, 'class_names_that_differ': flips,
+                        'note': "view direction angle of a cluster (pointcloud_utils.py:397): 'device' = correctly rounded atan2 on the GPU, 'reference' = "
+                                "this host's float32 np.arctan2 of the device medians (one [C,3] read-back per frame); they differ by <= 1 ulp"}
+            block('angle_modes', angle_modes)
             block('views6', shape_block(args.points, args.objects, 6, 'BASELINE config 3 as written: 150k points, 6 rendered views'))
             block('dense200k', shape_block(200_000, 120, args.views, 'BASELINE config 5 shape: dense 200k-point frames, ~120 objects, fp16 ViT'))
         if world == 1 and not args.no_sequence_pass and not args.stage_times:

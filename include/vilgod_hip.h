@@ -124,6 +124,9 @@ typedef struct vg_graph_cache vg_graph_cache;
 int vg_graph_cache_create(vg_graph_cache** out);
 void vg_graph_cache_destroy(vg_graph_cache* c);
 int vg_graph_cache_stats(const vg_graph_cache* c, int64_t* h_captured, int64_t* h_replayed);
+/* at most `max_graphs` graphExecs are kept (default 32); the least recently used one is destroyed when a new crop count arrives */
+int vg_graph_cache_limit(vg_graph_cache* c, int max_graphs);
+int vg_graph_cache_stats2(const vg_graph_cache* c, int64_t* h_captured, int64_t* h_replayed, int64_t* h_evicted, int64_t* h_live);
 int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                           const float* d_text, int dim, int n_classes, float* d_probs, int32_t* d_top1, float* d_top1_score, void* stream);
 

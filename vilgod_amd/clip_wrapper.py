@@ -107,12 +107,18 @@ class GraphClassifier:
     `patch_buffer(n)`; `classify(n)` replays (or, the first time a crop count shows up, captures) the graph of the ViT encode +
     scores on the current stream and returns views of the persistent outputs -- valid until the worker's next frame."""
 
-    def __init__(self, encoder, text_features, max_crops=512):
+    BUCKET = 8          # crop counts are rounded up to a multiple of this: a real stream has a new crop count almost every frame, a
+                        # graph per exact count would be captured (~150 nodes + instantiate) for most frames.  The rows of the
+                        # padding crops hold finite data of an earlier frame; their outputs are never read (<= 7 crops of ~330: ~1 %)
+
+    def __init__(self, encoder, text_features, max_crops=512, max_graphs=32):
         assert encoder.dtype == 'f16' and encoder.cfg['patch'] == 16 and encoder.cfg['resolution'] == 224
         self.enc, self.text = encoder, text_features
         self.device = encoder.device
+        self.max_graphs = int(max_graphs)
         self._cache = ctypes.c_void_p()
         check(lib.vg_graph_cache_create(ctypes.byref(self._cache)), 'vg_graph_cache_create')
+        check(lib.vg_graph_cache_limit(self._cache, self.max_graphs), 'vg_graph_cache_limit')
         self.cap = 0
         self._alloc(max_crops)
 
@@ -122,7 +128,8 @@ class GraphClassifier:
             lib.vg_graph_cache_destroy(self._cache)
             self._cache = ctypes.c_void_p()
             check(lib.vg_graph_cache_create(ctypes.byref(self._cache)), 'vg_graph_cache_create')
-        self.cap = int(n)
+            check(lib.vg_graph_cache_limit(self._cache, self.max_graphs), 'vg_graph_cache_limit')
+        self.cap = (int(n) + self.BUCKET - 1) // self.BUCKET * self.BUCKET
         rows = (self.cap * 196 + 255) // 256 * 256
         K = self.text.shape[0]
         self.patches = torch.zeros((rows, 768), dtype=torch.float16, device=self.device)
@@ -144,17 +151,21 @@ class GraphClassifier:
             self._alloc(max(n, int(self.cap * 1.5)))
         return self.patches
 
-    def classify(self, n):
+    def classify(self, n, text_features=None):
         """-> (probs [n,K], top1 [n], score [n]) views of the persistent outputs."""
-        check(lib.vg_vit_classify_graph(self.enc._h, self._cache, ptr(self.patches), 2, n, ptr(self.ws), ptr(self.feat), ptr(self.text),
+        if text_features is not None and text_features is not self.text:
+            assert text_features.shape == self.text.shape
+            self.text = text_features                # (its pointer is part of the graph key: new features -> new graphs)
+        nb = min(self.cap, (n + self.BUCKET - 1) // self.BUCKET * self.BUCKET)
+        check(lib.vg_vit_classify_graph(self.enc._h, self._cache, ptr(self.patches), 2, nb, ptr(self.ws), ptr(self.feat), ptr(self.text),
                                         self.feat.shape[1], self.text.shape[0], ptr(self.probs), ptr(self.top1), ptr(self.score),
                                         stream_ptr()), 'vg_vit_classify_graph')
         return self.probs[:n], self.top1[:n], self.score[:n]
 
     def stats(self):
-        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(lib.vg_graph_cache_stats(self._cache, ctypes.byref(a), ctypes.byref(b)), 'vg_graph_cache_stats')
-        return {'graphs_captured': a.value, 'graph_launches': b.value}
+        a, b, c, d = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib.vg_graph_cache_stats2(self._cache, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)), 'vg_graph_cache_stats2')
+        return {'graphs_captured': a.value, 'graph_launches': b.value, 'graphs_evicted': c.value, 'graphs_live': d.value}
 
 
 def clip_scores(feat, text_features, stream=None):

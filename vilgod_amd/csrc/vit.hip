@@ -1115,6 +1115,9 @@ struct vg_vit {
     // "#c1", "#c2" and are rebuilt when any of their inputs is set again.
     bool ln_fold = false;
     std::atomic<bool> fold_ready{false}, warmed{false};
+    // bumped whenever a device tensor the kernels read is replaced (vg_vit_set_weight, vit_fold_ln): part of the captured graphs'
+    // key, so a graph that holds pointers to freed weights is never replayed
+    std::atomic<uint64_t> weights_gen{0};
     std::mutex mtx;
     std::map<std::string, void*> w32;
 };
@@ -1860,6 +1863,7 @@ static int vit_fold_ln(vg_vit* v, hipStream_t st) {
         }
     }
     VG_CHECK(hipStreamSynchronize(st));          // other threads' streams may use the tensors as soon as the flag is up
+    v->weights_gen.fetch_add(1);
     v->fold_ready.store(true);
     return VG_OK;
 }
@@ -1923,6 +1927,7 @@ int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t 
     }
     v->w[n] = d;
     v->numel[n] = (size_t)numel;
+    v->weights_gen.fetch_add(1);
     return VG_OK;
 }
 
@@ -2227,11 +2232,16 @@ int vg_clip_scores(const float* d_feat, int n, int dim, const float* d_text, int
 struct vg_graph_key {
     int n_crops, input_kind, dim, n_classes;
     const void *crops, *ws, *feat, *text, *probs, *top1, *score;
+    const void* tower;            // the handle and the generation of its device tensors (weights are baked into the kernel nodes)
+    uint64_t weights_gen;
     bool operator<(const vg_graph_key& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
 };
+struct vg_graph_entry { hipGraphExec_t exec; long last_use; };
 struct vg_graph_cache {
-    std::map<vg_graph_key, hipGraphExec_t> graphs;
-    long captured = 0, replayed = 0;
+    std::map<vg_graph_key, vg_graph_entry> graphs;
+    long captured = 0, replayed = 0, evicted = 0, clock = 0;
+    int limit = 32;               // graphs kept (least recently used one is destroyed beyond that): a real sequence has a new crop
+                                  // count almost every frame, an unbounded cache would grow to hundreds of graphExecs per worker
 };
 
 int vg_graph_cache_create(vg_graph_cache** out) {
@@ -2242,8 +2252,23 @@ int vg_graph_cache_create(vg_graph_cache** out) {
 
 void vg_graph_cache_destroy(vg_graph_cache* c) {
     if (!c) return;
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
     delete c;
+}
+
+int vg_graph_cache_limit(vg_graph_cache* c, int max_graphs) {
+    if (!c || max_graphs < 1) return VG_ERR_ARG;
+    c->limit = max_graphs;
+    return VG_OK;
+}
+
+int vg_graph_cache_stats2(const vg_graph_cache* c, int64_t* h_captured, int64_t* h_replayed, int64_t* h_evicted, int64_t* h_live) {
+    if (!c) return VG_ERR_ARG;
+    if (h_captured) *h_captured = c->captured;
+    if (h_replayed) *h_replayed = c->replayed;
+    if (h_evicted) *h_evicted = c->evicted;
+    if (h_live) *h_live = (int64_t)c->graphs.size();
+    return VG_OK;
 }
 
 int vg_graph_cache_stats(const vg_graph_cache* c, int64_t* h_captured, int64_t* h_replayed) {
@@ -2279,6 +2304,7 @@ int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int
     memset(&key, 0, sizeof(key));
     key.n_crops = n_crops; key.input_kind = input_kind; key.dim = dim; key.n_classes = n_classes;
     key.crops = d_crops; key.ws = d_workspace; key.feat = d_feat; key.text = d_text; key.probs = d_probs; key.top1 = d_top1; key.score = d_top1_score;
+    key.tower = v; key.weights_gen = v->weights_gen.load();
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         // thread-local capture mode: the other workers keep launching on their streams meanwhile
@@ -2296,10 +2322,20 @@ int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         VG_CHECK(e);
-        it = c->graphs.emplace(key, exec).first;
+        while ((int)c->graphs.size() >= c->limit) {                    // least recently used out (its launches are stream-ordered
+            auto lru = c->graphs.begin();                               // before this point; hipGraphExecDestroy defers the release)
+            for (auto j = c->graphs.begin(); j != c->graphs.end(); ++j)
+                if (j->second.last_use < lru->second.last_use) lru = j;
+            VG_CHECK(hipStreamSynchronize(st));
+            (void)hipGraphExecDestroy(lru->second.exec);
+            c->graphs.erase(lru);
+            c->evicted++;
+        }
+        it = c->graphs.emplace(key, vg_graph_entry{exec, 0}).first;
         c->captured++;
     }
-    VG_CHECK(hipGraphLaunch(it->second, st));
+    it->second.last_use = ++c->clock;
+    VG_CHECK(hipGraphLaunch(it->second.exec, st));
     c->replayed++;
     return VG_OK;
 }

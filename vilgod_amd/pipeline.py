@@ -64,7 +64,7 @@ def _get(cfg, key, default=None):
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
                  clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
-                 box_mode='reference', box_workers=4, vit_graph=True, angle_mode='device'):
+                 box_mode='reference', box_workers=4, vit_graph=False, angle_mode='device'):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -98,7 +98,9 @@ class PseudoLabelPipeline:
             raise ValueError("box_mode: 'reference' (the reference's boxes: qhull vertex order, closing edge dropped) or 'fast' "
                              "(GPU hull + rectangle over all edges)")
         self.box_mode = box_mode
-        # hipGraph-captured classification (BASELINE config 5): one graph per distinct crop count, per worker (clip_wrapper.GraphClassifier)
+        # hipGraph-captured classification (BASELINE config 5): one graph per crop-count bucket, per worker, LRU-bounded
+        # (clip_wrapper.GraphClassifier).  Off by default: with several frames in flight the launch overhead is already hidden
+        # (bench.py `hipgraph_loop`: captured == plain launches within noise) and a real stream keeps meeting new crop counts.
         self.vit_graph = bool(vit_graph)
         self._graph_cls = None
         self._ground_stream = None
@@ -210,8 +212,17 @@ class PseudoLabelPipeline:
                 futures.append(w.thread.submit(run, w, i, d_pts, mask, ev))
             if after_ground is not None:
                 after_ground()         # every ground pass of the block is queued: e.g. hand the ground state to the next rank
-        out = [f.result() for f in futures]
-        torch.cuda.current_stream(self.device).wait_stream(main)
+        out, first_error = [], None
+        try:
+            for f in futures:                  # drain every worker even when one frame failed: nothing keeps running behind the caller's back
+                try:
+                    out.append(f.result())
+                except BaseException as e:     # noqa: BLE001
+                    first_error = first_error or e
+        finally:
+            torch.cuda.current_stream(self.device).wait_stream(main)
+        if first_error is not None:
+            raise first_error
         return out
 
     @staticmethod
@@ -327,7 +338,7 @@ class PseudoLabelPipeline:
                 g = self._graph_cls
                 self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16', out_buf=g.patch_buffer(n))
                 with self._vit_in_turn():
-                    probs, top1, score = g.classify(n)
+                    probs, top1, score = g.classify(n, self.clip.text_features)
                 return probs.clone(), top1.clone(), score.clone()
             patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16')
             with self._vit_in_turn():
