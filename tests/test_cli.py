@@ -258,6 +258,38 @@ def test_cli_on_openpcdet_layout(cuda, tmp_path, kind, caplog):
     assert 'Vehicle AP  L2:' in text and 'Vehicle APH L2:' in text
     ap = float(text.split('Vehicle AP  L2:')[1].split()[0])
     assert 0.0 <= ap <= 100.0
+    # what the entry point's evaluation must print for detections whose quality is known: the generator's own ground truth
+    # handed in as detections (load_detection_results) is AP = APH = 100.00; the ground truth of the first three frames only is
+    # precision 1 up to recall n_first / n_total
+    from vilgod_amd import config as vconfig, evaluation as ev
+    ov = [f'preprocessor={kind}', f'dataset={kind}_openpcdet', f'dataset.DATA_PATH={root}', 'end_sequence=1', 'device.max_points=24000',
+          'paths.clip_model=/nonexistent', 'pipeline.8.args.detection_3d.class_agnostic=True', 'pipeline.8.args.eval_range=[-75.,-75.,75.,75.]']
+    cfg = vconfig.load(os.path.join(ROOT, 'tools', 'configs'), 'preprocessing', ov)
+    ds = vconfig.instantiate(cfg.dataset_class, logger=logging.getLogger('t'), training=True, start_sequence=0, end_sequence=1)
+    ds.training = False
+    next(iter(ds.next_sequence()))
+    truth = []
+    for i in ds.sequence_indices:
+        a = ds.infos[i]['annos']
+        keep = np.isin(a['name'], ds.class_names) & (a['num_points_in_gt'] > 0)
+        truth.append({'boxes_lidar': a['gt_boxes_lidar'][keep][:, :7].astype(np.float64), 'name': a['name'][keep],
+                      'score': np.full(int(keep.sum()), 0.9, np.float32), 'moving': np.zeros(int(keep.sum()), bool)})
+    assert sum(len(t['name']) for t in truth) > 10
+    first = [t if k < 3 else {'boxes_lidar': np.zeros((0, 7)), 'name': np.array([]), 'score': np.array([]), 'moving': np.array([], bool)}
+             for k, t in enumerate(truth)]
+    _, gts = ev.filter_for_evaluation(ds, truth, ds.class_names, indices=ds.sequence_indices, class_agnostic=True,
+                                      eval_range=[-75., -75., 75., 75.], moving=False, static=False, score_thresh=0.0, sampling_rate=1)
+    n_gt = [int((g['num_points_in_gt'] > 0).sum()) for g in gts]
+    for name_, dets, want in (('all', truth, 100.0), ('first3', first, 100.0 * sum(n_gt[:3]) / sum(n_gt))):
+        path = str(tmp_path / f'{kind}_{name_}.pkl')
+        with open(path, 'wb') as f:
+            pickle.dump(dets, f)
+        caplog.clear()
+        with caplog.at_level(logging.INFO):
+            preprocess_data.main(ov + ['load_detection_results=True', f'result_path={path}'])
+        for key in ('Vehicle AP  L2:', 'Vehicle APH L2:'):
+            got = float(caplog.text.split(key)[1].split()[0])
+            assert abs(got - want) <= 0.006, (name_, key, got, want)
     # load_detection_results: evaluate the stored result pickle without processing anything (preprocess_data.py:66-70,108-110)
     stages = '_'.join(DEFAULT_STAGES)
     caplog.clear()

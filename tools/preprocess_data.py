@@ -132,7 +132,8 @@ def main(argv=None):
                                       dataset.sequence_indices, class_names=dataset.class_names)
         torch.cuda.synchronize()
         LAST_RUN['sequences'].append({'name': sequence_name, 'frames': dataset.sequence_length, 'world_size': world,
-                                      'seconds': time.perf_counter() - t_seq, 'stage_ms_per_frame': dict(zsd.stage_ms)})
+                                      'seconds': time.perf_counter() - t_seq, 'stage_ms_per_frame': dict(zsd.stage_ms),
+                                      'detail_ms': dict(zsd.detail_ms)})
         del zsd
         gc.collect()
         torch.cuda.empty_cache()

@@ -15,3 +15,5 @@ with tempfile.TemporaryDirectory() as root:
 seq = preprocess_data.LAST_RUN['sequences'][0]
 print(f"frames {seq['frames']}  {1000 * seq['seconds'] / seq['frames']:.2f} ms per frame  ({seq['frames'] / seq['seconds']:.2f} frames/s)  " +
       '  '.join(f'{k} {v:.2f}' for k, v in seq['stage_ms_per_frame'].items()))
+if seq.get('detail_ms'):
+    print('parts (ms per frame): ' + '  '.join(f"{k} {v / seq['frames']:.3f}" for k, v in seq['detail_ms'].items()))

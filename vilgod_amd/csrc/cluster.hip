@@ -46,6 +46,10 @@
 struct ClGrid {
     double ox, oy, oz;                // world coordinate of cell (0,0,0)'s min corner
     unsigned int kmin[3], kmax[3];    // ordered-int bbox keys (scratch for the reduction)
+    double inf;                       // +infinity, set by the host.  Kernels that keep a wave-uniform float64 in SGPRs read it from
+                                      // here: ROCm 7.2's gfx950 back end materialises a uniform `double x = INFINITY` as
+                                      // `s_mov_b64 s[..], 0x7ff0000000000000`, which gfx9 cannot encode (32-bit literals only; the
+                                      // assembler rejects the line, the direct object emission truncates it to 0.0)
 };
 
 struct vg_cluster {
@@ -375,6 +379,239 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
     }
     core2[i] = h[k];
     if (dbg_scan) dbg_scan[i] = scanned;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cooperative exact k-NN core distances (north_star: "LDS-staged radius-neighbour / HDBSCAN core-distance kernel over
+// Morton-sorted points with coalesced HBM reads").  Two phases, both exact, both bit-identical to the walk above (the same
+// float64 pair distances; the k-th smallest value does not depend on the order in which the pairs are met):
+//   A  k_cl_core_blk   one WAVE per (0.8 m block, 64 queries): the queries of a level-1 node are 64 consecutive sorted points,
+//                      lane = query.  The 27 neighbouring level-1 nodes are 27 contiguous ranges of the sorted array: they are
+//                      read with coalesced loads (one point per lane), staged in LDS as float64 and scanned by every lane
+//                      (broadcast reads) into its register top-16 (min / max chain, entered only when some lane improves).  A
+//                      neighbour node is skipped when its box is at least as far as every lane's current k-th distance.  A
+//                      lane is DONE when its k-th distance does not exceed the distance to the shell's outer faces (nothing
+//                      outside the 2.4 m cube can be closer); the others -- isolated points, ~8 % of a LiDAR frame -- go on a
+//                      list with their k-th distance so far as an upper bound.
+//   B  k_cl_core_far   one WAVE per listed query, lane = candidate: the level-L 3x3x3 shell that covers the bound (L = 2..6) is
+//                      expanded to its 27 x 64 level-(L-2) sub-nodes lane-parallel (range + box distance per lane), the
+//                      sub-nodes nearer than the running k-th distance are streamed 64 points at a time (coalesced), and the
+//                      wave keeps ONE sorted list of the smallest distances across lanes 0..15 (insert = two DPP shifts, max,
+//                      min).  No per-lane dependent walk: the slowest lane of the old kernel (an isolated point opening ~100
+//                      nodes, each behind two dependent reads of the 64 MB cell table) no longer sets the launch time.
+__constant__ signed char CLB_ORDER[27][3] = {
+    {0, 0, 0},
+    {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+    {-1, -1, 0}, {1, -1, 0}, {-1, 1, 0}, {1, 1, 0}, {-1, 0, -1}, {1, 0, -1}, {-1, 0, 1}, {1, 0, 1}, {0, -1, -1}, {0, 1, -1}, {0, -1, 1}, {0, 1, 1},
+    {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
+#define CLB_TILE 128                  // candidates staged per pass (two coalesced loads per lane)
+
+// work list of phase A: one entry (first query index) per 64 consecutive points of a level-1 node
+__global__ void k_cl_blocks(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ cs,
+                            int* __restrict__ entries, int* __restrict__ counters) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int key = code_s[i] >> 3;
+    if (i > 0 && (code_s[i - 1] >> 3) == key) return;
+    const int end = cl_start(cs, (key + 1u) << 3);
+    const int chunks = (end - i + 63) >> 6;
+    const int base = atomicAdd(&counters[2], chunks);
+    for (int c = 0; c < chunks; ++c) entries[base + c] = i + (c << 6);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void k_cl_core_blk(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
+                                                    const ClGrid* __restrict__ gp, const int* __restrict__ cs,
+                                                    const unsigned int* __restrict__ code_s, const int* __restrict__ entries,
+                                                    int* __restrict__ counters, int k, double* __restrict__ core2,
+                                                    int* __restrict__ far_list, int* __restrict__ dbg_scan) {
+    __shared__ int bnd[27][2];
+    __shared__ double tile[DIM][CLB_TILE];
+    const int lane = threadIdx.x;
+    const ClGrid g = *gp;
+    const int n_entries = counters[2];
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const int i0 = entries[e];
+        const unsigned int key = code_s[i0] >> 3;
+        const int iend = min(cl_start(cs, (key + 1u) << 3), i0 + 64);
+        const int i = i0 + lane;
+        const bool active = i < iend;
+        const float4 qf = spts[active ? i : i0];
+        const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[active ? i : i0] : 0.0;
+        int bx, by, bz;                                   // the node's coordinates at level 1 (wave-uniform: from its first point)
+        {
+            const float4 f0 = spts[i0];
+            cl_cell_of(g, (double)f0.x, (double)f0.y, (double)f0.z, bx, by, bz);
+            bx >>= 1; by >>= 1; bz >>= 1;
+        }
+        __syncthreads();                                  // the previous entry's reads of bnd / tile are over
+        if (lane < 27) {
+            const int nx = bx + CLB_ORDER[lane][0], ny = by + CLB_ORDER[lane][1], nz = bz + CLB_ORDER[lane][2];
+            int j0 = 0, j1 = 0;
+            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (CL_NX >> 1) && ny < (CL_NY >> 1) && nz < (CL_NZ >> 1)) {
+                const unsigned int c0 = cl_code(nx << 1, ny << 1, nz << 1);
+                j0 = cl_start(cs, c0);
+                j1 = cl_start(cs, c0 + 8u);
+            }
+            bnd[lane][0] = j0;
+            bnd[lane][1] = j1;
+        }
+        __syncthreads();
+        double h[CL_K];
+#pragma unroll
+        for (int j = 0; j < CL_K; ++j) h[j] = INFINITY;
+        int scanned = 0;
+        for (int t = 0; t < 27; ++t) {
+            const int j0 = bnd[t][0], j1 = bnd[t][1];
+            if (j0 == j1) continue;
+            // the node's box against every lane's k-th distance so far (same rule as the walk: >= cannot lower it)
+            const double nb2 = cl_box_d2(g, qx, qy, qz, 1, bx + CLB_ORDER[t][0], by + CLB_ORDER[t][1], bz + CLB_ORDER[t][2]);
+            if (!__any(active && nb2 < h[k])) continue;
+            for (int base = j0; base < j1; base += CLB_TILE) {
+                const int cnt = min(CLB_TILE, j1 - base);
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < CLB_TILE / 64; ++r) {
+                    const int c = lane + 64 * r;
+                    if (c < cnt) {
+                        const float4 p = spts[base + c];
+                        tile[0][c] = (double)p.x; tile[1][c] = (double)p.y; tile[2][c] = (double)p.z;
+                        if (DIM >= 4) tile[3 < DIM ? 3 : 0][c] = (double)p.w;
+                        if (DIM >= 5) tile[4 < DIM ? 4 : 0][c] = (double)stt[base + c];
+                    }
+                }
+                __syncthreads();
+                scanned += cnt;
+                for (int c = 0; c < cnt; ++c) {
+                    const double dx = qx - tile[0][c], dy = qy - tile[1][c], dz = qz - tile[2][c];
+                    double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (DIM >= 4) { const double de = qe - tile[3 < DIM ? 3 : 0][c]; d2 = d2 + de * de; }
+                    if (DIM >= 5) { const double dt = qt - tile[4 < DIM ? 4 : 0][c]; d2 = d2 + dt * dt; }
+                    if (__any(d2 < h[CL_K - 1])) {
+#pragma unroll
+                        for (int u = 0; u < CL_K; ++u) {
+                            const double lo = fmin(h[u], d2);
+                            d2 = fmax(h[u], d2);
+                            h[u] = lo;
+                        }
+                    }
+                }
+            }
+        }
+        // nothing outside the 3 x 3 x 3 shell is nearer than its outer faces
+        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, 1);
+        const bool done = h[k] <= r2;
+        if (active) {
+            core2[i] = h[k];                              // final, or an upper bound for phase B
+            if (dbg_scan) dbg_scan[i] = scanned;
+        }
+        const unsigned long long far = __ballot(active && !done);
+        if (far) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counters[3], __popcll(far));
+            base = __shfl(base, 0);
+            if (active && !done) far_list[base + __popcll(far & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+}
+
+// value of lane l - 1 within the 16-lane row (0 for the row's first lane): the neighbour a sorted insert needs
+__device__ __forceinline__ double cl_row_shr1(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), 0x111, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x111, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double cl_readlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(64) void k_cl_core_far(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
+                                                    const ClGrid* __restrict__ gp, const int* __restrict__ cs,
+                                                    const int* __restrict__ far_list, const int* __restrict__ counters, int k,
+                                                    double* __restrict__ core2, int* __restrict__ dbg_scan, int force_level) {
+    const int lane = threadIdx.x;
+    const ClGrid g = *gp;
+    const int n_far = counters[3];
+    for (int u = blockIdx.x; u < n_far; u += gridDim.x) {
+        const int i = far_list[u];
+        const float4 qf = spts[i];
+        const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[i] : 0.0;
+        int cx, cy, cz;
+        cl_cell_of(g, qx, qy, qz, cx, cy, cz);
+        const double bound = core2[i];                    // phase A's k-th distance: the true one is not larger
+        int L = 2;
+        while (L < CL_LMAX && !(bound <= cl_block_radius2(g, qx, qy, qz, cx >> L, cy >> L, cz >> L, L))) ++L;
+        if (isinf(bound)) L = 3;
+        if (force_level) L = force_level;
+        double hs = g.inf;                                // lanes 0..15: the smallest distances so far, ascending
+        double T = g.inf;                                 // = lane k's entry (wave-uniform; see ClGrid::inf)
+        int scanned = 0;
+        for (;;) {
+            hs = g.inf; T = g.inf;
+            auto stream = [&](int j0, int j1) {
+#ifdef VG_DEV
+                if (dbg_scan && u == 0 && lane == 0) { const int w = atomicAdd(&dbg_scan[n + 1], 2); if (w < 200) { dbg_scan[n + 100 + w] = j0; dbg_scan[n + 100 + w + 1] = j1; } }
+#endif
+                for (int base = j0; base < j1; base += 64) {
+                    const int j = base + lane;
+                    double d2 = INFINITY;
+                    if (j < j1) d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, spts[j], stt, j);
+                    scanned += min(64, j1 - base);
+                    unsigned long long pm = __ballot(d2 < T);
+                    while (pm) {
+                        const int b = __ffsll((long long)pm) - 1;
+                        pm &= pm - 1;
+                        const double v = cl_readlane_d(d2, b);
+                        if (v < T) {
+                            hs = fmin(fmax(v, cl_row_shr1(hs)), hs);
+                            T = cl_readlane_d(hs, k);
+                        }
+                    }
+                }
+            };
+            if (L > CL_LMAX) {                            // the grid's roots did not settle it: every point (exact for any input)
+                stream(0, n);
+                break;
+            }
+            const int BX = cx >> L, BY = cy >> L, BZ = cz >> L;
+            const int l2 = L - 2;
+            for (int t = 0; t < 27; ++t) {
+                const int nx = BX + CLB_ORDER[t][0], ny = BY + CLB_ORDER[t][1], nz = BZ + CLB_ORDER[t][2];
+                if (nx < 0 || ny < 0 || nz < 0 || nx >= (CL_NX >> L) || ny >= (CL_NY >> L) || nz >= (CL_NZ >> L)) continue;
+                if (cl_box_d2(g, qx, qy, qz, L, nx, ny, nz) >= T) continue;
+                // the node's 64 level-(L-2) sub-nodes, one per lane (Morton order: consecutive ranges)
+                const unsigned int c0 = cl_code(nx << L, ny << L, nz << L);
+                const int s0 = cl_start(cs, c0 + ((unsigned int)lane << (3 * l2)));
+                const int s1 = cl_start(cs, c0 + ((unsigned int)(lane + 1) << (3 * l2)));
+                const int sx = (nx << 2) | (((lane >> 3) & 1) << 1) | (lane & 1);
+                const int sy = (ny << 2) | (((lane >> 4) & 1) << 1) | ((lane >> 1) & 1);
+                const int sz = (nz << 2) | (((lane >> 5) & 1) << 1) | ((lane >> 2) & 1);
+                const double sb2 = cl_box_d2(g, qx, qy, qz, l2, sx, sy, sz);
+                unsigned long long sm = __ballot(s0 != s1 && sb2 < T);
+                while (sm) {
+                    const int b = __ffsll((long long)sm) - 1;
+                    sm &= sm - 1;
+                    if (cl_readlane_d(sb2, b) >= T) continue;
+                    stream(__builtin_amdgcn_readlane(s0, b), __builtin_amdgcn_readlane(s1, b));
+                }
+            }
+            if (T <= cl_block_radius2(g, qx, qy, qz, BX, BY, BZ, L)) break;
+            ++L;
+        }
+        if (lane == 0) {
+            core2[i] = T;
+            if (dbg_scan) dbg_scan[i] += scanned;
+        }
+#ifdef VG_DEV
+        if (dbg_scan && u == 0 && lane < 16) dbg_scan[n + 16 + lane] = __float_as_int((float)hs);
+        if (dbg_scan && u == 0 && lane == 0) { dbg_scan[n + 2] = i; dbg_scan[n + 3] = L; dbg_scan[n + 4] = __float_as_int((float)T); dbg_scan[n + 5] = __float_as_int((float)bound); }
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,7 +1082,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_mst_idx_s, 4 * n));
     VG_CHECK(hipHostMalloc((void**)&h->h_counter, 64));
     h->d_dbg = nullptr;
-    if (getenv("VG_CLUSTER_DEBUG")) VG_CHECK(hipMalloc(&h->d_dbg, 4 * n));
+    if (getenv("VG_CLUSTER_DEBUG")) VG_CHECK(hipMalloc(&h->d_dbg, 4 * n + 4096));     // + 1024 ints of scratch for VG_DEV dumps
     size_t t1 = 0, t2 = 0, t3 = 0;
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t1, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, n, 0, 24));
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t2, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, n, 0, 64));
@@ -875,6 +1112,7 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
     ClGrid g0;
     memset(&g0, 0, sizeof(g0));
     for (int a = 0; a < 3; ++a) { g0.kmin[a] = 0xFFFFFFFFu; g0.kmax[a] = 0u; }
+    g0.inf = INFINITY;
     VG_CHECK(hipMemcpyAsync(h->d_grid, &g0, sizeof(g0), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_cl_bbox, dim3(std::min(nb, 64)), dim3(256), 0, st, d_points, n, stride, h->d_grid);
     hipLaunchKernelGGL(k_cl_grid, dim3(1), dim3(64), 0, st, h->d_grid);
@@ -896,18 +1134,48 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
 
 template <int DIM>
 static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
-    hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, h->d_cell_e, k, h->d_core2, h->d_dbg);
+    static const int walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;   // 1: the per-point tree walk (A/B aid)
+    if (walk) {
+        hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                           h->d_cell_start, h->d_cell_e, k, h->d_core2, h->d_dbg);
+    } else {
+        // counters[2] = work-list entries of phase A, counters[3] = queries left for phase B; lists in buffers Boruvka fills later
+        (void)hipMemsetAsync(h->d_counter + 2, 0, 8, st);
+#ifdef VG_DEV
+        if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg, 0, 4 * (size_t)n + 4096, st);
+#endif
+        hipLaunchKernelGGL(k_cl_blocks, dim3(vg_div_up(n, 256)), dim3(256), 0, st, n, h->d_code_s, h->d_cell_start, h->d_parent, h->d_counter);
+        hipLaunchKernelGGL((k_cl_core_blk<DIM>), dim3(std::min(n, 16384)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
+                           h->d_code_s, h->d_parent, h->d_counter, k, h->d_core2, h->d_parent2, h->d_dbg);
+        if (!getenv("VG_CLUSTER_CORE_NOFAR"))
+        hipLaunchKernelGGL((k_cl_core_far<DIM>), dim3(std::min(n, 8192)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
+                           h->d_parent2, h->d_counter, k, h->d_core2, h->d_dbg, getenv("VG_CLUSTER_FAR_LEVEL") ? atoi(getenv("VG_CLUSTER_FAR_LEVEL")) : 0);
+    }
     if (h->d_dbg) {
         // VG_CLUSTER_DEBUG=1: pairs evaluated / pairs needed: the exact answer needs n * k distances
         std::vector<int> sc(n);
+        int cnt[4] = {0, 0, 0, 0};
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(sc.data(), h->d_dbg, 4 * (size_t)n, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(cnt, h->d_counter, 16, hipMemcpyDeviceToHost);
         long long tot = 0;
         for (int v : sc) tot += v;
         std::sort(sc.begin(), sc.end());
-        fprintf(stderr, "[cluster dbg] core distances: n %d, k %d, pair distances evaluated %lld = %.1f x the %lld needed (n*k); per point median %d, p99 %d, max %d\n",
-                n, k, tot, (double)tot / ((double)n * k), (long long)n * k, sc[n / 2], sc[(size_t)n * 99 / 100], sc[n - 1]);
+#ifdef VG_DEV
+        if (!walk) {
+            std::vector<int> raw(1024);
+            (void)hipMemcpy(raw.data(), h->d_dbg + n, 4096, hipMemcpyDeviceToHost);
+            float Tf, Bf; memcpy(&Tf, &raw[4], 4); memcpy(&Bf, &raw[5], 4);
+            fprintf(stderr, "[cluster dev] far query 0: sorted index %d, final level %d, T %.6g, bound %.6g, list:", raw[2], raw[3], Tf, Bf);
+            for (int j = 0; j < 16; ++j) { float f; memcpy(&f, &raw[16 + j], 4); fprintf(stderr, " %.4g", f); }
+            fprintf(stderr, "\n[cluster dev] streamed ranges (%d):", raw[1] / 2);
+            for (int j = 0; j < std::min(raw[1], 200); j += 2) fprintf(stderr, " [%d,%d)", raw[100 + j], raw[100 + j + 1]);
+            fprintf(stderr, "\n");
+        }
+#endif
+        fprintf(stderr, "[cluster dbg] core distances: n %d, k %d, pair distances evaluated %lld = %.1f x the %lld needed (n*k); per point median %d, p99 %d, max %d"
+                        "; cooperative: %d (node, 64-query) work items, %d queries left to the far phase\n",
+                n, k, tot, (double)tot / ((double)n * k), (long long)n * k, sc[n / 2], sc[(size_t)n * 99 / 100], sc[n - 1], walk ? 0 : cnt[2], walk ? 0 : cnt[3]);
     }
 }
 template <int DIM>

@@ -23,6 +23,8 @@ the ranks (contiguous blocks): every rank replays the cheap, stateful ground sta
 parity with the sequential reference), the other stages run on the rank's own block, and
 `evaluate_sequence` all-gathers scores and per-frame results so that every rank holds the sequence result.
 """
+import contextlib
+import os
 import pickle
 import time
 from pathlib import Path
@@ -63,6 +65,8 @@ class ZeroShotDetector:
         self.n_workers = int(dev.get('frames_in_flight', 6))
         self.sync_every_stage = bool(dev.get('sync_every_stage', False))
         self.stage_ms = {}                               # stage name -> ms per (own) frame of the last process()
+        self.detail_ms = {}                              # VILGOD_STAGE_DETAIL=1: wall ms of the parts of the host-heavy stages (whole sequence)
+        self._detail_on = os.environ.get('VILGOD_STAGE_DETAIL', '0') == '1'
         self._dirty = False
         self._snapshot, self._frozen = None, False       # serialised frames as of the last stage that synchronises (propagate_labels)
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
@@ -76,6 +80,17 @@ class ZeroShotDetector:
             pass
         self.logger.info(f'Loaded {len(self.lidar_frame_list)} lidar frames')
         self.detection_3d_result_list = []
+
+    @contextlib.contextmanager
+    def _part(self, name):
+        if not self._detail_on:
+            yield
+            return
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            self.detail_ms[name] = self.detail_ms.get(name, 0.0) + 1000.0 * (time.perf_counter() - t0)
 
     # ------------------------------------------------------------------------------------------------
     def init_lidar_frames(self):
@@ -177,9 +192,10 @@ class ZeroShotDetector:
                 if self.rank != 0:
                     self._dirty = False
                     return
-            with open(path, 'wb') as fp:
-                pickle.dump(snapshot if snapshot is not None else [f.serialize for f in self.lidar_frame_list], fp,
-                            protocol=pickle.HIGHEST_PROTOCOL)
+            with self._part('state.serialize'):
+                data = snapshot if snapshot is not None else [f.serialize for f in self.lidar_frame_list]
+            with self._part('state.pickle'), open(path, 'wb') as fp:
+                pickle.dump(data, fp, protocol=pickle.HIGHEST_PROTOCOL)
             self._dirty = False
         elif mode == 'load':
             if path.exists():
@@ -576,24 +592,26 @@ class ZeroShotDetector:
         # Detection.cluster_mass_center (objects.py:121-123) of every detection the tracker sees: one kernel launch per frame
         # (vg_cluster_medians, exact np.median semantics), queued for all frames before the first result is read back
         med, cnt, pending = {}, {}, []
-        for fs in self.lidar_frame_list:
-            rows = np.flatnonzero(fs.valid) if valid_only else np.arange(fs.n_detections)
-            if len(rows):
-                X = self._ref_and_nonground(fs.fnr)[1]
-                d_index, d_seg = self._cluster_lists(fs.fnr, rows)
-                pending.append((fs, rows, self.pipe.cluster_medians(X, d_index, d_seg)))
-            else:
-                pending.append((fs, rows, None))
+        with self._part('track.medians_queue'):
+            for fs in self.lidar_frame_list:
+                rows = np.flatnonzero(fs.valid) if valid_only else np.arange(fs.n_detections)
+                if len(rows):
+                    X = self._ref_and_nonground(fs.fnr)[1]
+                    d_index, d_seg = self._cluster_lists(fs.fnr, rows)
+                    pending.append((fs, rows, self.pipe.cluster_medians(X, d_index, d_seg)))
+                else:
+                    pending.append((fs, rows, None))
         self._med = med
-        for fs, rows, d_med in pending:
-            keys = [(fs.fnr, int(r)) for r in rows]
-            if keys:
-                m = d_med.cpu().numpy()
-                for j, k in enumerate(keys):
-                    med[k], cnt[k] = m[j], int(fs.seg_off[k[1] + 1] - fs.seg_off[k[1]])
-            centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
-            self.tracker.next(fs.fnr, keys, centers, [cnt[k] for k in keys], lambda k: (med[k], cnt[k]))
-        self.tracker.finish()
+        with self._part('track.tracker'):
+            for fs, rows, d_med in pending:
+                keys = [(fs.fnr, int(r)) for r in rows]
+                if keys:
+                    m = d_med.cpu().numpy()
+                    for j, k in enumerate(keys):
+                        med[k], cnt[k] = m[j], int(fs.seg_off[k[1] + 1] - fs.seg_off[k[1]])
+                centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
+                self.tracker.next(fs.fnr, keys, centers, [cnt[k] for k in keys], lambda k: (med[k], cnt[k]))
+            self.tracker.finish()
         self.logger.info(f'  tracks: {len(self.tracker.tracks)} ({sum(len(t) >= self.tracker.min_length for t in self.tracker.tracks)} of length >= {self.tracker.min_length})')
 
     def _cluster_points_host(self, key):
@@ -610,23 +628,28 @@ class ZeroShotDetector:
                 tracked.setdefault(fnr, set()).add(row)
         gpu_box = {}
         jobs = []
-        for fnr, rows in tracked.items():                # every frame's request goes out before the first answer is awaited
-            rows = sorted(rows)
-            _, X = self._ref_and_nonground(fnr)
-            jobs.append((fnr, rows, self._boxes_of_rows(fnr, rows, X)))
-        for fnr, rows, fut in jobs:
-            for r, b in zip(rows, fut.result()):
-                gpu_box[(fnr, r)] = b
-        tab = DetectionTable()
-        for fs in self.lidar_frame_list:
-            for r in range(fs.n_detections):
-                tab.valid[(fs.fnr, r)] = bool(fs.valid[r])
+        with self._part('boxes.request_static'):
+            for fnr, rows in tracked.items():                # every frame's request goes out before the first answer is awaited
+                rows = sorted(rows)
+                _, X = self._ref_and_nonground(fnr)
+                jobs.append((fnr, rows, self._boxes_of_rows(fnr, rows, X)))
+        with self._part('boxes.await_static'):
+            for fnr, rows, fut in jobs:
+                for r, b in zip(rows, fut.result()):
+                    gpu_box[(fnr, r)] = b
+        with self._part('boxes.table'):
+            tab = DetectionTable()
+            for fs in self.lidar_frame_list:
+                for r in range(fs.n_detections):
+                    tab.valid[(fs.fnr, r)] = bool(fs.valid[r])
         med = getattr(self, '_med', None) or {}
-        fit_track_boxes(self.tracker, tab, self._cluster_points_host, lambda k: bool(self.lidar_frame_list[k[0]].static[k[1]]),
-                        lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__,
-                        median_of=(med.__getitem__ if med else None))
+        with self._part('boxes.fit_track_boxes'):
+            fit_track_boxes(self.tracker, tab, self._cluster_points_host, lambda k: bool(self.lidar_frame_list[k[0]].static[k[1]]),
+                            lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__,
+                            median_of=(med.__getitem__ if med else None))
         self._tab = tab
-        self._write_back_tracked()
+        with self._part('boxes.write_back'):
+            self._write_back_tracked()
 
     def _write_back_tracked(self, key=None):
         tab = self._tab
@@ -673,7 +696,10 @@ class ZeroShotDetector:
         if (self._dirty or self.world_size > 1) and not self._frozen:
             self._frozen = True                          # every rank holds every frame's state here (_exchange_states above)
             if self.rank == 0:
-                self._snapshot = [f.serialize for f in self.lidar_frame_list]
-        propagate_labels(self.tracker, tab, lambda k: len(self.lidar_frame_list[k[0]].cluster_index(k[1])), self.dataset.class_names,
-                         min_length=kwargs.get('min_length', 5))
-        self._write_back_tracked(key)
+                with self._part('propagate.snapshot'):
+                    self._snapshot = [f.serialize for f in self.lidar_frame_list]
+        with self._part('propagate.logic'):
+            propagate_labels(self.tracker, tab, lambda k: len(self.lidar_frame_list[k[0]].cluster_index(k[1])), self.dataset.class_names,
+                             min_length=kwargs.get('min_length', 5))
+        with self._part('propagate.write_back'):
+            self._write_back_tracked(key)
