@@ -78,6 +78,8 @@ struct vg_cluster {
     size_t temp_bytes;
     int* h_counter;                       // pinned
     int* d_dbg;                           // VG_CLUSTER_DEBUG=1: points scanned per thread in the last search round
+    unsigned int* d_entries;
+    int *d_far, *d_far_flag;  // cooperative kernels: (node, 64-query) work list of the frame; queries handed on to the next phase
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -406,52 +408,106 @@ __constant__ signed char CLB_ORDER[27][3] = {
     {-1, -1, -1}, {1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {-1, 1, 1}, {1, 1, 1}};
 #define CLB_TILE 128                  // candidates staged per pass (two coalesced loads per lane)
 
-// work list of phase A: one entry (first query index) per 64 consecutive points of a level-1 node
+// (h, v) <- (min(h, v), max(h, v)) for non-NaN doubles
+__device__ __forceinline__ void cl_minmax(double& h, double& v) {
+    double lo, hi;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(h), "v"(v));
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(h), "v"(v));
+    h = lo;
+    v = hi;
+}
+
+// Work list of the cooperative kernels.  A work item = up to 64 consecutive sorted points = the points of ONE octree node,
+// chosen top-down from level 3 (3.2 m): a node that holds at most 64 points is one item (lane utilisation: a LiDAR frame's
+// 0.8 m nodes hold 9 points on average), a fuller node is split into its children, level-0 cells (0.4 m) are cut into chunks of
+// 64.  The item's candidates are the 27 nodes around it AT ITS LEVEL, so sparse regions get a wide shell (more queries end in
+// the cooperative phase) and dense surfaces near the sensor a narrow one (a 0.8 m node there holds up to ~600 points with
+// ~4 000 in its shell; the heaviest item sets the launch time).  entry = first query index | level << 30.
+#define CLB_TOP 1                     // coarsest work-item level (levels 2 / 3 were measured: their shells next to dense objects hold
+                                      // 10-20 k candidates and the heaviest item sets the launch time: 832 us instead of 267)
+#define CLB_SPLIT 96                  // a level-1 node with more points than this is handled cell by cell
+#define CLB_SHELL_CAP 4096            // ... and so is one whose level + 2 ancestor (a 4 x 4 x 4 block that holds most of its shell) is crowded
 __global__ void k_cl_blocks(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ cs,
-                            int* __restrict__ entries, int* __restrict__ counters) {
+                            unsigned int* __restrict__ entries, int* __restrict__ counters) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned int key = code_s[i] >> 3;
-    if (i > 0 && (code_s[i - 1] >> 3) == key) return;
-    const int end = cl_start(cs, (key + 1u) << 3);
-    const int chunks = (end - i + 63) >> 6;
-    const int base = atomicAdd(&counters[2], chunks);
-    for (int c = 0; c < chunks; ++c) entries[base + c] = i + (c << 6);
+    const unsigned int code = code_s[i], prev = i > 0 ? code_s[i - 1] : ~code;
+    if (prev == code) return;                             // not the first point of any node
+    // the node that holds point i at every level up to CLB_TOP + 2: its range (independent reads of the cell table)
+    int j0[CLB_TOP + 3], j1[CLB_TOP + 3];
+#pragma unroll
+    for (int lv = 0; lv <= CLB_TOP + 2; ++lv) {
+        const unsigned int kk = code >> (3 * lv);
+        j0[lv] = cl_start(cs, kk << (3 * lv));
+        j1[lv] = cl_start(cs, (kk + 1u) << (3 * lv));
+    }
+    // a node "fits" when it fills at most one wave and its surroundings are not crowded (the item's cost is its shell's
+    // population); the work item of point i's branch is the coarsest node that fits (cells always do, in chunks of 64)
+    bool fits[CLB_TOP + 2];
+    fits[0] = true;
+#pragma unroll
+    for (int lv = 1; lv <= CLB_TOP; ++lv) fits[lv] = (j1[lv] - j0[lv]) <= CLB_SPLIT && (j1[lv + 2] - j0[lv + 2]) <= CLB_SHELL_CAP;
+    fits[CLB_TOP + 1] = false;
+#pragma unroll
+    for (int lv = 0; lv <= CLB_TOP; ++lv) {
+        if (j0[lv] != i) break;                           // i does not start this node, nor any coarser one
+        if (!fits[lv] || fits[lv + 1]) continue;
+        const int cnt = j1[lv] - j0[lv];
+        const int chunks = (cnt + 63) >> 6;
+        const int base = atomicAdd(&counters[2], chunks);
+        for (int c = 0; c < chunks; ++c) entries[base + c] = (unsigned int)(i + (c << 6)) | ((unsigned int)lv << 30);
+    }
+}
+
+// Staging plan of one pass of a cooperative kernel: the candidates of up to 27 neighbour nodes, CONCATENATED, so that one
+// pass (one round trip to memory for the whole wave) covers a whole neighbourhood when it holds <= CLB_TILE points -- most of
+// them do.  seg[t] = {first sorted index, points taken, offset in the tile}; filled by wave-uniform code.
+struct ClbPlan {
+    int start[27], take[27], off[28];
+};
+// sorted index of the tile's f-th candidate
+__device__ __forceinline__ int clb_locate(const ClbPlan& p, int nseg, int f) {
+    int t = 0;
+    for (int u = 1; u < nseg; ++u) t += (f >= p.off[u]) ? 1 : 0;
+    return p.start[t] + (f - p.off[t]);
 }
 
 template <int DIM>
 __global__ __launch_bounds__(64) void k_cl_core_blk(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                     const ClGrid* __restrict__ gp, const int* __restrict__ cs,
-                                                    const unsigned int* __restrict__ code_s, const int* __restrict__ entries,
+                                                    const unsigned int* __restrict__ code_s, const unsigned int* __restrict__ entries,
                                                     int* __restrict__ counters, int k, double* __restrict__ core2,
                                                     int* __restrict__ far_list, int* __restrict__ dbg_scan) {
     __shared__ int bnd[27][2];
-    __shared__ double tile[DIM][CLB_TILE];
+    __shared__ ClbPlan plan;
+    __shared__ float4 tile[CLB_TILE];                 // x, y, z, 4th coordinate
+    __shared__ float tile_t[DIM >= 5 ? CLB_TILE : 1]; // 5th coordinate
     const int lane = threadIdx.x;
     const ClGrid g = *gp;
     const int n_entries = counters[2];
     for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
-        const int i0 = entries[e];
-        const unsigned int key = code_s[i0] >> 3;
-        const int iend = min(cl_start(cs, (key + 1u) << 3), i0 + 64);
+        const int lv = (int)(entries[e] >> 30), i0 = (int)(entries[e] & 0x3FFFFFFFu);   // node level (0 .. 3), first query
+        const unsigned int key = code_s[i0] >> (3 * lv);
+        const int iend = min(cl_start(cs, (key + 1u) << (3 * lv)), i0 + 64);
         const int i = i0 + lane;
         const bool active = i < iend;
         const float4 qf = spts[active ? i : i0];
-        const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[active ? i : i0] : 0.0;
-        int bx, by, bz;                                   // the node's coordinates at level 1 (wave-uniform: from its first point)
+        const float qtf = DIM >= 5 ? stt[active ? i : i0] : 0.f;
+        const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = qtf;
+        int bx, by, bz;                                   // the node's coordinates at its level (wave-uniform: from its first point)
         {
             const float4 f0 = spts[i0];
             cl_cell_of(g, (double)f0.x, (double)f0.y, (double)f0.z, bx, by, bz);
-            bx >>= 1; by >>= 1; bz >>= 1;
+            bx >>= lv; by >>= lv; bz >>= lv;
         }
-        __syncthreads();                                  // the previous entry's reads of bnd / tile are over
+        __syncthreads();                                  // the previous entry's reads of bnd / plan / tile are over
         if (lane < 27) {
             const int nx = bx + CLB_ORDER[lane][0], ny = by + CLB_ORDER[lane][1], nz = bz + CLB_ORDER[lane][2];
             int j0 = 0, j1 = 0;
-            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (CL_NX >> 1) && ny < (CL_NY >> 1) && nz < (CL_NZ >> 1)) {
-                const unsigned int c0 = cl_code(nx << 1, ny << 1, nz << 1);
+            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (CL_NX >> lv) && ny < (CL_NY >> lv) && nz < (CL_NZ >> lv)) {
+                const unsigned int c0 = cl_code(nx << lv, ny << lv, nz << lv);
                 j0 = cl_start(cs, c0);
-                j1 = cl_start(cs, c0 + 8u);
+                j1 = cl_start(cs, c0 + (1u << (3 * lv)));
             }
             bnd[lane][0] = j0;
             bnd[lane][1] = j1;
@@ -460,46 +516,84 @@ __global__ __launch_bounds__(64) void k_cl_core_blk(const float4* __restrict__ s
         double h[CL_K];
 #pragma unroll
         for (int j = 0; j < CL_K; ++j) h[j] = INFINITY;
+        float thr = INFINITY;                             // float32 screen: a candidate whose float32 distance exceeds it cannot enter the list
         int scanned = 0;
-        for (int t = 0; t < 27; ++t) {
-            const int j0 = bnd[t][0], j1 = bnd[t][1];
-            if (j0 == j1) continue;
-            // the node's box against every lane's k-th distance so far (same rule as the walk: >= cannot lower it)
-            const double nb2 = cl_box_d2(g, qx, qy, qz, 1, bx + CLB_ORDER[t][0], by + CLB_ORDER[t][1], bz + CLB_ORDER[t][2]);
-            if (!__any(active && nb2 < h[k])) continue;
-            for (int base = j0; base < j1; base += CLB_TILE) {
-                const int cnt = min(CLB_TILE, j1 - base);
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < CLB_TILE / 64; ++r) {
-                    const int c = lane + 64 * r;
-                    if (c < cnt) {
-                        const float4 p = spts[base + c];
-                        tile[0][c] = (double)p.x; tile[1][c] = (double)p.y; tile[2][c] = (double)p.z;
-                        if (DIM >= 4) tile[3 < DIM ? 3 : 0][c] = (double)p.w;
-                        if (DIM >= 5) tile[4 < DIM ? 4 : 0][c] = (double)stt[base + c];
-                    }
+        int t_next = 0, cur = bnd[0][0];                  // next neighbour node to plan, next point of it
+        while (t_next < 27) {
+            // ---- plan one pass (wave-uniform) ----
+            int nseg = 0, tot = 0;
+            while (t_next < 27 && tot < CLB_TILE) {
+                const int j1 = bnd[t_next][1];
+                bool need = cur < j1;
+                if (need) {
+                    // the node's box against every lane's k-th distance so far (same rule as the walk: >= cannot lower it)
+                    const double nb2 = cl_box_d2(g, qx, qy, qz, lv, bx + CLB_ORDER[t_next][0], by + CLB_ORDER[t_next][1], bz + CLB_ORDER[t_next][2]);
+                    need = __any(active && nb2 < h[k]);
                 }
-                __syncthreads();
-                scanned += cnt;
-                for (int c = 0; c < cnt; ++c) {
-                    const double dx = qx - tile[0][c], dy = qy - tile[1][c], dz = qz - tile[2][c];
-                    double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (DIM >= 4) { const double de = qe - tile[3 < DIM ? 3 : 0][c]; d2 = d2 + de * de; }
-                    if (DIM >= 5) { const double dt = qt - tile[4 < DIM ? 4 : 0][c]; d2 = d2 + dt * dt; }
-                    if (__any(d2 < h[CL_K - 1])) {
+                if (need) {
+                    const int take = min(j1 - cur, CLB_TILE - tot);
+                    if (lane == 0) { plan.start[nseg] = cur; plan.take[nseg] = take; plan.off[nseg] = tot; }
+                    ++nseg; tot += take; cur += take;
+                    if (cur < j1) break;                  // tile full: the rest of this node in the next pass
+                }
+                ++t_next;
+                if (t_next < 27) cur = bnd[t_next][0];
+            }
+            if (tot == 0) break;
+            __syncthreads();
+            // ---- stage: coalesced within each node's range ----
 #pragma unroll
-                        for (int u = 0; u < CL_K; ++u) {
-                            const double lo = fmin(h[u], d2);
-                            d2 = fmax(h[u], d2);
-                            h[u] = lo;
-                        }
+            for (int r = 0; r < CLB_TILE / 64; ++r) {
+                const int f = lane + 64 * r;
+                if (f < tot) {
+                    const int j = clb_locate(plan, nseg, f);
+                    tile[f] = spts[j];
+                    if (DIM >= 5) tile_t[f] = stt[j];
+                }
+            }
+            __syncthreads();
+            scanned += tot;
+            // ---- scan, four candidates per trip.  Screen in float32 first: the float64 distance of the (exactly converted)
+            // float32 coordinates differs from this float32 evaluation by a few ulp, the threshold carries a 1e-5 margin, so
+            // a candidate the screen drops is farther than the lane's 16th distance and the exact chain never misses one ----
+            for (int c0 = 0; c0 < tot; c0 += 4) {
+                float4 p[4];
+                float sd[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    p[v] = tile[min(c0 + v, tot - 1)];
+                    const float dx = qf.x - p[v].x, dy = qf.y - p[v].y, dz = qf.z - p[v].z;
+                    float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    if (DIM >= 4) { const float de = qf.w - p[v].w; d = fmaf(de, de, d); }
+                    if (DIM >= 5) { const float dt = qtf - tile_t[min(c0 + v, tot - 1)]; d = fmaf(dt, dt, d); }
+                    sd[v] = c0 + v < tot ? d : INFINITY;
+                }
+                if (!__any(fminf(fminf(sd[0], sd[1]), fminf(sd[2], sd[3])) <= thr)) continue;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (!__any(sd[v] <= thr)) continue;
+                    const double dx = qx - (double)p[v].x, dy = qy - (double)p[v].y, dz = qz - (double)p[v].z;
+                    double x = (dx * dx + dy * dy) + dz * dz;
+                    if (DIM >= 4) { const double de = qe - (double)p[v].w; x = x + de * de; }
+                    if (DIM >= 5) { const double dt = qt - (double)tile_t[min(c0 + v, tot - 1)]; x = x + dt * dt; }
+                    if (c0 + v >= tot) x = INFINITY;
+                    if (!__any(x < h[CL_K - 1])) continue;
+                    // sorted insert as a min / max chain.  Raw v_min_f64 / v_max_f64: the operands are squared distances or
+                    // +inf, never NaN, so the canonicalising v_max_f64 x, x that fmin / fmax put in front of every operand in
+                    // IEEE mode (half of the chain's instructions) is not needed.  The lower half of the list is entered only
+                    // when some lane's value belongs there.
+                    if (__any(x < h[CL_K / 2 - 1])) {
+#pragma unroll
+                        for (int u = 0; u < CL_K / 2; ++u) cl_minmax(h[u], x);
                     }
+#pragma unroll
+                    for (int u = CL_K / 2; u < CL_K; ++u) cl_minmax(h[u], x);
+                    thr = (float)h[CL_K - 1] * 1.00001f + 1e-30f;       // (float)(+inf) stays +inf
                 }
             }
         }
         // nothing outside the 3 x 3 x 3 shell is nearer than its outer faces
-        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, 1);
+        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, lv);
         const bool done = h[k] <= r2;
         if (active) {
             core2[i] = h[k];                              // final, or an upper bound for phase B
@@ -568,7 +662,9 @@ __global__ __launch_bounds__(64) void k_cl_core_far(const float4* __restrict__ s
                         pm &= pm - 1;
                         const double v = cl_readlane_d(d2, b);
                         if (v < T) {
-                            hs = fmin(fmax(v, cl_row_shr1(hs)), hs);
+                            double mx, prev = cl_row_shr1(hs);
+                            asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(prev), "v"(v));
+                            asm("v_min_f64 %0, %1, %2" : "=v"(hs) : "v"(mx), "v"(hs));
                             T = cl_readlane_d(hs, k);
                         }
                     }
@@ -647,6 +743,7 @@ __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned 
                                   int* __restrict__ sel_a, const int* __restrict__ flags) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) const_cast<int*>(flags)[4] = 0;   // queries the cooperative search hands on to the walk this round
     if (i >= n) return;
     best_w[i] = CL_NONE;
     best_d[i] = ~0ull;
@@ -711,18 +808,31 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      unsigned long long* __restrict__ pt_w,
                                                      unsigned long long* __restrict__ pt_d,
                                                      unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b,
-                                                     double* __restrict__ pt_lb, int* __restrict__ dbg_scan, const int* __restrict__ flags) {
+                                                     double* __restrict__ pt_lb, int* __restrict__ dbg_scan, const int* __restrict__ flags,
+                                                     const int* __restrict__ far_list, const int* __restrict__ far_flag) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     __shared__ unsigned int stack[CL_STACK * 256];
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    // far_list != NULL: only the queries the cooperative search (k_cl_b_search_blk) could not finish inside its shell, each
+    // starting from the best edge it found there (pt_w / pt_d / pt_key / pt_b hold it; pt_b = -1: none)
+    // (far_flag instead of far_list: the same queries, but each in the lane its point index maps to -- 64 hard walks packed into
+    // one wave diverge and run one after the other, spread over all waves they run side by side)
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (far_list) {
+        if (a >= flags[4]) return;
+        a = far_list[a];
+    }
     if (a >= n) return;
+    if (far_flag) {
+        if (!far_flag[a]) return;
+        far_list = far_flag;                             // from here on: "start from the edge the point holds"
+    }
     int scanned = 0;
-    if (dbg_scan) dbg_scan[a] = 0;
+    if (dbg_scan && !far_list) dbg_scan[a] = 0;
     unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[a];
     const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[a] : 0.0;
-    if (pt_b[a] >= 0) return;                        // candidate of an earlier round still valid (k_cl_b_seed)
+    if (!far_list && pt_b[a] >= 0) return;           // candidate of an earlier round still valid (k_cl_b_seed)
     const int ca = comp[a];
     const double core_a = core2[a];
     // Every edge that leaves a's component from a weighs at least lb_a: its mutual-reachability weight is >= core_a, and
@@ -749,7 +859,13 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     double cbest = INFINITY;       // best weight published for the whole component (refreshed now and then)
     unsigned long long bkey = ~0ull;
     int bb = -1;
-    int since_refresh = 0;
+    if (far_list && pt_b[a] >= 0) {
+        bw = __longlong_as_double((long long)pt_w[a]);
+        bd2 = __longlong_as_double((long long)pt_d[a]);
+        bkey = pt_key[a];
+        bb = pt_b[a];
+    }
+    int since_refresh = 64;        // the component's published bound is read before the first node
     const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
     const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
     for (int rr = 0; rr < nrx * nry; ++rr) {
@@ -831,7 +947,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             }
         }
     }
-    if (dbg_scan) dbg_scan[a] = scanned;
+    if (dbg_scan) dbg_scan[a] = (far_list ? dbg_scan[a] : 0) + scanned;
     if (bb >= 0 && bw <= cbest) {
         pt_w[a] = (unsigned long long)__double_as_longlong(bw);
         pt_d[a] = (unsigned long long)__double_as_longlong(bd2);
@@ -844,6 +960,162 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
         pt_d[a] = ~0ull;
         pt_key[a] = ~0ull;
         pt_b[a] = -1;
+    }
+}
+
+// Cooperative nearest-foreign search of a Boruvka round (same layout as k_cl_core_blk: one wave per (0.8 m node, 64 queries),
+// lane = query, the 27 neighbour nodes staged in LDS by coalesced loads: coordinates as float64, component id, squared core
+// distance, original id).  A lane keeps the best edge (w, d2, key) it has met under the walk's strict order.  Everything outside
+// the shell is at least r away (r = distance to the shell's outer faces), so its edges weigh >= r^2: a lane whose best edge --
+// or whose component's published bound -- is lighter than that is finished; the others start the tree walk from what they found.
+// A neighbour node is skipped when it is pure and owned by the component of every searching lane, or when it is farther than
+// every searching lane's bounds.
+template <int DIM>
+__global__ __launch_bounds__(64) void k_cl_b_search_blk(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
+                                                        const ClGrid* __restrict__ gp, const int* __restrict__ cs,
+                                                        const unsigned int* __restrict__ code_s, const unsigned int* __restrict__ entries,
+                                                        const int* __restrict__ cell_comp, const int* __restrict__ perm,
+                                                        const double* __restrict__ core2, const int* __restrict__ comp,
+                                                        unsigned long long* __restrict__ best_w, unsigned long long* __restrict__ pt_w,
+                                                        unsigned long long* __restrict__ pt_d, unsigned long long* __restrict__ pt_key,
+                                                        int* __restrict__ pt_b, double* __restrict__ pt_lb, int* __restrict__ dbg_scan,
+                                                        int* __restrict__ flags, int* __restrict__ far_list, int* __restrict__ far_flag) {
+    if (flags[1]) return;
+    __shared__ int bnd[27][3];                        // range + purity of the 27 neighbour nodes
+    __shared__ ClbPlan plan;
+    __shared__ double tile[DIM + 1][CLB_TILE];        // coordinates, squared core distance
+    __shared__ int tile_i[2][CLB_TILE];               // component, original id
+    const int lane = threadIdx.x;
+    const ClGrid g = *gp;
+    const int n_entries = flags[2];
+    for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
+        const int lv = (int)(entries[e] >> 30), i0 = (int)(entries[e] & 0x3FFFFFFFu);   // node level (0 .. 3), first query
+        const unsigned int key1 = code_s[i0] >> (3 * lv);
+        const int iend = min(cl_start(cs, (key1 + 1u) << (3 * lv)), i0 + 64);
+        const int a = i0 + lane;
+        const bool active = a < iend;
+        const int aa = active ? a : i0;
+        bool searching = active && pt_b[aa] < 0;      // a candidate of an earlier round that is still foreign is kept (k_cl_b_seed)
+        if (far_flag && active) far_flag[a] = 0;
+        if (!__any(searching)) continue;
+        const float4 qf = spts[aa];
+        const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[aa] : 0.0;
+        const int ca = comp[aa];
+        const double core_a = core2[aa];
+        const double lb_a = fmax(core_a, pt_lb[aa]);
+        double cbest = g.inf;
+        {
+            const unsigned long long cb0 = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cb0 != CL_NONE) cbest = __longlong_as_double((long long)cb0);
+        }
+        if (searching && lb_a > cbest) {              // cannot supply its component's edge (same exit as the walk)
+            pt_w[a] = CL_NONE; pt_d[a] = ~0ull; pt_key[a] = ~0ull; pt_b[a] = -1;
+            searching = false;
+        }
+        if (!__any(searching)) continue;
+        const int oa = perm[aa];
+        int bx, by, bz;
+        {
+            const float4 f0 = spts[i0];
+            cl_cell_of(g, (double)f0.x, (double)f0.y, (double)f0.z, bx, by, bz);
+            bx >>= lv; by >>= lv; bz >>= lv;
+        }
+        __syncthreads();
+        if (lane < 27) {
+            const int nx = bx + CLB_ORDER[lane][0], ny = by + CLB_ORDER[lane][1], nz = bz + CLB_ORDER[lane][2];
+            int j0 = 0, j1 = 0, pure = -1;
+            if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (CL_NX >> lv) && ny < (CL_NY >> lv) && nz < (CL_NZ >> lv)) {
+                const unsigned int c0 = cl_code(nx << lv, ny << lv, nz << lv);
+                j0 = cl_start(cs, c0);
+                j1 = cl_start(cs, c0 + (1u << (3 * lv)));
+                if (j0 != j1) pure = cell_comp[cl_pur_off(lv) + (c0 >> (3 * lv))];
+            }
+            bnd[lane][0] = j0; bnd[lane][1] = j1; bnd[lane][2] = pure;
+        }
+        __syncthreads();
+        double bw = g.inf, bd2 = g.inf;
+        unsigned long long bkey = ~0ull;
+        int bb = -1, scanned = 0;
+        int t_next = 0, cur = bnd[0][0];
+        while (t_next < 27) {
+            int nseg = 0, tot = 0;
+            while (t_next < 27 && tot < CLB_TILE) {
+                const int j1 = bnd[t_next][1], pure = bnd[t_next][2];
+                bool need = cur < j1;
+                if (need) {
+                    const double nd2 = cl_box_d2(g, qx, qy, qz, lv, bx + CLB_ORDER[t_next][0], by + CLB_ORDER[t_next][1], bz + CLB_ORDER[t_next][2]);
+                    const double lb = fmax(lb_a, nd2);
+                    need = __any(searching && pure != ca && !(lb > bw || lb > cbest || (lb == bw && nd2 > bd2)));
+                }
+                if (need) {
+                    const int take = min(j1 - cur, CLB_TILE - tot);
+                    if (lane == 0) { plan.start[nseg] = cur; plan.take[nseg] = take; plan.off[nseg] = tot; }
+                    ++nseg; tot += take; cur += take;
+                    if (cur < j1) break;
+                }
+                ++t_next;
+                if (t_next < 27) cur = bnd[t_next][0];
+            }
+            if (tot == 0) break;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CLB_TILE / 64; ++r) {
+                const int f = lane + 64 * r;
+                if (f < tot) {
+                    const int j = clb_locate(plan, nseg, f);
+                    const float4 p = spts[j];
+                    tile[0][f] = (double)p.x; tile[1][f] = (double)p.y; tile[2][f] = (double)p.z;
+                    if (DIM >= 4) tile[3 < DIM ? 3 : 0][f] = (double)p.w;
+                    if (DIM >= 5) tile[4 < DIM ? 4 : 0][f] = (double)stt[j];
+                    tile[DIM][f] = core2[j];
+                    tile_i[0][f] = comp[j];
+                    tile_i[1][f] = j;
+                }
+            }
+            __syncthreads();
+            scanned += tot;
+            for (int c = 0; c < tot; ++c) {
+                if (tile_i[0][c] == ca) continue;
+                const double dx = qx - tile[0][c], dy = qy - tile[1][c], dz = qz - tile[2][c];
+                double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (DIM >= 4) { const double de = qe - tile[3 < DIM ? 3 : 0][c]; d2 = d2 + de * de; }
+                if (DIM >= 5) { const double dt = qt - tile[4 < DIM ? 4 : 0][c]; d2 = d2 + dt * dt; }
+                if (d2 > bw) continue;
+                const double w = fmax(fmax(d2, core_a), tile[DIM][c]);
+                if (w > bw || (w == bw && d2 > bd2)) continue;
+                const int j = tile_i[1][c];
+                const unsigned long long key = cl_edge_key(oa, perm[j]);   // (rare: only for edges that tie or win)
+                if (w < bw || d2 < bd2 || key < bkey) { bw = w; bd2 = d2; bkey = key; bb = j; }
+            }
+        }
+        if (searching) {
+            if (bb >= 0) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
+            const unsigned long long cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cbest = cb == CL_NONE ? g.inf : __longlong_as_double((long long)cb);
+        }
+        const double r2 = cl_block_radius2(g, qx, qy, qz, bx, by, bz, lv);
+        const bool done = fmin(bw, cbest) < r2;           // strictly lighter than anything outside the shell
+        if (searching) {
+            if (dbg_scan) dbg_scan[a] = scanned;
+            if (done && !(bb >= 0 && bw <= cbest)) {
+                if (cbest < g.inf && cbest > pt_lb[a]) pt_lb[a] = cbest;
+                pt_w[a] = CL_NONE; pt_d[a] = ~0ull; pt_key[a] = ~0ull; pt_b[a] = -1;
+            } else {                                      // final (done), or the walk's starting point
+                pt_w[a] = bb >= 0 ? (unsigned long long)__double_as_longlong(bw) : CL_NONE;
+                pt_d[a] = bb >= 0 ? (unsigned long long)__double_as_longlong(bd2) : ~0ull;
+                pt_key[a] = bkey;
+                pt_b[a] = bb;
+                if (done) pt_lb[a] = bw;
+            }
+        }
+        const unsigned long long far = __ballot(searching && !done);
+        if (far) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&flags[4], __popcll(far));
+            base = __shfl(base, 0);
+            if (searching && !done) far_list[base + __popcll(far & ((1ull << lane) - 1ull))] = a;
+            if (far_flag && searching && !done) far_flag[a] = 1;
+        }
     }
 }
 
@@ -1074,6 +1346,10 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_best_d, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_b, 4 * n));
     VG_CHECK(hipMalloc(&h->d_counter, 64));
+    VG_CHECK(hipMalloc(&h->d_entries, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_far, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_far_flag, 4 * n));
+    VG_CHECK(hipMemset(h->d_far_flag, 0, 4 * n));
     VG_CHECK(hipMalloc(&h->d_mst_a, 4 * n));
     VG_CHECK(hipMalloc(&h->d_mst_b, 4 * n));
     VG_CHECK(hipMalloc(&h->d_mst_w, 8 * n));
@@ -1082,7 +1358,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_mst_idx_s, 4 * n));
     VG_CHECK(hipHostMalloc((void**)&h->h_counter, 64));
     h->d_dbg = nullptr;
-    if (getenv("VG_CLUSTER_DEBUG")) VG_CHECK(hipMalloc(&h->d_dbg, 4 * n + 4096));     // + 1024 ints of scratch for VG_DEV dumps
+    if (getenv("VG_CLUSTER_DEBUG")) VG_CHECK(hipMalloc(&h->d_dbg, 4 * n));
     size_t t1 = 0, t2 = 0, t3 = 0;
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t1, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, n, 0, 24));
     VG_CHECK(rocprim::radix_sort_pairs(nullptr, t2, h->d_mst_w, h->d_mst_w_s, h->d_mst_idx, h->d_mst_idx_s, n, 0, 64));
@@ -1098,7 +1374,7 @@ void vg_cluster_destroy(vg_cluster* h) {
     void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp, h->d_cell_e,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
                     h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_pt_lb, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
-                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp};
+                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp, h->d_entries, h->d_far, h->d_far_flag};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(h->h_counter);
     delete h;
@@ -1139,17 +1415,14 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
         hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_e, k, h->d_core2, h->d_dbg);
     } else {
-        // counters[2] = work-list entries of phase A, counters[3] = queries left for phase B; lists in buffers Boruvka fills later
+        // counters[2] = work-list entries of phase A (kept for the Boruvka rounds), counters[3] = queries left for phase B
         (void)hipMemsetAsync(h->d_counter + 2, 0, 8, st);
-#ifdef VG_DEV
-        if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg, 0, 4 * (size_t)n + 4096, st);
-#endif
-        hipLaunchKernelGGL(k_cl_blocks, dim3(vg_div_up(n, 256)), dim3(256), 0, st, n, h->d_code_s, h->d_cell_start, h->d_parent, h->d_counter);
+        hipLaunchKernelGGL(k_cl_blocks, dim3(vg_div_up(n, 256)), dim3(256), 0, st, n, h->d_code_s, h->d_cell_start, h->d_entries, h->d_counter);
         hipLaunchKernelGGL((k_cl_core_blk<DIM>), dim3(std::min(n, 16384)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
-                           h->d_code_s, h->d_parent, h->d_counter, k, h->d_core2, h->d_parent2, h->d_dbg);
+                           h->d_code_s, h->d_entries, h->d_counter, k, h->d_core2, h->d_far, h->d_dbg);
         if (!getenv("VG_CLUSTER_CORE_NOFAR"))
         hipLaunchKernelGGL((k_cl_core_far<DIM>), dim3(std::min(n, 8192)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
-                           h->d_parent2, h->d_counter, k, h->d_core2, h->d_dbg, getenv("VG_CLUSTER_FAR_LEVEL") ? atoi(getenv("VG_CLUSTER_FAR_LEVEL")) : 0);
+                           h->d_far, h->d_counter, k, h->d_core2, h->d_dbg, getenv("VG_CLUSTER_FAR_LEVEL") ? atoi(getenv("VG_CLUSTER_FAR_LEVEL")) : 0);
     }
     if (h->d_dbg) {
         // VG_CLUSTER_DEBUG=1: pairs evaluated / pairs needed: the exact answer needs n * k distances
@@ -1161,18 +1434,6 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
         long long tot = 0;
         for (int v : sc) tot += v;
         std::sort(sc.begin(), sc.end());
-#ifdef VG_DEV
-        if (!walk) {
-            std::vector<int> raw(1024);
-            (void)hipMemcpy(raw.data(), h->d_dbg + n, 4096, hipMemcpyDeviceToHost);
-            float Tf, Bf; memcpy(&Tf, &raw[4], 4); memcpy(&Bf, &raw[5], 4);
-            fprintf(stderr, "[cluster dev] far query 0: sorted index %d, final level %d, T %.6g, bound %.6g, list:", raw[2], raw[3], Tf, Bf);
-            for (int j = 0; j < 16; ++j) { float f; memcpy(&f, &raw[16 + j], 4); fprintf(stderr, " %.4g", f); }
-            fprintf(stderr, "\n[cluster dev] streamed ranges (%d):", raw[1] / 2);
-            for (int j = 0; j < std::min(raw[1], 200); j += 2) fprintf(stderr, " [%d,%d)", raw[100 + j], raw[100 + j + 1]);
-            fprintf(stderr, "\n");
-        }
-#endif
         fprintf(stderr, "[cluster dbg] core distances: n %d, k %d, pair distances evaluated %lld = %.1f x the %lld needed (n*k); per point median %d, p99 %d, max %d"
                         "; cooperative: %d (node, 64-query) work items, %d queries left to the far phase\n",
                 n, k, tot, (double)tot / ((double)n * k), (long long)n * k, sc[n / 2], sc[(size_t)n * 99 / 100], sc[n - 1], walk ? 0 : cnt[2], walk ? 0 : cnt[3]);
@@ -1180,9 +1441,25 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
 }
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
+    // VG_CLUSTER_SEARCH_MODE (A/B aid): 0 = the tree walk alone, 1 = cooperative search, leftovers walk as a compacted list,
+    // 2 = cooperative search, leftovers walk in place.  Default 0: measured on 150k-point frames the cooperative search + the
+    // leftover walks take longer than the walk alone
+    static const int mode = getenv("VG_CLUSTER_SEARCH_MODE") ? atoi(getenv("VG_CLUSTER_SEARCH_MODE")) : 0;
+    static const int core_walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;  // (no work list then)
+    if (mode == 0 || core_walk) {
+        hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
+        return;
+    }
+    hipLaunchKernelGGL((k_cl_b_search_blk<DIM>), dim3(std::min(n, 16384)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
+                       h->d_code_s, h->d_entries, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_pt_key,
+                       h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, h->d_far, mode == 2 ? h->d_far_flag : (int*)nullptr);
+    // the queries left over walk the tree from the edge they hold
     hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                        h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                       h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter);
+                       h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
+                       mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr);
 }
 
 extern "C" {
