@@ -67,12 +67,14 @@ struct vg_ground {
 // ---------------------------------------------------------------------------------------------
 __global__ void k_pw_classify(const float* __restrict__ pts, int n, int stride, double z_offset,
                               const vg_ground_params* __restrict__ P, const PwGeom* __restrict__ G,
-                              const PwState* __restrict__ S, int* __restrict__ patch_id, int* __restrict__ count) {
+                              const PwState* __restrict__ S, int* __restrict__ patch_id, int* __restrict__ count,
+                              unsigned char* __restrict__ inlier) {
     __shared__ int hist[PW_MAX_PATCHES];
     for (int b = threadIdx.x; b < PW_MAX_PATCHES; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
+        inlier[i] = 0;                    // (was a memset in front of the pass: one launch less on the frame chain)
         const float x = pts[(size_t)i * stride], y = pts[(size_t)i * stride + 1];
         // pointcloud_utils.py:50-51: float64 subtraction, then Eigen::MatrixXf (float32)
         const float z = (float)((double)pts[(size_t)i * stride + 2] - z_offset);
@@ -108,7 +110,7 @@ __global__ void k_pw_classify(const float* __restrict__ pts, int n, int stride, 
         if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 
-__global__ __launch_bounds__(64) void k_pw_offsets(const int* __restrict__ count, int* __restrict__ offset, int* __restrict__ cursor,
+__global__ __launch_bounds__(64) void k_pw_offsets(int* __restrict__ count, int* __restrict__ offset, int* __restrict__ cursor,
                                                    int n_patches) {
     // exclusive scan of the patch sizes by one wave: lane l takes a run of patches, the runs' totals are scanned across the lanes
     const int lane = threadIdx.x, per = (n_patches + 63) / 64;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(64) void k_pw_offsets(const int* __restrict__ count
         offset[p] = acc;
         cursor[p] = 0;
         acc += count[p];
+        count[p] = 0;                     // ready for the next pass (the histogram is zero at creation; was a memset per pass)
     }
     if (lane == 63) offset[n_patches] = incl;
 }
@@ -479,29 +482,22 @@ __global__ __launch_bounds__(PW_T) void k_pw_patch(const float* __restrict__ pts
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ void pw_mean_stdev(const double* v, int head, int cnt, double& mean, double& stdev) {   // :558-567
-    if (cnt <= 1) return;
-    double s = 0.0;
-    for (int i = 0; i < cnt; ++i) s += v[(head + i) & (PW_STORE_CAP - 1)];
-    mean = s / (double)cnt;
-    for (int i = 0; i < cnt; ++i) {
-        double x = v[(head + i) & (PW_STORE_CAP - 1)];
-        stdev += (x - mean) * (x - mean);
-    }
-    stdev /= (double)(cnt - 1);
-    stdev = sqrt(stdev);
-}
-
-// lane r < n_rings: sequential GLE + TGR for ring r (concentric index r).  Then lanes 0..7 update thresholds.
-__global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__ P, const PwGeom* __restrict__ G,
+// lane r < n_rings: sequential GLE + TGR for ring r (concentric index r).  Then lanes 0..3 / 8..11 update thresholds.  (256 threads:
+// the other three waves only help with the copies into LDS.)
+__global__ __launch_bounds__(256) void k_pw_decide(vg_ground_params* __restrict__ P, const PwGeom* __restrict__ G,
                                                   PwState* __restrict__ S, PwPatchRec* __restrict__ recs) {
     const int lane = threadIdx.x;
     __shared__ double sh_rf[4][64];          // per near ring: the flatness values it appends to `ringwise_flatness`
     __shared__ int sh_nrf[4], sh_ncand[4];
+    // one 48 KB buffer, two uses: the patch records while the rings are decided (each ring's lane walks its <= 54 sectors one
+    // after the other: from LDS, not through ~100 dependent reads of global memory), then the threshold stores (below)
+    __shared__ double raw[PW_MAX_PATCHES * sizeof(PwPatchRec) / 8];
+    PwPatchRec* const lrec = reinterpret_cast<PwPatchRec*>(raw);
     if (lane < 4) { sh_nrf[lane] = 0; sh_ncand[lane] = 0; }
+    int n_rings = 0, n_patches = 0;
+    for (int k = 0; k < P->num_zones; ++k) { n_rings += P->num_rings_each_zone[k]; n_patches += P->num_rings_each_zone[k] * P->num_sectors_each_zone[k]; }
+    for (int w = lane; w < n_patches * (int)(sizeof(PwPatchRec) / 4); w += blockDim.x) reinterpret_cast<int*>(raw)[w] = reinterpret_cast<const int*>(recs)[w];
     __syncthreads();
-    int n_rings = 0;
-    for (int k = 0; k < P->num_zones; ++k) n_rings += P->num_rings_each_zone[k];
     if (lane < n_rings) {
         int zone = 0, ring = lane;
         while (ring >= P->num_rings_each_zone[zone]) { ring -= P->num_rings_each_zone[zone]; zone++; }
@@ -512,7 +508,7 @@ __global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__
         double* rf = sh_rf[cidx < 4 ? cidx : 0];    // this ring's part of `ringwise_flatness` (<= sectors per ring <= 64; only near rings add to it)
         int nrf = 0, ncand = 0;
         for (int s = 0; s < ns; ++s) {
-            PwPatchRec& r = recs[base + s];
+            PwPatchRec& r = lrec[base + s];
             if (r.decision != -1) continue;              // < num_min_pts points: all non-ground
             const double upright = r.normal[2], elevation = r.mean[2];
             const double flatness = fmin(fmin((double)r.sv[0], (double)r.sv[1]), (double)r.sv[2]);
@@ -571,7 +567,7 @@ __global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__
                 std_f = sqrt(std_f);
             }
             for (int s = 0; s < ns; ++s) {
-                PwPatchRec& r = recs[base + s];
+                PwPatchRec& r = lrec[base + s];
                 if (r.decision != 2) continue;
                 bool revert = false;
                 if (P->enable_TGR) {
@@ -589,39 +585,80 @@ __global__ __launch_bounds__(64) void k_pw_decide(vg_ground_params* __restrict__
         }
     }
     __syncthreads();
-    // ---- update_elevation_thr (:339-358): independent per ring; ring 0 also rewrites sensor_height ----
-    if (lane < P->num_rings_of_interest && lane < 4) {
-        const int i = lane;
-        if (S->elev_cnt[i] > 0) {
-            double m = 0.0, sd = 0.0;
-            pw_mean_stdev(S->elev[i], S->elev_head[i], S->elev_cnt[i], m, sd);
-            if (i == 0) {
-                S->elevation_thr[i] = m + 3 * sd;
-                S->sensor_height = -m;
-            } else
-                S->elevation_thr[i] = m + 2 * sd;
-            int exceed = S->elev_cnt[i] - P->max_elevation_storage;
-            if (exceed > 0) {
-                S->elev_head[i] = (S->elev_head[i] + exceed) & (PW_STORE_CAP - 1);
-                S->elev_cnt[i] -= exceed;
+    for (int w = lane; w < n_patches; w += blockDim.x) recs[w].decision = lrec[w].decision;
+    __syncthreads();                                        // `raw` changes hands
+    // ---- update_elevation_thr (:339-358) and update_flatness_thr (:360-376) ----
+    // Mean and standard deviation of the eight stores (<= ~1050 values each), summed SEQUENTIALLY in stored order like the
+    // reference's loops (the order is part of the parity model).  One lane per store walking its ring buffer in global memory
+    // was a chain of ~2 100 dependent-latency reads: 373 us per pass once the stores are full, two thirds of the whole ground
+    // pass.  The wave now copies the stores into LDS with coalesced loads, 512 values at a time, and the owner lanes add from
+    // there: the same additions in the same order, ~10 us.
+    double (*const sbuf)[512] = reinterpret_cast<double (*)[512]>(raw);      // [8][512]
+    __shared__ int sh_head[8], sh_cnt[8];
+    const int sid = lane < 4 ? lane : ((lane >= 8 && lane < 12) ? lane - 4 : -1);      // stores 0..3 elevation, 4..7 flatness
+    bool own = false;
+    if (sid >= 0 && sid < 4) own = sid < P->num_rings_of_interest && S->elev_cnt[sid] > 0;
+    if (sid >= 4) {
+        const int i = sid - 4;
+        own = i < P->num_rings_of_interest;
+        for (int j = 0; j <= i; ++j)
+            if (S->flat_cnt[j] <= 1) own = false;           // the reference BREAKS at the first ring with <= 1 entries
+    }
+    if (lane < 8) {
+        sh_head[lane] = lane < 4 ? S->elev_head[lane] : S->flat_head[lane - 4];
+        sh_cnt[lane] = lane < 4 ? S->elev_cnt[lane] : S->flat_cnt[lane - 4];
+    }
+    __syncthreads();
+    int maxcnt = 0;
+    for (int t = 0; t < 8; ++t) maxcnt = max(maxcnt, sh_cnt[t]);
+    const int cnt = sid >= 0 ? sh_cnt[sid] : 0;
+    double mean = 0.0, stdev = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double acc = 0.0;
+        for (int c0 = 0; c0 < maxcnt; c0 += 512) {
+            for (int t = 0; t < 8; ++t) {
+                const double* v = t < 4 ? S->elev[t] : S->flat[t - 4];
+                const int m = min(512, sh_cnt[t] - c0);
+                for (int i = lane; i < m; i += blockDim.x) sbuf[t][i] = v[(sh_head[t] + c0 + i) & (PW_STORE_CAP - 1)];
             }
+            __syncthreads();
+            if (own && cnt > 1) {
+                const int m = min(512, cnt - c0);
+                if (pass == 0) {
+#pragma unroll 8
+                    for (int i = 0; i < m; ++i) acc += sbuf[sid][i];
+                } else {
+#pragma unroll 8
+                    for (int i = 0; i < m; ++i) { const double x = sbuf[sid][i]; acc += (x - mean) * (x - mean); }
+                }
+            }
+            __syncthreads();
+        }
+        if (own && cnt > 1) {                               // pw_mean_stdev (:558-567)
+            if (pass == 0) mean = acc / (double)cnt;
+            else { stdev = acc / (double)(cnt - 1); stdev = sqrt(stdev); }
         }
     }
-    // ---- update_flatness_thr (:360-376): the reference BREAKS at the first ring with <= 1 entries ----
-    if (lane >= 8 && lane < 8 + 4 && (lane - 8) < P->num_rings_of_interest) {
-        const int i = lane - 8;
-        bool blocked = false;
-        for (int j = 0; j <= i; ++j)
-            if (S->flat_cnt[j] <= 1) blocked = true;
-        if (!blocked) {
-            double m = 0.0, sd = 0.0;
-            pw_mean_stdev(S->flat[i], S->flat_head[i], S->flat_cnt[i], m, sd);
-            S->flatness_thr[i] = m + sd;
-            int exceed = S->flat_cnt[i] - P->max_flatness_storage;
-            if (exceed > 0) {
-                S->flat_head[i] = (S->flat_head[i] + exceed) & (PW_STORE_CAP - 1);
-                S->flat_cnt[i] -= exceed;
-            }
+    if (own && sid < 4) {
+        const int i = sid;
+        if (i == 0) {
+            S->elevation_thr[i] = mean + 3 * stdev;
+            S->sensor_height = -mean;
+        } else
+            S->elevation_thr[i] = mean + 2 * stdev;
+        int exceed = S->elev_cnt[i] - P->max_elevation_storage;
+        if (exceed > 0) {
+            S->elev_head[i] = (S->elev_head[i] + exceed) & (PW_STORE_CAP - 1);
+            S->elev_cnt[i] -= exceed;
+        }
+    }
+    if (own && sid >= 4) {
+        const int i = sid - 4;
+        S->flatness_thr[i] = mean + stdev;
+        int exceed = S->flat_cnt[i] - P->max_flatness_storage;
+        if (exceed > 0) {
+            S->flat_head[i] = (S->flat_head[i] + exceed) & (PW_STORE_CAP - 1);
+            S->flat_cnt[i] -= exceed;
         }
     }
 }
@@ -702,6 +739,7 @@ int vg_ground_create(vg_ground** out, const vg_ground_params* p, int max_points)
     VG_CHECK(hipMalloc(&h->d_state, sizeof(PwState)));
     VG_CHECK(hipMalloc(&h->d_patch_id, sizeof(int) * (size_t)max_points));
     VG_CHECK(hipMalloc(&h->d_count, sizeof(int) * PW_MAX_PATCHES));
+    VG_CHECK(hipMemset(h->d_count, 0, sizeof(int) * PW_MAX_PATCHES));
     VG_CHECK(hipMalloc(&h->d_offset, sizeof(int) * (PW_MAX_PATCHES + 1)));
     VG_CHECK(hipMalloc(&h->d_cursor, sizeof(int) * PW_MAX_PATCHES));
     VG_CHECK(hipMalloc(&h->d_keys, sizeof(unsigned long long) * (size_t)max_points));
@@ -733,11 +771,9 @@ int vg_ground_estimate(vg_ground* h, const float* d_points, int n, int stride, d
     if (n > h->max_points) return VG_ERR_CAPACITY;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) return VG_OK;
-    VG_CHECK(hipMemsetAsync(h->d_count, 0, sizeof(int) * PW_MAX_PATCHES, st));
-    VG_CHECK(hipMemsetAsync(h->d_inlier, 0, (size_t)n, st));
     const int nb = vg_div_up(n, 256);
     hipLaunchKernelGGL(k_pw_classify, dim3(nb), dim3(256), 0, st, d_points, n, stride, z_offset, h->d_p, h->d_g,
-                       h->d_state, h->d_patch_id, h->d_count);
+                       h->d_state, h->d_patch_id, h->d_count, h->d_inlier);
     hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(64), 0, st, h->d_count, h->d_offset, h->d_cursor, h->g.n_patches);
     hipLaunchKernelGGL(k_pw_scatter, dim3(nb), dim3(256), 0, st, d_points, n, stride, z_offset, h->d_patch_id,
                        h->d_offset, h->d_cursor, h->d_keys);
@@ -752,7 +788,7 @@ int vg_ground_estimate(vg_ground* h, const float* d_points, int n, int stride, d
     // k_pw_patch reads x, y straight from d_points and z from the key (already offset)
     hipLaunchKernelGGL(k_pw_patch, dim3(h->g.n_patches), dim3(PW_T), 0, st, d_points, stride, h->d_p, h->d_g, h->d_state,
                        h->d_offset, h->d_keys, h->d_inlier, h->d_rec);
-    hipLaunchKernelGGL(k_pw_decide, dim3(1), dim3(64), 0, st, h->d_p, h->d_g, h->d_state, h->d_rec);
+    hipLaunchKernelGGL(k_pw_decide, dim3(1), dim3(256), 0, st, h->d_p, h->d_g, h->d_state, h->d_rec);
     hipLaunchKernelGGL(k_pw_finalize, dim3(nb), dim3(256), 0, st, h->d_patch_id, h->d_inlier, h->d_rec, n, d_ground_mask);
     VG_LAUNCH_CHECK();
     return VG_OK;
