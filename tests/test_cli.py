@@ -174,6 +174,11 @@ def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
             assert np.array_equal(d['cluster_points_index'], e['cluster_points_index']) and d['valid'] == e['valid']
             assert d['static'] == e['static'] and d.get('static_track') == e.get('static_track')
             assert ('_bounding_box' in d) == ('_bounding_box' in e) and ('_bounding_box' not in d or np.array_equal(d['_bounding_box'], e['_bounding_box']))
+    # one sequence on two ranks = frame sharding (device.shard=auto): the part that does not shrink with the number of ranks --
+    # the sequence-level stages every rank repeats -- is measured and logged by the entry point
+    rep = [ln for ln in open(tmp_path / 'rank0.log').read().splitlines() if 'repeated on every rank' in ln]
+    assert rep, 'the entry point reports the replicated sequence-level stages of a frame-sharded run'
+    print(rep[-1].split(' - ')[-1].strip())
 
 
 @pytest.mark.gpu

@@ -63,6 +63,35 @@ def test_greedy_assignment_properties():
     assert m0.shape == (0, 2) and len(n0) == 0
 
 
+def test_array_form_of_the_track_boxes_equals_the_line_by_line_form():
+    """vilgod_amd/tracking.py evaluates the motion vectors and the motion-aligned boxes of a track with array operations; the
+    line-by-line restatement of zero_shot_detector.py:491-659 (oracle/tracking_oracle.py, the form pinned against the reference's
+    own run by track_golden.pkl) must come out bit for bit: directions (values and dtype) and boxes, on 200 seeded tracks that
+    cover standing, creeping, walking and driving objects, short tracks, and both sources of the cluster medians."""
+    from oracle import tracking_oracle as to
+    rng = np.random.default_rng(0)
+    n_vec = n_box = 0
+    for trial in range(200):
+        n = int(rng.integers(1, 40))
+        speed = rng.choice([0.0, 0.02, 0.2, 0.6, 1.5])
+        head = rng.uniform(0, 6.28)
+        c = np.cumsum(np.c_[np.cos(head + rng.normal(0, 0.3, n)), np.sin(head + rng.normal(0, 0.3, n))] * speed * rng.uniform(0.5, 1.5, (n, 1)), axis=0)
+        c = (c + rng.normal(0, 0.05, (n, 2)) + rng.uniform(-50, 50, 2)).astype(np.float32)
+        a, b = to.motion_vectors(c), tracking.motion_vectors(c)
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and np.array_equal(x, y), trial
+        if not a:
+            continue
+        n_vec += 1
+        pts = [(rng.normal(size=(int(rng.integers(12, 300)), 5)) * [1.5, 0.7, 0.6, 1, 1] + [c[i, 0], c[i, 1], 0.8, 0, 0]).astype(np.float32) for i in range(n)]
+        T = [np.linalg.inv(p) for p in synthetic.make_poses(n, seed=trial)]
+        for c3 in (None, [np.median(p[:, :3], axis=0) for p in pts]):
+            assert np.array_equal(to.moving_boxes(pts, a, T, centers3=c3), tracking.moving_boxes(pts, a, T, centers3=c3)), trial
+            n_box += 1
+    assert n_vec > 50 and n_box > 100
+
+
 def build_table(gold, X):
     tab = tracking.DetectionTable()
     pts, stat = {}, {}

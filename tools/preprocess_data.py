@@ -93,7 +93,17 @@ def main(argv=None):
     # several ranks: device.shard = frames (default; north_star's configuration: every sequence's frames in contiguous blocks over the
     # ranks, Patchwork++ state handed down the rank chain, one all-gather of the scores per sequence) or sequences (rank r takes
     # sequences r, r + N, ...: no exchange at all until the final evaluation -- the better choice for data sets of many sequences)
-    by_sequence = world > 1 and dev.get('shard', 'frames') == 'sequences'
+    # auto (default): sequences when there are at least as many sequences as ranks, else frames.  Sharding the frames of one sequence
+    # leaves its sequence-level stages -- track_clusters, the tracked box fit, propagate_labels, the state pickle: ~5 of ~25 ms per
+    # frame on one GPU -- replicated on every rank (Amdahl: ~3.5x at 8 GPUs); whole sequences per rank have none.
+    shard = dev.get('shard', 'auto')
+    if shard == 'auto':
+        names = getattr(dataset, 'sequence_names', None)
+        shard = 'sequences' if (world > 1 and names is not None and len(names) >= world) else 'frames'
+    if isinstance(dev, dict):
+        dev['shard'] = shard                                # (the stage dispatcher reads the resolved choice)
+    by_sequence = world > 1 and shard == 'sequences'
+    logger.info(f'ranks: {world}; sharding: {shard}')
     if by_sequence:
         result_path.mkdir(parents=True, exist_ok=True)      # every rank writes the pickles of its own sequences
     starts = []                                             # (sequence number, offsets into detection_results / indices) of this rank's sequences
@@ -133,7 +143,15 @@ def main(argv=None):
         torch.cuda.synchronize()
         LAST_RUN['sequences'].append({'name': sequence_name, 'frames': dataset.sequence_length, 'world_size': world,
                                       'seconds': time.perf_counter() - t_seq, 'stage_ms_per_frame': dict(zsd.stage_ms),
+                                      # the stages every rank repeats over ALL frames when the frames of one sequence are sharded (ms per frame of the
+                                      # sequence; with device.shard=sequences nothing is replicated)
+                                      'replicated_ms_per_frame': 0.0 if (world == 1 or by_sequence) else round(sum(
+                                          zsd.stage_ms.get(k, 0.0) * max(len(zsd.my_frames), 1) for k in ('track_clusters', 'propagate_labels', 'write_sequence_state')
+                                      ) / max(dataset.sequence_length, 1), 3),
                                       'detail_ms': dict(zsd.detail_ms)})
+        if LAST_RUN['sequences'][-1]['replicated_ms_per_frame']:
+            logger.info(f"  sequence-level stages repeated on every rank: {LAST_RUN['sequences'][-1]['replicated_ms_per_frame']:.2f} ms per frame of the sequence "
+                        f"(of {1000.0 * LAST_RUN['sequences'][-1]['seconds'] / max(dataset.sequence_length, 1):.2f}); device.shard=sequences has none")
         del zsd
         gc.collect()
         torch.cuda.empty_cache()

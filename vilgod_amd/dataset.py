@@ -47,6 +47,11 @@ class SyntheticDataset:
     def sequence_length(self):
         return len(self.sequence_infos)
 
+    @property
+    def sequence_names(self):
+        """Names `next_sequence` will yield (the real-data adapters' member of the same name, sequence_datasets.py)."""
+        return [f'synthetic_{self.split}_{sid:04d}' for sid in range(self.start_sequence, min(self.end_sequence + 1, self.n_sequences))]
+
     def next_sequence(self):
         """Generator of sequence names; loads poses/infos of each sequence (waymo_dataset.py `next_sequence`)."""
         for sid in range(self.start_sequence, min(self.end_sequence + 1, self.n_sequences)):

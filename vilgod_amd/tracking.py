@@ -208,11 +208,9 @@ def static_box(points, rectangle):
     return np.array([c[0], c[1], points[:, 2].min() + height / 2, l, w, height + 0.3, rz])
 
 
-def _angle_deg(v1, v2):
-    """common_utils.py:73-76 (a zero vector gives nan, which fails every comparison below, as upstream)."""
-    with np.errstate(invalid='ignore', divide='ignore'):
-        cos = v1 @ v2 / (np.linalg.norm(v1) * np.linalg.norm(v2))
-    return np.rad2deg(np.arccos(np.clip(cos, -0.9999, 0.9999)))
+def _norm2(v):
+    """np.linalg.norm of float32 2-vectors along the last axis (x.dot(x) then sqrt, in float32)."""
+    return np.sqrt(v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1])
 
 
 def motion_vectors(centers_xy, look_ahead=10, min_far=0.5, min_step=0.3, max_angle=60):
@@ -221,82 +219,119 @@ def motion_vectors(centers_xy, look_ahead=10, min_far=0.5, min_step=0.3, max_ang
     yet; otherwise the last good one is kept); the steps to the entries in between that point within 60 deg of `far` and are
     longer than 0.3 m are averaged with weights 0.95^(i+1) / sum 0.9^(i+1) (i = ABSOLUTE entry index) and blended 50:50 with
     the previous direction; no such step -> previous direction, else `far`.  Any entry without a `far` vector voids the whole
-    track (-> []), which sends it down the static path.  float32 throughout, like the medians."""
+    track (-> []), which sends it down the static path.  float32 throughout, like the medians.
+
+    Evaluated with array operations over the whole track (the line-by-line form, oracle/tracking_oracle.py, spent ~250 us of
+    interpreter time per entry: 3.5 ms per frame of a 199-frame sequence); same float32 operations in the same order, so the
+    directions are the same bits (tests/test_tracking.py)."""
+    centers_xy = np.asarray(centers_xy)
     n = len(centers_xy)
-    out = []
+    if n == 0:
+        return []
+    idx = np.arange(n)
+    c_far = np.minimum(idx + look_ahead - 1, n - 1)
+    cand = centers_xy[c_far] - centers_xy                                # [n,2] float32
+    cand_norm = _norm2(cand)
+    # ---- the far vector of every entry (sequential state: the last good one is kept) ----
+    fars = np.empty_like(cand)
     far = None
     for c in range(n):
-        here = centers_xy[c]
-        c_far = min(c + look_ahead - 1, n - 1)
-        cand = np.array([centers_xy[c_far, 0] - here[0], centers_xy[c_far, 1] - here[1]])
-        if np.linalg.norm(cand) < min_far and far is None:
-            k = 1
-            while np.linalg.norm(cand) < min_far and (c_far + k) < n:
-                cand = np.array([centers_xy[c_far + k, 0] - here[0], centers_xy[c_far + k, 1] - here[1]])
+        if cand_norm[c] < min_far and far is None:
+            k = c_far[c] + 1                                             # look further on while nothing longer than 0.5 m is known
+            v, vn = cand[c], cand_norm[c]
+            while vn < min_far and k < n:
+                v = centers_xy[k] - centers_xy[c]
+                vn = _norm2(v)
                 k += 1
-            if np.linalg.norm(cand) >= min_far:
-                far = cand
-        elif np.linalg.norm(cand) < min_far:
-            pass                                         # slow stretch in the middle / at the end: keep the last direction
-        else:
-            far = cand
+            if vn >= min_far:
+                far = v
+        elif cand_norm[c] >= min_far:
+            far = cand[c]
         if far is None:
             return []
-        steps, wsum = [], 0
-        for i in range(c + 1, c_far):
-            step = np.array([centers_xy[i, 0] - here[0], centers_xy[i, 1] - here[1]])
-            if _angle_deg(far, step) < max_angle and np.linalg.norm(step) > min_step:
-                steps.append(step * (0.95 ** (i + 1)))
-                wsum += (0.9 ** (i + 1))
-        if steps:
-            v = np.mean(steps, axis=0) / wsum
+        fars[c] = far
+    # ---- the steps c+1 .. c_far-1 of every entry, padded to look_ahead - 2 columns ----
+    m = max(look_ahead - 2, 0)
+    out = []
+    if m:
+        j = idx[:, None] + 1 + np.arange(m)[None, :]                     # absolute index i of the step's end
+        ok = j < c_far[:, None]
+        jj = np.minimum(j, n - 1)
+        step = centers_xy[jj] - centers_xy[:, None, :]                   # [n,m,2]
+        sn = _norm2(step)
+        fn = _norm2(fars)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            cos = (fars[:, None, 0] * step[..., 0] + fars[:, None, 1] * step[..., 1]) / (fn[:, None] * sn)
+        ang = np.rad2deg(np.arccos(np.clip(cos, -0.9999, 0.9999)))
+        sel = ok & (ang < max_angle) & (sn > min_step)
+        w95 = np.array([0.95 ** (i + 1) for i in range(n + m + 1)], dtype=np.float32)[jj]
+        w90 = np.array([0.9 ** (i + 1) for i in range(n + m + 1)])[jj]
+        contrib = np.where(sel[..., None], step * w95[..., None], np.float32(0))
+        cnt = sel.sum(axis=1)
+        ssum = contrib.sum(axis=1, dtype=np.float32)                     # sequential over the steps: zeros of unselected ones change nothing
+        wsum = np.zeros(n)
+        for q in range(m):                                               # python floats added in step order, like upstream's `+=`
+            wsum = np.where(sel[:, q], wsum + w90[:, q], wsum)
+    else:
+        cnt = np.zeros(n, int)
+    for c in range(n):
+        if cnt[c]:
+            v = (ssum[c] / np.float32(cnt[c])) / float(wsum[c])       # (python float: the quotient stays float32, like upstream's)
             if out:
                 v = v * 0.5 + out[-1] * 0.5
             out.append(v)
         elif out:
             out.append(out[-1])
         else:
-            out.append(far)
+            out.append(fars[c].copy())
     return out
 
 
 def moving_boxes(points_list, directions, to_ego_list, top_k=3, centers3=None):
     """zero_shot_detector.py:572-659: a box per entry aligned with its direction of travel, all resized to the median size of the
-    top_k entries with the most points and shifted so that the corner closest to the ego vehicle stays where it was."""
+    top_k entries with the most points and shifted so that the corner closest to the ego vehicle stays where it was.
+    The rotations of a track come from one scipy call and the closest-corner shifts are array operations over the track; the
+    products that go through BLAS upstream (np.dot) stay per-entry np.dot calls so that their rounding is the same."""
     from scipy.spatial.transform import Rotation as R
-    boxes, corner_list = [], []
-    for j, (pts_all, d) in enumerate(zip(points_list, directions)):
-        angle = np.arctan2(d[1], d[0])
-        rot = R.from_euler('z', angle, degrees=False).as_matrix()
+    n = len(points_list)
+    d = np.asarray(directions)
+    angle = np.arctan2(d[:, 1], d[:, 0])
+    rots = R.from_euler('z', angle, degrees=False).as_matrix()
+    boxes = np.empty((n, 7))
+    corner_arr = np.empty((n, 4, 2))
+    tops = np.empty(n)
+    for j, pts_all in enumerate(points_list):
+        rot = rots[j]
         center = np.median(pts_all[..., :3], axis=0) if centers3 is None else np.asarray(centers3[j], dtype=pts_all.dtype)
         proj = np.dot(pts_all[..., :3] - center, rot)
-        min_x, max_x = proj[:, 0].min(), proj[:, 0].max()
-        min_y, max_y = proj[:, 1].min(), proj[:, 1].max()
-        rect = np.array([[max_x, min_y], [min_x, min_y], [min_x, max_y], [max_x, max_y]], dtype=np.float32)
+        mn, mx = proj.min(axis=0), proj.max(axis=0)
+        rect = np.array([[mx[0], mn[1]], [mn[0], mn[1]], [mn[0], mx[1]], [mx[0], mx[1]]], dtype=np.float32)
         corners = np.dot(rect, rot[:2, :2].T)
         corners += center[:2]
         w = np.linalg.norm(corners[0] - corners[1])
         l = np.linalg.norm(corners[0] - corners[-1])
         c = (corners[0] + corners[2]) / 2
-        corner_list.append(corners)
-        height = pts_all[:, 2].max() - pts_all[:, 2].min()
-        boxes.append(np.array([c[0], c[1], pts_all[:, 2].min() + height / 2, w, l, height, angle]))
-    boxes = np.array(boxes)
+        corner_arr[j] = corners
+        z = pts_all[:, 2]
+        zmin, zmax = z.min(), z.max()
+        height = zmax - zmin
+        tops[j] = zmax
+        boxes[j] = (c[0], c[1], zmin + height / 2, w, l, height, angle[j])
     top = np.argsort([len(p) for p in points_list])[-top_k:]
     ref = np.median(boxes[top], axis=0)
-    tops = np.array([np.max(p[..., 2]) for p in points_list])
-    for i, (corners, T) in enumerate(zip(corner_list, to_ego_list)):
-        h = np.hstack((np.concatenate([corners, np.zeros((4, 1))], axis=1), np.ones((4, 1))))
+    cc = np.empty(n, dtype=np.int64)
+    for i, T in enumerate(to_ego_list):
+        h = np.hstack((np.concatenate([corner_arr[i], np.zeros((4, 1))], axis=1), np.ones((4, 1))))
         ego = np.einsum('ij,kj->ki', T, h)[:, :2]                      # apply_transform (pointcloud_utils.py:21-46)
-        cc = int(np.linalg.norm(ego, axis=1).argmin())
-        dw, dl = ref[3] - boxes[i, 3], ref[4] - boxes[i, 4]
-        ang = np.arctan2(directions[i][1], directions[i][0])
-        sx = -1.0 if cc in (0, 3) else 1.0                             # corners 0,3 hold max x: grow towards -x
-        sy = 1.0 if cc in (0, 1) else -1.0                             # corners 0,1 hold min y: grow towards +y
-        boxes[i, 0] += sx * (dw / 2) * np.cos(ang)
-        boxes[i, 1] += sx * (dw / 2) * np.sin(ang)
-        boxes[i, 0] += sy * (dl / 2) * np.sin(-ang)
-        boxes[i, 1] += sy * (dl / 2) * np.cos(-ang)
+        cc[i] = int(np.linalg.norm(ego, axis=1).argmin())
+    dw, dl = ref[3] - boxes[:, 3], ref[4] - boxes[:, 4]
+    ang = angle                                                         # (dtype of the directions, as upstream's np.arctan2 of them)
+    sx = np.where((cc == 0) | (cc == 3), -1.0, 1.0)                     # corners 0,3 hold max x: grow towards -x
+    sy = np.where((cc == 0) | (cc == 1), 1.0, -1.0)                     # corners 0,1 hold min y: grow towards +y
+    boxes[:, 0] += sx * (dw / 2) * np.cos(ang)
+    boxes[:, 1] += sx * (dw / 2) * np.sin(ang)
+    boxes[:, 0] += sy * (dl / 2) * np.sin(-ang)
+    boxes[:, 1] += sy * (dl / 2) * np.cos(-ang)
     boxes[..., 3:6] = ref[3:6]
     boxes[..., 2] = tops - (ref[5] / 2)
     return boxes

@@ -43,7 +43,7 @@ class ZeroShotDetector:
         self.lenght = dataset.sequence_length          # (sic) attribute name of the reference, :31
         self.rank, self.world_size = vdist.world()
         dev = cfg.get('device', {}) if hasattr(cfg, 'get') else {}
-        if dev.get('shard', 'frames') == 'sequences':
+        if dev.get('shard', 'auto') == 'sequences':         # (tools/preprocess_data.py resolves `auto` before it builds the detector)
             self.rank, self.world_size = 0, 1            # whole sequences per rank (tools/preprocess_data.py): nothing is exchanged inside one
         if pipeline is None:
             margs = [t for t in cfg.pipeline if t['name'] == 'mask_ground_points']
