@@ -30,3 +30,11 @@ def test_header_has_no_torch_types():
 def test_header_cites_reference_lines():
     src = open(os.path.join(ROOT, 'include', 'vilgod_hip.h')).read()
     assert len(re.findall(r'\.(py|cpp|h):\d+', src)) >= 8
+
+
+def test_cluster_kernels_hold_no_unencodable_64bit_literals():
+    """ROCm 7.2's gfx950 back end can materialise a wave-uniform `double x = INFINITY` as `s_mov_b64 s[..], 0x7ff0000000000000`,
+    which gfx9 cannot encode (the object file then holds 0.0; round 3, k_cl_core_far).  csrc/cluster.hip keeps such values in
+    SGPRs, so its assembly is scanned here; `python -m vilgod_amd.build --check-isa` scans every source (vit.hip takes a minute)."""
+    from vilgod_amd import build
+    assert build.check_isa(sources=['cluster.hip']) == []

@@ -92,5 +92,41 @@ def build(force=False, verbose=True, dev=False):
     return LIB
 
 
+def check_isa(sources=None, verbose=False):
+    """Guard against a code-generation bug of this ROCm's gfx950 back end (found in round 3, csrc/cluster.hip ClGrid::inf): a
+    wave-uniform 64-bit constant whose HIGH half is not zero -- `double x = INFINITY` kept in SGPRs -- can be materialised as
+    `s_mov_b64 s[..], 0x7ff0000000000000`.  gfx9 encodes 32-bit literals only: the assembler rejects that line, and the direct
+    object emission drops the high half (the kernel then sees 0.0).  Compiles the sources to assembly (device side only) and
+    returns the offending lines (empty = clean)."""
+    import re
+    import tempfile
+    hipcc = _hipcc()
+    bad = []
+    pat = re.compile(r's_mov_b64\s+s\[[0-9:]+\],\s*0x[0-9a-fA-F]{9,}')
+    for src, extra in SOURCES.items():
+        if not src.endswith('.hip') or (sources is not None and src not in sources):
+            continue
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, src + '.s')
+            cmd = [hipcc] + [c for c in COMMON if c != '-fPIC'] + extra + ['-S', '--cuda-device-only', os.path.join(CSRC, src), '-o', out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f'hipcc -S failed for {src}:\n{r.stderr}')
+            kernel = None
+            for line in open(out):
+                if line.startswith('_Z') and line.rstrip().endswith(':'):
+                    kernel = line.strip()[:-1]
+                if pat.search(line):
+                    bad.append((src, kernel, line.strip()))
+        if verbose:
+            print(f'[vilgod_amd.build] isa check {src}: {sum(1 for b in bad if b[0] == src)} unencodable literals', flush=True)
+    return bad
+
+
 if __name__ == '__main__':
+    if '--check-isa' in sys.argv:
+        found = check_isa(verbose=True)
+        for f in found:
+            print(*f)
+        sys.exit(1 if found else 0)
     print(build(force='--force' in sys.argv, dev='--dev' in sys.argv))
