@@ -314,11 +314,14 @@ def main():
     # (1 frame in flight) of the same workload right after the timed region -- with several frames in flight the pairs would
     # also span other streams' kernels and stop measuring this kernel.
     launches = gemm_ms = gemm_flops = all_launches = all_ms = all_flops = 0
-    n_pass = min(4, K)
+    # the FIRST six clouds of the stream: the frames tools/collect_profiles.sh's run (--warmup 2 --steps 4 --inflight 1) processes, so
+    # that the live average and the rocprofv3 kernel-trace average are taken over the same launches (the average launch time follows
+    # the frame's crop count)
+    n_pass = min(6, W + K)
     if not args.no_roofline_pass:
         pipe.clip.encoder.profile(True)
         for i in range(n_pass):
-            pipe.process_frame(pipe.upload(frames[W + i]), poses[i + 1], poses[0], fnr=i)
+            pipe.process_frame(pipe.upload(frames[i]), poses[i + 1], poses[0], fnr=i)
         launches, gemm_ms, gemm_flops = pipe.clip.encoder.profile_read(kind=1)        # the dominant kernel alone
         all_launches, all_ms, all_flops = pipe.clip.encoder.profile_read(kind=-1)
         pipe.clip.encoder.profile(False)
@@ -362,7 +365,7 @@ def main():
                 'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_unit': 'HBM bytes per launch (PMC)',
                 'traffic_source': traffic_src,
-                'method': f'HIP event pairs on the launch stream around every {DOMINANT_KERNEL} launch, sequential pass (1 frame in flight) of the same frames right after the timed region',
+                'method': f'HIP event pairs on the launch stream around every {DOMINANT_KERNEL} launch, sequential pass (1 frame in flight) over the first {n_pass} clouds of the stream right after the timed region (the frames of the committed rocprofv3 run)',
                 'note': 'the launches also carry the blocks\' LayerNorms (folded into the GEMM epilogues; their work is not counted in the algorithmic FLOPs). '
                         'Like for like: with separate LayerNorm kernels (VG_VIT_LN_FOLD=0) the GEMM launches alone reach 0.31, GEMM + LayerNorm launches together 0.29 '
                         '(13.96 + 1.27 ms per frame against 14.67 ms now, profiles/r02i vs r02l)',
