@@ -166,3 +166,26 @@ def test_stage_fusion_plan_follows_the_stage_list():
     assert plan(single) == ['filter_detections', 'classification']
     assert plan('pipeline_active=[mask_ground_points,spatial_clustering,classification]') == []          # valid_only without the filter stage
     assert plan('pipeline_active=[mask_ground_points,filter_detections,classification]') == []           # no clustering stage to ride in
+
+
+def test_box_helper_pool_survives_a_dead_helper():
+    """box_mode='reference': a helper process that died is replaced and the request repeated; results equal the in-thread ones."""
+    from vilgod_amd import boxes
+    rng = np.random.default_rng(0)
+    xy = rng.normal(size=(300, 2)).astype(np.float32)
+    seg = np.array([0, 100, 180, 300], np.int64)
+    zmin, zmax = np.zeros(3, np.float32), np.ones(3, np.float32)
+    want = boxes.reference_boxes_packed(xy, seg, zmin, zmax)
+    pool = boxes.BoxWorkerPool(1)
+    try:
+        assert np.array_equal(pool.submit(xy, seg, zmin, zmax).result(), want)
+        pool.procs[0].kill()
+        pool.procs[0].wait(timeout=10)
+        assert np.array_equal(pool.submit(xy, seg, zmin, zmax).result(), want)
+        assert pool.respawned == 1
+        pool.grow(2)
+        assert len(pool.procs) == 2
+        futs = [pool.submit(xy, seg, zmin, zmax) for _ in range(6)]
+        assert all(np.array_equal(f.result(), want) for f in futs)
+    finally:
+        pool.close()

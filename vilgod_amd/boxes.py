@@ -92,41 +92,71 @@ class BoxWorkerPool:
     and any number of requests may be outstanding (a stage may queue every frame of a sequence before it reads the first answer)."""
 
     def __init__(self, n_procs):
-        import os
         import queue
+        self.requests = queue.Queue()
+        self.procs, self.threads = [], []
+        self.respawned = 0
+        self.grow(n_procs)
+
+    @staticmethod
+    def _spawn():
+        import os
         import subprocess
         import sys
-        import threading
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
         env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
-        self.requests = queue.Queue()
-        self.procs, self.threads = [], []
-        for _ in range(int(n_procs)):
-            p = subprocess.Popen([sys.executable, '-m', 'vilgod_amd.box_worker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
-            t = threading.Thread(target=self._serve, args=(p,), daemon=True)
+        return subprocess.Popen([sys.executable, '-m', 'vilgod_amd.box_worker'], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env, cwd=root)
+
+    def grow(self, n_procs):
+        """At least n_procs helpers (a pipeline that asks for more than an earlier one built gets them)."""
+        import threading
+        while len(self.procs) < int(n_procs):
+            slot = len(self.procs)
+            self.procs.append(self._spawn())
+            t = threading.Thread(target=self._serve, args=(slot,), daemon=True)
             t.start()
-            self.procs.append(p)
             self.threads.append(t)
 
-    def _serve(self, p):
+    @staticmethod
+    def _exchange(p, req):
         import pickle
         import struct
+        blob = pickle.dumps(req, protocol=pickle.HIGHEST_PROTOCOL)
+        p.stdin.write(struct.pack('<q', len(blob)))
+        p.stdin.write(blob)
+        p.stdin.flush()
+        head = p.stdout.read(8)
+        if len(head) < 8:
+            raise BrokenPipeError('box helper process ended unexpectedly')
+        (n,) = struct.unpack('<q', head)
+        body = p.stdout.read(n)
+        if len(body) < n:
+            raise BrokenPipeError('box helper process ended in the middle of an answer')
+        return pickle.loads(body)
+
+    def _serve(self, slot):
         while True:
             item = self.requests.get()
             if item is None:
                 return
             fut, req = item
             try:
-                blob = pickle.dumps(req, protocol=pickle.HIGHEST_PROTOCOL)
-                p.stdin.write(struct.pack('<q', len(blob)))
-                p.stdin.write(blob)
-                p.stdin.flush()
-                head = p.stdout.read(8)
-                if len(head) < 8:
-                    raise RuntimeError('box helper process ended unexpectedly')
-                (n,) = struct.unpack('<q', head)
-                status, val = pickle.loads(p.stdout.read(n))
+                try:
+                    status, val = self._exchange(self.procs[slot], req)
+                except (BrokenPipeError, EOFError, OSError, ValueError):
+                    # the helper died (or the pipe's framing is lost): a fresh child process, the request once more; if that fails
+                    # too the boxes are computed here, by the same function the helper runs
+                    try:
+                        self.procs[slot].kill()
+                    except Exception:       # noqa: BLE001
+                        pass
+                    self.procs[slot] = self._spawn()
+                    self.respawned += 1
+                    try:
+                        status, val = self._exchange(self.procs[slot], req)
+                    except (BrokenPipeError, EOFError, OSError, ValueError):
+                        status, val = 'ok', reference_boxes_packed(*req)
                 if status != 'ok':
                     raise RuntimeError(f'box helper process: {val}')
                 fut.set_result(val)
@@ -177,6 +207,8 @@ def _pool(n_procs):
             import atexit
             _POOL = BoxWorkerPool(n_procs)
             atexit.register(shutdown_pool)
+        else:
+            _POOL.grow(n_procs)             # one pool per process; it only ever grows
     return _POOL
 
 

@@ -23,6 +23,27 @@
 
 static inline int vg_div_up(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute belongs to the device's code object, so a
+// process-wide `static bool` would leave a second device of the process without it (its launches with > 64 KB of dynamic LDS fail).
+// One bit per device in an atomic word; setting it twice is harmless, so racing threads need no lock.
+#include <atomic>
+struct VgPerDeviceOnce { std::atomic<unsigned long long> done{0}; };
+static inline int vg_max_dynamic_lds(const void* kernel, int bytes, VgPerDeviceOnce& once) {
+    int dev = 0;
+    VG_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (once.done.load(std::memory_order_acquire) & bit) return VG_OK;
+    VG_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    once.done.fetch_or(bit, std::memory_order_release);
+    return VG_OK;
+}
+#define VG_MAX_DYNAMIC_LDS(kernel, bytes)                                                   \
+    do {                                                                                    \
+        static VgPerDeviceOnce _once;                                                       \
+        const int _rc = vg_max_dynamic_lds((const void*)(kernel), (int)(bytes), _once);    \
+        if (_rc != VG_OK) return _rc;                                                       \
+    } while (0)
+
 #define WAVE 64
 
 // order-preserving float <-> uint key (for radix select / atomic min-max on signed floats)

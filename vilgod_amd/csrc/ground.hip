@@ -778,11 +778,7 @@ int vg_ground_estimate(vg_ground* h, const float* d_points, int n, int stride, d
     hipLaunchKernelGGL(k_pw_scatter, dim3(nb), dim3(256), 0, st, d_points, n, stride, z_offset, h->d_patch_id,
                        h->d_offset, h->d_cursor, h->d_keys);
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            VG_CHECK(hipFuncSetAttribute((const void*)k_pw_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, PW_BIG_LDS_POINTS * 8));
-            attr_set = true;
-        }
+        VG_MAX_DYNAMIC_LDS(k_pw_sort_big, PW_BIG_LDS_POINTS * 8);
         hipLaunchKernelGGL(k_pw_sort_big, dim3(h->g.n_patches), dim3(1024), PW_BIG_LDS_POINTS * 8, st, h->d_p, h->d_offset, h->d_keys);
     }
     // k_pw_patch reads x, y straight from d_points and z from the key (already offset)

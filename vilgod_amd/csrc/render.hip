@@ -531,13 +531,8 @@ int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clust
     if (n_clusters <= 0 || n_views <= 0) return VG_OK;
     if (!d_origin || !d_seg_off || !d_view_rot || !d_lut || !d_out || out_kind < 0 || out_kind > 4)
         return VG_ERR_ARG;
-    static bool attr_set = false;
     const size_t lds_bytes = (size_t)(GR * GR + GR * GO) * sizeof(float);
-    if (!attr_set) {
-        VG_CHECK(hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes));
-        attr_set = true;
-    }
+    VG_MAX_DYNAMIC_LDS(k_render, lds_bytes);
     RenderArgs a;
     a.origin = d_origin;
     a.seg_off = d_seg_off;

@@ -1653,11 +1653,7 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
     if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
     auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST, LN>;
     const int lds = 5 * 32768;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
     int cwt = gemm_chunk_tiles_256(ntn);
     if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep
@@ -1682,11 +1678,7 @@ static int launch_gemm_pp16(const void* X, const void* Wt, const float* bias, vo
     if (M % 256 || N % 256 || K % GK || K / GK < STAGES) return VG_ERR_ARG;
     auto kern = k_gemm_f16_pp16<EPI, STAGES>;
     const int lds = STAGES * 32768;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
     int cwt = gemm_chunk_tiles_256(ntn);
     hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
@@ -1701,11 +1693,7 @@ static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void
     if (M % 256 || N % 256 || K % GK || K / GK < STAGES) return VG_ERR_ARG;
     auto kern = k_gemm_f16_pp<EPI, STAGES, TRACE, PH>;
     const int lds = STAGES * 32768;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VG_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
     int cwt = gemm_chunk_tiles_256(ntn);
     hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
@@ -1759,11 +1747,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
         }
         if (LN != 0) return VG_ERR_ARG;            // the folded LayerNorm exists in the 256 x 256 kernel only
         int nwg = (M / GBM) * (N / GBN);
-        static bool attr_set = false;
-        if (!attr_set) {
-            VG_CHECK(hipFuncSetAttribute((const void*)k_gemm_f16<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-            attr_set = true;
-        }
+        VG_MAX_DYNAMIC_LDS(k_gemm_f16<EPI>, G_LDS_BYTES);
         hipLaunchKernelGGL((k_gemm_f16<EPI>), dim3(nwg), dim3(512), G_LDS_BYTES, st, (const f16*)X, (const f16*)Wt, bias, C,
                            resid, M, N, K, ldc, gemm_chunk_tiles(N, K));
     } else {
@@ -1783,13 +1767,11 @@ static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, i
     const dim3 grid(items < 256 ? items : 256), block(448);
 #define VG_ATT(N)                                                                                                                  \
     case N: {                                                                                                                      \
-        static bool attr_ = false;                                                                                                 \
-        if (!attr_) { VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<TRACE, N>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES)); attr_ = true; } \
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<TRACE, N>), AT_LDS_BYTES);                                                              \
         hipLaunchKernelGGL((k_attention_f16<TRACE, N>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);   \
         break; }
     if (T == 197 && !TRACE) {                  // ViT-B/16
-        static bool attr_ = false;
-        if (!attr_) { VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f16<false, 7, 197>, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES)); attr_ = true; }
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197>), AT_LDS_BYTES);
         hipLaunchKernelGGL((k_attention_f16<false, 7, 197>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);
         VG_LAUNCH_CHECK();
         return VG_OK;

@@ -400,6 +400,7 @@ class ZeroShotDetector:
             else:
                 labels, probs = p.cluster(X)
             fs.set_clusters(*pack_clusters(labels, probs, p.prob_threshold))     # lidar_frame.py:154-248
+            self._box_prefetch.pop(fnr, None)                                    # (requests sent for the frame's previous clusters)
             ent = self._dev[fnr].get('ent')
             if ent is not None and fs.n_detections:
                 fs.static = static_from_entropy(ent.cpu().numpy(), fs.index, fs.seg_off,
@@ -429,6 +430,7 @@ class ZeroShotDetector:
         valid, _ = p.filter(X, d_index, d_seg, fs.ground_plane_model_ref)
         fs.valid = valid.cpu().numpy().astype(bool)
         fs.filtered = True
+        self._box_prefetch.pop(fnr, None)                                        # (a request keyed on the previous valid rows)
 
     def filter_detections(self, **kwargs):
         force = kwargs.get('force', False)
@@ -497,6 +499,8 @@ class ZeroShotDetector:
             for fs in self.lidar_frame_list:
                 fs.boxes = None
             self._fit_boxes_tracked(valid_only)
+            self._box_prefetch.clear()
+            self._host_X.clear()                         # host copies of the frames' points: only this stage and the prefetch read them
             self.sync_lidar_frames()
             return
         jobs = []
@@ -516,6 +520,8 @@ class ZeroShotDetector:
             jobs.append((fs, rows, self._boxes_of_rows(fnr, rows, X)))
         for fs, rows, fut in jobs:
             fs.boxes[rows] = fut.result()
+        self._box_prefetch.clear()
+        self._host_X.clear()
         self.sync_lidar_frames()
 
     def _boxes_of_rows(self, fnr, rows, X):
