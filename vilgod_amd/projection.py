@@ -108,7 +108,10 @@ class RealisticProjection:
                 assert out_buf.dtype == torch.float16 and out_buf.shape[1] == 768 and out_buf.shape[0] >= rows
                 result = out_buf
             else:
-                result = torch.zeros((rows, 768), dtype=torch.float16, device=dev)
+                # the renderer writes every one of the n * 196 patch rows: only the <= 255 rows of tile padding need zeros
+                # (a zero-fill of the whole buffer was 96 MB per frame)
+                result = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+                result[n * 196:].zero_()
         else:
             result = torch.empty((n, 110, 110), dtype=torch.float32, device=dev)
         if n_clusters == 0 or ptot == 0:
