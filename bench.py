@@ -18,7 +18,9 @@ frames (north_star).  The run is a real stream: every one of the W + K frames of
 cycling -- a new crop count almost every frame), handed over as a pinned HOST buffer (SURVEY 8d's clock: "raw points resident in
 host pinned memory" to "result dict on the host"; the copy to HBM is queued inside the timed region; `--input resident` uploads
 the K clouds before the clock starts instead and is reported as the `resident_input` block).  Each rank keeps `--inflight` frames
-(default 6) in flight on worker threads with their own streams and handles.  The ViT runs as plain stream launches (default) or
+(default 6) in flight on worker threads with their own streams and handles.  Before the W warm-up steps one untimed set-up block
+of min(K, 24) further distinct clouds brings the caching allocator to the steady state of a long-running stream (config.setup_frames;
+not steps of the metric).  The ViT runs as plain stream launches (default) or
 as captured hipGraphs per crop-count bucket (`--vit-graph`; captures then happen INSIDE the timed region and are counted in
 `config.graphs_captured`).  The K timed frames include filling and draining the pipeline (small K therefore reads a little
 lower: the driver's K = 20 run vs the default K = 96).
@@ -32,6 +34,7 @@ The JSON line also carries
 and, as information beside the metric (N=1 only; each block reports its own failure instead of costing the metric line):
   box_modes            the same frames with box_mode 'fast' (GPU hull, all edges) next to the default 'reference' mode
   resident_input       the same frames uploaded to HBM before the clock starts (what rounds 1-2 quoted as the metric)
+  resid16              the same frames with the fp16 residual stream of the reference's own GPU run (VG_VIT_RESID16=1) beside the default fp32 stream
   hipgraph_loop        the same frames with the ViT as captured hipGraphs (per crop-count bucket, LRU-bounded) next to the default plain launches
   views6, dense200k    BASELINE configs 3 (6 rendered views) and 5 (200k points, ~120 objects) shapes
   default_config_mode  the reference's default stage order -- entropy scores + two-frame clustering -- as a library call
@@ -295,6 +298,19 @@ def main():
         dist.barrier()
 
     pipe.new_sequence()
+    # Set-up before the warm-up (not steps of the metric; distinct clouds of their own): one block of the timed block's length
+    # brings torch's caching allocator to the steady state of a long-running stream.  Every frame in flight allocates its
+    # temporaries (non-ground points, packed clusters, crops' patch rows, ViT workspace ...) through it, and the first block of a
+    # process that needs a new size pays a device-synchronising hipMalloc inside the timed region: measured on K = 20, the metric's
+    # block -- the first of the process -- read 55.4 frames/s while every later block of the same run (same frames, other pipeline
+    # objects) read 57.8-59.2.  Model set-up like weight loading; reported as config.setup_frames.
+    n_setup = 0 if args.stage_times else min(K, 24)
+    if n_setup:
+        setup_frames = [torch.from_numpy(synthetic.make_frame(900_001 + rank * 100_000 + i, args.points, n_objects=args.objects)).pin_memory()
+                        for i in range(n_setup)]
+        run_steps(pipe, 0, n_setup, 0, src=setup_frames)
+        del setup_frames
+        pipe.new_sequence()
     run_steps(pipe, 0, W, 0)                                   # warm-up, also builds the worker handles
     comm_warmup()
     stage = {}
@@ -348,6 +364,7 @@ def main():
                              f'{world}-way in contiguous blocks' + (f', ground state by {args.ground_handoff}' if world > 1 else '') +
                              ', one all-gather of the score matrices'),
                 'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,
+                'setup_frames': n_setup,
                 'distinct_frames': len({id(f) for f in frames[W:W + K]}), 'distinct_crop_counts': len({int(p.shape[0]) for _, _, p in outs}),
                 'input': ('pinned host buffers, H2D copy inside the timed region' if args.input == 'host' else 'resident in HBM before the timed region'),
                 'vit_launch': 'captured hipGraphs per crop-count bucket' if args.vit_graph else 'plain stream launches',
@@ -413,6 +430,13 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             other_shape.graphs = {k: v - g0[k] for k, v in graph_stats(p2).items()}
+            # this block's pipeline (six workers' cluster / ViT handles: gigabytes of device buffers) is released HERE, outside any
+            # timed region: left to the garbage collector its hipFree calls (device-synchronising) landed inside a later block's clock
+            p2._workers = None
+            del p2, fr
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
             return dt, res
 
         if extras:
@@ -480,6 +504,49 @@ def main():
                         'note': "view direction angle of a cluster (pointcloud_utils.py:397): 'device' = correctly rounded atan2 on the GPU, 'reference' = "
                                 "this host's float32 np.arctan2 of the device medians (one [C,3] read-back per frame); they differ by <= 1 ulp"}
             block('angle_modes', angle_modes)
+
+            def resid16():
+                # upstream's own GPU arithmetic (model.py:375-396 converts the whole tower to fp16: the residual stream too) as a
+                # documented mode beside the default (fp32 residual stream, fp16 GEMM operands): a second tower handle created with
+                # VG_VIT_RESID16=1, the same frames
+                from vilgod_amd.clip_wrapper import ClipWrapper
+                os.environ['VG_VIT_RESID16'] = '1'
+                try:
+                    clip16 = ClipWrapper(pipe._clip_cfg, '/nonexistent', device=dev, dtype=args.dtype)
+                finally:
+                    os.environ.pop('VG_VIT_RESID16', None)
+                p2 = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=args.views, max_points=args.points + 1024, clip_model_path='/nonexistent',
+                                         clip=clip16, box_mode=args.box_mode, vit_graph=args.vit_graph, angle_mode=args.angle_mode)
+                fr = [f.to(dev) for f in host_frames] if args.input == 'resident' else host_frames
+                p2.new_sequence()
+                p2.process_frames(fr[:W], [poses[i] for i in range(W)], poses[0], n_workers=inflight)
+                p2.new_sequence()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = p2.process_frames(fr[W:W + K], [poses[W + i] for i in range(K)], poses[0], n_workers=inflight)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                p2._workers = None
+                del p2, fr, clip16
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                n = flips = 0
+                worst = 0.0
+                for a, b in zip(outs, res):
+                    if a[2].shape == b[2].shape and a[2].numel():
+                        worst = max(worst, float((a[2] - b[2]).abs().max()))
+                    if np.array_equal(a[0].valid, b[0].valid) and pipe.cls_key in a[0].cls and pipe.cls_key in b[0].cls:
+                        rows = np.flatnonzero(a[0].valid)
+                        n += len(rows)
+                        flips += int(sum(str(a[0].cls[pipe.cls_key]['name'][r]) != str(b[0].cls[pipe.cls_key]['name'][r]) for r in rows))
+                return {'fp32_residual_stream': {'value': round(value, 3), 'unit': 'frames/s'},
+                        'fp16_residual_stream': {'value': round(K / dt, 3), 'unit': 'frames/s'},
+                        'max_abs_probability_difference': round(worst, 5), 'clusters_compared': n, 'class_names_that_differ': flips,
+                        'note': 'VG_VIT_RESID16=1 at vg_vit_create: the residual stream in fp16 like the reference\'s CUDA run (EPI_BIAS_RESID_H epilogue: '
+                                'half the read-modify-write bytes of out_proj / c_proj, no separate fp16 copy); NOT the default: against the fp32 oracle its '
+                                'probability error is ~2.7e-3 (fp32 stream: ~6e-4), north_star asks for 1e-3'}
+            block('resid16', resid16)
             block('views6', shape_block(args.points, args.objects, 6, 'BASELINE config 3 as written: 150k points, 6 rendered views'))
             block('dense200k', shape_block(200_000, 120, args.views, 'BASELINE config 5 shape: dense 200k-point frames, ~120 objects, fp16 ViT'))
         if world == 1 and not args.no_sequence_pass and not args.stage_times:
