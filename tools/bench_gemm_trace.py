@@ -15,10 +15,10 @@ for N, K, ldc in [(2304, 768, 2560), (3072, 768, 3072), (768, 3072, 768)]:
         for _ in range(int(os.environ.get('REPS', '3'))):
             check(lib.vg_gemm_trace(var, ptr(X), ptr(W), ptr(b), ptr(C), ptr(tr), M, N, K, ldc, stream_ptr()))
         torch.cuda.synchronize()
-        nk = K // (64 if var in (32, 33) else 32)
+        nk = K // (64 if var in (32, 33, 40) else 32)
         if True:
             t = tr.view(-1, 8).cpu().double(); t = t[t[:, 7] > 0]
-            for g in (0, 1):
+            for g in ((0,) if var == 40 else (0, 1)):
                 tg = t[(t[:, 6] >= 4) == bool(g)]
                 main, wait, bar, epi, load, mma = tg.mean(0).tolist()[:6]; ghz = ((tg[:, 0] + tg[:, 3]) / tg[:, 7]).median().item() * 0.1
                 print(f'N={N} K={K} var={var} group {g}: per K-step: load {load/nk:5.0f}  wait {wait/nk:5.0f}  barriers {bar/nk:5.0f}  '

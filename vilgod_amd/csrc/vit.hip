@@ -1099,6 +1099,7 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 #define VG_PROF_MAX 4096
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
+    bool gemm_x2 = getenv("VG_GEMM_X2") ? atoi(getenv("VG_GEMM_X2")) != 0 : false;   // projection GEMMs by k_gemm_f16_x2 (two workgroups per CU)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1644,6 +1645,316 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm_f16_x2: TWO independent 4-wave workgroups per CU, each a 128 x 256 tile (one "group" of k_gemm_f16_pp64).
+// Why: in k_gemm_f16_pp64 the one workgroup that owns a CU reaches its epilogue with all eight waves at once, and the matrix pipe
+// idles while the tile is written -- 3.5 of the 14.7 ms of projection GEMMs per frame; the out_proj /
+// c_proj epilogues (fp32 residual read-modify-write + fp16 copy = 10 B per element) are HBM-bound on top, all CUs at the same time.
+// Two workgroups that share a CU's SIMDs (2 waves per SIMD, as before) drift apart: one's epilogue runs under the other's MFMAs.
+//   * 160 KB of LDS do not hold two K-step-64 rings of X AND W.  In a 4-wave workgroup every W row is read by exactly ONE wave
+//     (wave wn owns columns [64 wn, +64)), so W does not need LDS at all: each lane loads its own MFMA fragments from global
+//     memory (L2-resident weights; 16 rows x 64 B per instruction), one K-tile ahead, straight into registers.  X (read by all four
+//     waves) goes through a 3-stage LDS ring (3 x 16 KB) filled by LDS-DMA as before.  96 KB per CU.
+//   * The fragment reads are software-pipelined across K-tiles: every MFMA group is followed by the ds_read of a fragment the
+//     group after next needs, so the only point a wave waits at is the one barrier per K-tile (placed after the last read of
+//     the current stage; the other workgroup's waves have the pipe meanwhile).
+//   * Epilogue without workgroup barriers: a wave transposes its own 128 x 64 block through a private 12 KB slice of the (now
+//     idle) ring, 64 (fp16) or 32 (fp32) rows at a time, and writes full 128 / 256-byte row segments.
+//   * Folded LayerNorm: the partial row statistics are per 64 columns (one wave's share of a row) instead of per 256, so no
+//     exchange between waves; the consumer merges K / 64 partials (Chan et al.) instead of K / 256.
+#define X2_STAGE 16384
+#define X2_NST 4
+#define X2_LN_MAXP 16                 // partials per row the consumer merges (width <= 1024)
+__device__ __forceinline__ float row16_sum(float v) {             // sum over the 16 lanes of a DPP row, in every lane of it
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+template <int EPI, int LN = 0, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void k_gemm_f16_x2(const f16* __restrict__ X, const f16* __restrict__ Wt,
+                                                        const float* __restrict__ bias, void* __restrict__ Cout,
+                                                        float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
+                                                        const float* __restrict__ ln_c1, LnPartial* __restrict__ ln_stats,
+                                                        f16* __restrict__ ln_x16, long long* __restrict__ trace = nullptr) {
+    constexpr int BM = 128, BN = 256, TM = 8, TN = 4;
+    long long tr_entry = 0, tr_w0 = 0, tr_t0 = 0, tr_main = 0, tr_wait = 0, tr_bar = 0;
+    if (TRACE) { tr_entry = clock64(); tr_w0 = wall_clock64(); }
+    __shared__ __attribute__((aligned(16))) char smem[X2_NST * X2_STAGE + 1024];
+    const int tid = threadIdx.x, wn = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int ntm = M / BM;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = ntm * cw;
+    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // Addressing through buffer descriptors: SGPR base + one VGPR offset per operand + an SGPR offset that carries everything
+    // wave-uniform (tile, K-tile, piece / fragment row).  With 64-bit pointers per piece and fragment row the loop carried 16 VGPRs
+    // of addresses -- and spilled them.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((size_t)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)((size_t)N * K * 2), 0x00020000);
+    // X pieces: 8 rows x 128 B per wave instruction; lane -> row l >> 3, chunk slot l & 7 (source chunk = slot ^ ((row >> 1) & 7);
+    // rows 8 i + prow: the swizzle term alternates between two values with i)
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int xv0 = ((wn * 32 + prow) * K + (pslot ^ (prow >> 1)) * 8) * 2;       // odd pieces: ^ 64 (chunk ^ 4)
+    auto issue_x = [&](int kt) {
+        char* d = smem + (kt % X2_NST) * X2_STAGE + (wn * 32) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(d + i * 1024), 16, (i & 1) ? (xv0 ^ 64) : xv0,
+                                                     ((m0 + 8 * i) * K + kt * 64) * 2, 0, 0);
+    };
+    const int r15 = lane & 15, q4 = lane >> 4;
+    // W fragments of this wave's 64 columns: row n0 + 64 wn + 16 ni + r15, halves [8 q4, +8) of each k32 sub-step
+    const int wv = (r15 * K + q4 * 8) * 2;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int swz = (r15 >> 1) & 7;
+    const int xo0 = r15 * 128 + ((q4 ^ swz) << 4), xo1 = r15 * 128 + (((4 + q4) ^ swz) << 4);
+    const int np = K / 64;                         // host guarantees K % 256 == 0 (np a multiple of 4)
+
+    // folded LayerNorm, consumer side: thread t < 128 merges the K / 64 partials of tile row t into (mean, rstd)
+    float2 ln_row = make_float2(0.f, 0.f);
+    if (LN == 1 && tid < BM) {
+        const int nst = K >> 6;
+        const LnPartial* sp = ln_stats + (size_t)(m0 + tid) * nst;
+        LnPartial pt[X2_LN_MAXP];
+#pragma unroll
+        for (int u = 0; u < X2_LN_MAXP; ++u) pt[u] = u < nst ? sp[u] : LnPartial{0.f, 0.f};
+        float ms = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < X2_LN_MAXP; ++u) { ms += pt[u].mean; m2 += pt[u].m2; }
+        const float mean = ms / (float)nst;
+        float dev = 0.f;
+#pragma unroll
+        for (int u = 0; u < X2_LN_MAXP; ++u) if (u < nst) { const float d = pt[u].mean - mean; dev += d * d; }
+        ln_row = make_float2(mean, rsqrtf((m2 + 64.f * dev) / (float)K + 1e-5f));
+    }
+
+    // W fragments: two pairs of sets (the K-tile in work, the next one).  Both k32 halves of a W row -- one 128-byte line -- are
+    // requested back to back: requested half a K-tile apart the line had left the L1 in between and came from L2 twice
+    f16x8 wa0[TN], wa1[TN], wb0[TN], wb1[TN], fb[TM];
+    auto load_w = [&](int kt, f16x8 (&a)[TN], f16x8 (&a2)[TN]) {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            a[ni] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wv, ((n0 + wn * 64 + ni * 16) * K + kt * 64) * 2, 0));
+            a2[ni] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wv, ((n0 + wn * 64 + ni * 16) * K + kt * 64 + 32) * 2, 0));
+        }
+    };
+    issue_x(0);
+    issue_x(1);
+    load_w(0, wa0, wa1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < TM - 2; ++mi) fb[mi] = *(const f16x8*)(smem + xo0 + mi * 2048);
+
+    // one K-tile: wc0 / wc1 hold its two sub-steps' W fragments, wn0 / wn1 receive the next tile's.  fb[0..5] hold the first
+    // sub-step's X fragments of rows 0..95 on entry, and the next tile's on exit.  (stage and the two "is there a next / next but
+    // one tile" flags are compile-time: the steady-state body has no branches and every LDS offset is an immediate)
+    auto ktile = [&](auto stage_c, auto more_c, auto more2_c, int j, f16x8 (&wc0)[TN], f16x8 (&wc1)[TN], f16x8 (&wn0)[TN], f16x8 (&wn1)[TN]) {
+        constexpr int STG = decltype(stage_c)::value;
+        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+        const char* xb = smem + STG * X2_STAGE;
+        const char* xnb = smem + ((STG + 1) % X2_NST) * X2_STAGE;
+        if (more) load_w(j + 1, wn0, wn1);
+        if (more2) {
+            char* d = smem + ((STG + 2) % X2_NST) * X2_STAGE + (wn * 32) * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int xv = xv0;
+                if (i & 1) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(xv) : "v"(xv0));      // (not kept in a register across the loop)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(d + i * 1024), 16, xv, ((m0 + 8 * i) * K + (j + 2) * 64) * 2, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc0[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+            if (mi < 2) fb[TM - 2 + mi] = *(const f16x8*)(xb + xo0 + (TM - 2 + mi) * 2048);
+            else fb[mi - 2] = *(const f16x8*)(xb + xo1 + (mi - 2) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc1[ni], fb[mi], acc[ni][mi], 0, 0, 0);
+            if (mi < 2) fb[TM - 2 + mi] = *(const f16x8*)(xb + xo1 + (TM - 2 + mi) * 2048);
+            else if (more) fb[mi - 2] = *(const f16x8*)(xnb + xo0 + (mi - 2) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mi == 1 && more) {
+                // the last read of this stage is out; the next stage's pieces (issued one K-tile ago) must have landed, for every
+                // wave.  Still in flight may be this tile's 8 W loads and 4 X pieces (none for the last but one tile)
+                __builtin_amdgcn_s_setprio(0);
+                long long c0 = 0, c1 = 0;
+                if (TRACE) c0 = clock64();
+                if (more2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                if (TRACE) c1 = clock64();
+                __builtin_amdgcn_s_barrier();
+                if (TRACE) { const long long c2 = clock64(); tr_wait += c1 - c0; tr_bar += c2 - c1; }
+                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using std::integral_constant;
+    constexpr integral_constant<int, 0> S0; constexpr integral_constant<int, 1> S1; constexpr integral_constant<int, 2> S2; constexpr integral_constant<int, 3> S3;
+    constexpr integral_constant<bool, true> YES; constexpr integral_constant<bool, false> NO;
+    if (TRACE) tr_t0 = clock64();
+    int j = 0;
+    for (; j < np - 4; j += 4) {                   // host guarantees np % 4 == 0
+        ktile(S0, YES, YES, j, wa0, wa1, wb0, wb1);
+        ktile(S1, YES, YES, j + 1, wb0, wb1, wa0, wa1);
+        ktile(S2, YES, YES, j + 2, wa0, wa1, wb0, wb1);
+        ktile(S3, YES, YES, j + 3, wb0, wb1, wa0, wa1);
+    }
+    ktile(S0, YES, YES, j, wa0, wa1, wb0, wb1);
+    ktile(S1, YES, YES, j + 1, wb0, wb1, wa0, wa1);
+    ktile(S2, YES, NO, j + 2, wa0, wa1, wb0, wb1);
+    ktile(S3, NO, NO, j + 3, wb0, wb1, wa0, wa1);
+    if (TRACE) tr_main = clock64() - tr_t0;
+    __syncthreads();                               // every wave is done with the ring: its slices become the waves' scratch
+    char* sc = smem + wn * 16384;
+    // (the epilogue's per-lane values are derived again from an opaque copy of the lane id: nothing of it lives through the K loop)
+    int lane_e = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_e));
+    const int r15e = lane_e & 15, q4e = lane_e >> 4;
+
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        float ln_mean[TM], ln_rstd[TM];
+        if (LN == 1) {
+            float2* lsm = (float2*)(smem + X2_NST * X2_STAGE);
+            if (tid < BM) lsm[tid] = ln_row;
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const float2 t2 = lsm[mi * 16 + r15e];
+                ln_mean[mi] = t2.x; ln_rstd[mi] = t2.y;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {              // rows [64 p, +64)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int nloc = wn * 64 + ni * 16 + 4 * q4e;
+                const float4 b4 = *(const float4*)(bias + n0 + nloc);
+                float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (LN == 1) c4 = *(const float4*)(ln_c1 + n0 + nloc);
+                const int ch = ni * 2 + (q4e >> 1);
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) {
+                    const int mi = p * 4 + mq, row = mq * 16 + r15e;
+                    float v[4] = {acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w};
+                    if (LN == 1) {
+                        v[0] = ln_rstd[mi] * (acc[ni][mi][0] - ln_mean[mi] * c4.x) + b4.x;
+                        v[1] = ln_rstd[mi] * (acc[ni][mi][1] - ln_mean[mi] * c4.y) + b4.y;
+                        v[2] = ln_rstd[mi] * (acc[ni][mi][2] - ln_mean[mi] * c4.z) + b4.z;
+                        v[3] = ln_rstd[mi] * (acc[ni][mi][3] - ln_mean[mi] * c4.w) + b4.w;
+                    }
+                    f16x4 h4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = v[e];
+                        if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
+                        h4[e] = (f16)x;
+                    }
+                    *(f16x4*)(sc + row * 128 + ((ch ^ (row & 7)) << 4) + (q4e & 1) * 8) = h4;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane_e >> 3), c = lane_e & 7;
+                const f16x8 v = *(const f16x8*)(sc + row * 128 + ((c ^ (row & 7)) << 4));
+                *(f16x8*)((f16*)Cout + (size_t)(m0 + p * 64 + row) * ldc + n0 + wn * 64 + c * 8) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {              // rows [32 p, +32)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int nloc = wn * 64 + ni * 16 + 4 * q4e;
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
+                const int ch = ni * 4 + q4e;
+#pragma unroll
+                for (int mq = 0; mq < 2; ++mq) {
+                    const int mi = p * 2 + mq, row = mq * 16 + r15e;
+                    *(float4*)(sc + row * 256 + ((ch ^ (row & 15)) << 4)) =
+                        make_float4(acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w);
+                }
+            }
+            const int c = lane_e & 15;
+            // eight residual loads in flight before the first store
+            float4 x4[8];
+            if (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + (lane_e >> 4);
+                    x4[it] = *(const float4*)(resid + (size_t)(m0 + p * 32 + row) * ldc + n0 + wn * 64 + c * 4);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane_e >> 4);
+                float4 v = *(const float4*)(sc + row * 256 + ((c ^ (row & 15)) << 4));
+                const size_t off = (size_t)(m0 + p * 32 + row) * ldc + n0 + wn * 64 + c * 4;
+                if (EPI == EPI_BIAS_RESID) {
+                    v.x += x4[it].x; v.y += x4[it].y; v.z += x4[it].z; v.w += x4[it].w;
+                    *(float4*)(resid + off) = v;
+                    if (LN == 2) {
+                        // the 16 lanes of a DPP row hold this wave's 64 columns of the row: fp16 copy for the next GEMM + partial statistics
+                        const f16x4 h4 = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                        *(f16x4*)(ln_x16 + off) = h4;
+                        const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+                        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+                        const float m2 = row16_sum((a * a + b * b) + (cc * cc + d * d));
+                        if (c == 0) ln_stats[(size_t)(m0 + p * 32 + row) * (N >> 6) + (n0 >> 6) + wn] = LnPartial{mean, m2};
+                    }
+                } else {
+                    *(float4*)((float*)Cout + off) = v;
+                }
+            }
+        }
+    }
+    if (TRACE && (tid & 63) == 0 && trace) {
+        long long* o = trace + ((size_t)blockIdx.x * 4 + wn) * 8;
+        const long long t2 = clock64();
+        o[0] = tr_main; o[1] = tr_wait; o[2] = tr_bar; o[3] = (t2 - tr_entry) - tr_main; o[4] = 0; o[5] = tr_main - tr_wait - tr_bar; o[6] = wn;
+        o[7] = wall_clock64() - tr_w0;
+    }
+}
+
+template <int EPI, int LN = 0, bool TRACE = false>
+static int launch_gemm_x2(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
+                          hipStream_t st, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr, f16* ln_x16 = nullptr,
+                          long long* trace = nullptr) {
+    if (M % 128 || N % 256 || K % 256) return VG_ERR_ARG;
+    if (LN == 1 && (K / 64 > X2_LN_MAXP || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
+    if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
+    const int ntn = N / 256;
+    int cwt = gemm_chunk_tiles_256(ntn);
+    if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep
+    hipLaunchKernelGGL((k_gemm_f16_x2<EPI, LN, TRACE>), dim3((M / 128) * ntn), dim3(256), 0, st, (const f16*)X, (const f16*)Wt, bias, C, resid,
+                       M, N, K, ldc, cwt, ln_c1, ln_stats, ln_x16, trace);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
 template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
@@ -1742,6 +2053,9 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                     if ((persist_mask >> EPI) & 1) return launch_gemm_pp64<EPI, false, true>(X, Wt, bias, C, resid, M, N, K, ldc, st);
                 }
 #endif
+                if (v->gemm_x2 && K % 256 == 0 && (LN != 1 || K / 64 <= X2_LN_MAXP))
+                    return launch_gemm_x2<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
+                if (v->gemm_x2 && LN != 0) return VG_ERR_ARG;       // (the two kernels keep different partial statistics)
                 return launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
             }
         }
@@ -1863,6 +2177,9 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
     const char* fold = getenv("VG_VIT_LN_FOLD");
     v->ln_fold = dtype == 1 && width % 256 == 0 && !v->resid_h && !getenv("VG_GEMM_V4") && !(fold && atoi(fold) == 0);
+    // k_gemm_f16_x2 serves K % 256 == 0 and merges at most X2_LN_MAXP partial statistics per row: a tower uses it for all of its
+    // projection GEMMs or for none (the two kernels keep the folded LayerNorm's partials at different granularity)
+    if (v->gemm_x2 && !(dtype == 1 && width % 256 == 0 && width / 64 <= X2_LN_MAXP && !v->resid_h && !getenv("VG_GEMM_V4"))) v->gemm_x2 = false;
     *out = v;
     return VG_OK;
 }
@@ -1926,7 +2243,7 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops) {
                 + Mp * 4 * W * es     // mlp
                 + Pp * Kp * es        // patches
                 + Pp * W * 4;         // patch-embed output (f32)
-    if (v->ln_fold) b += Mp * W * 2 + Mp * (W / 256) * 8;      // fp16 copy of the residual + per-row partial statistics (folded LayerNorm)
+    if (v->ln_fold) b += Mp * W * 2 + Mp * (W / 64) * 8;      // fp16 copy of the residual + per-row partial statistics (folded LayerNorm)
     return b + 1024;
 }
 
@@ -2134,6 +2451,7 @@ int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bia
         case 33: return launch_gemm_pp64<EPI_BIAS_GELU, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
         case 34: return launch_gemm_pp64<EPI_BIAS_RESID, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
         case 35: return launch_gemm_pp64<EPI_BIAS_RESID_H, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
+        case 40: return launch_gemm_x2<EPI_BIAS, 0, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr, nullptr, nullptr, (long long*)d_trace);
         default: return VG_ERR_ARG; }
     VG_LAUNCH_CHECK();
     return VG_OK;
