@@ -38,3 +38,11 @@ def test_cluster_kernels_hold_no_unencodable_64bit_literals():
     SGPRs, so its assembly is scanned here; `python -m vilgod_amd.build --check-isa` scans every source (vit.hip takes a minute)."""
     from vilgod_amd import build
     assert build.check_isa(sources=['cluster.hip']) == []
+
+
+def test_projection_gemm_instantiations_do_not_spill():
+    """Every instantiation of k_gemm_f16_pp64 in the product library fits its 256-register budget (no scratch).  Round 3: an
+    experimental persistent instantiation that spilled eight registers returned wrong values for the rows of one accumulator
+    register; spills in this kernel are treated as build errors since."""
+    from vilgod_amd import build
+    assert build.check_scratch('vit.hip', 'k_gemm_f16_pp64') == []

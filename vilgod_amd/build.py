@@ -92,6 +92,27 @@ def build(force=False, verbose=True, dev=False):
     return LIB
 
 
+def check_scratch(source='vit.hip', name_part='k_gemm_f16_pp64'):
+    """Kernels of `source` whose mangled name contains `name_part` and that use scratch memory (register spills) -> [(kernel, bytes)].
+    The projection GEMM runs with 128 accumulator registers per wave and a 256-register budget: an instantiation that spills keeps
+    its spill slots busy inside the tile loop, and one that did (round 3) returned wrong values."""
+    import re
+    import tempfile
+    hipcc = _hipcc()
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, source + '.s')
+        cmd = [hipcc] + [c for c in COMMON if c != '-fPIC'] + SOURCES[source] + ['-S', '--cuda-device-only', os.path.join(CSRC, source), '-o', out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc -S failed for {source}:\n{r.stderr}')
+        text = open(out).read()
+    found = []
+    for m in re.finditer(r'\.set (\S+)\.private_seg_size, (\d+)', text):
+        if name_part in m.group(1) and int(m.group(2)) > 0:
+            found.append((m.group(1), int(m.group(2))))
+    return found
+
+
 def check_isa(sources=None, verbose=False):
     """Guard against a code-generation bug of this ROCm's gfx950 back end (found in round 3, csrc/cluster.hip ClGrid::inf): a
     wave-uniform 64-bit constant whose HIGH half is not zero -- `double x = INFINITY` kept in SGPRs -- can be materialised as
