@@ -68,6 +68,7 @@ struct vg_cluster {
     unsigned long long *d_best_w, *d_best_e;
     int *d_sel_a, *d_sel_b;
     unsigned long long *d_pt_w, *d_pt_key, *d_pt_d, *d_best_d;   // pt_d / best_d: squared pair distance (tie-break after w)
+    int4* d_aux;                          // per sorted point {core2 (2 words), component, 5th coordinate}: what a leaf scan needs next to spts
     double* d_pt_lb;                      // per point: a lower bound of the weight of ANY edge leaving its component (grows over the rounds)
     int* d_pt_b;
     int* d_counter;                       // [0] number of MST edges emitted
@@ -106,6 +107,26 @@ __device__ __forceinline__ void cl_cell_of(const ClGrid& g, double x, double y, 
 // cell_start is stored reversed (index NCODES - code) so that the "first point with code >= c" table is a
 // forward inclusive min-scan.
 __device__ __forceinline__ int cl_start(const int* __restrict__ cs, unsigned int code) { return cs[CL_NCODES - code]; }
+// The same table per coarser level l = 1 .. CL_LMAX, stored FORWARD and compact right behind the cell table: entry c of level l =
+// first sorted point whose code >> 3l is >= c (c = 0 .. NCODES >> 3l, the last one = n).  The eight children of a node (nine
+// consecutive entries: they include the node's own range) and the 64 grand-children of a block are then neighbours in memory,
+// where the cell table has them 4 * 8^l bytes apart (k_cl_levels fills them, 16 us per frame).
+__device__ __host__ __forceinline__ size_t cl_lvl_off(int l) {      // offset of level l (>= 1) behind the cell table
+    return ((size_t)CL_NCODES - ((size_t)CL_NCODES >> (3 * (l - 1)))) / 7 + (size_t)(l - 1);
+}
+#define CL_LVL_TOTAL (cl_lvl_off(CL_LMAX + 1))
+// first sorted point of node c (= code >> 3l) of level l; c + 1 gives the node's end
+__device__ __forceinline__ int cl_start_l(const int* __restrict__ cs, int l, unsigned int c) {
+    return l == 0 ? cs[CL_NCODES - c] : cs[(size_t)(CL_NCODES + 1) + cl_lvl_off(l) + c];
+}
+__global__ void k_cl_levels(int* __restrict__ cs) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= CL_LVL_TOTAL) return;
+    int l = 1;
+    while (l < CL_LMAX && idx >= cl_lvl_off(l + 1)) ++l;
+    const size_t c = idx - cl_lvl_off(l);
+    cs[(size_t)(CL_NCODES + 1) + idx] = cs[(size_t)CL_NCODES - (c << (3 * l))];
+}
 
 __global__ void k_cl_bbox(const float* __restrict__ pts, int n, int stride, ClGrid* g) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -292,7 +313,7 @@ __global__ void k_cl_e_up(int n, int l, const unsigned int* __restrict__ code_s,
     for (unsigned int ch = 0; ch < 8; ++ch) {
         const unsigned int ck = key * 8 + ch;
         const unsigned int c0 = ck << (3 * (l - 1));
-        if (cl_start(cs, c0) == cl_start(cs, c0 + (1u << (3 * (l - 1))))) continue;   // empty child: entry not written
+        if (cl_start_l(cs, l - 1, c0 >> (3 * (l - 1))) == cl_start_l(cs, l - 1, (c0 >> (3 * (l - 1))) + 1u)) continue;   // empty child: entry not written
         float a, b;
         cl_unpack_e(below[ck], a, b);
         mn = fminf(mn, a);
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             const double nb2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
             if (nb2 >= h[k]) continue;                                       // cannot lower the k-th distance (ALU only)
             const unsigned int c0 = cl_code(x << l, y << l, z << l);
-            const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
+            const int j0 = cl_start_l(cs, l, c0 >> (3 * l)), j1 = cl_start_l(cs, l, (c0 >> (3 * l)) + 1u);
             if (j0 == j1) continue;
             if (DIM >= 4 && l < CL_PUR_LEVELS && nb2 + cl_e_gap2(cell_e[cl_pur_off_fwd(l) + (c0 >> (3 * l))], qe) >= h[k]) continue;
             if (l == 0 || j1 - j0 <= CL_LEAF) {
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
             // empty octants -- most of them in LiDAR data -- are never pushed and never cost a pop with two dependent loads
             int bnd[9];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) bnd[c] = cl_start(cs, c0 + ((unsigned int)c << (3 * l1)));
+            for (int c = 0; c < 9; ++c) bnd[c] = cl_start_l(cs, l1, (c0 >> (3 * l1)) + (unsigned int)c);
             unsigned int occupied = 0;                    // bit c: child c holds points (static indices only: no scratch)
 #pragma unroll
             for (int c = 0; c < 8; ++c) occupied |= (bnd[c] != bnd[c + 1]) ? (1u << c) : 0u;
@@ -438,8 +459,8 @@ __global__ void k_cl_blocks(int n, const unsigned int* __restrict__ code_s, cons
 #pragma unroll
     for (int lv = 0; lv <= CLB_TOP + 2; ++lv) {
         const unsigned int kk = code >> (3 * lv);
-        j0[lv] = cl_start(cs, kk << (3 * lv));
-        j1[lv] = cl_start(cs, (kk + 1u) << (3 * lv));
+        j0[lv] = cl_start_l(cs, lv, kk);
+        j1[lv] = cl_start_l(cs, lv, kk + 1u);
     }
     // a node "fits" when it fills at most one wave and its surroundings are not crowded (the item's cost is its shell's
     // population); the work item of point i's branch is the coarsest node that fits (cells always do, in chunks of 64)
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(64) void k_cl_core_blk(const float4* __restrict__ s
     for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
         const int lv = (int)(entries[e] >> 30), i0 = (int)(entries[e] & 0x3FFFFFFFu);   // node level (0 .. 3), first query
         const unsigned int key = code_s[i0] >> (3 * lv);
-        const int iend = min(cl_start(cs, (key + 1u) << (3 * lv)), i0 + 64);
+        const int iend = min(cl_start_l(cs, lv, key + 1u), i0 + 64);
         const int i = i0 + lane;
         const bool active = i < iend;
         const float4 qf = spts[active ? i : i0];
@@ -506,8 +527,8 @@ __global__ __launch_bounds__(64) void k_cl_core_blk(const float4* __restrict__ s
             int j0 = 0, j1 = 0;
             if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (CL_NX >> lv) && ny < (CL_NY >> lv) && nz < (CL_NZ >> lv)) {
                 const unsigned int c0 = cl_code(nx << lv, ny << lv, nz << lv);
-                j0 = cl_start(cs, c0);
-                j1 = cl_start(cs, c0 + (1u << (3 * lv)));
+                j0 = cl_start_l(cs, lv, c0 >> (3 * lv));
+                j1 = cl_start_l(cs, lv, (c0 >> (3 * lv)) + 1u);
             }
             bnd[lane][0] = j0;
             bnd[lane][1] = j1;
@@ -682,8 +703,8 @@ __global__ __launch_bounds__(64) void k_cl_core_far(const float4* __restrict__ s
                 if (cl_box_d2(g, qx, qy, qz, L, nx, ny, nz) >= T) continue;
                 // the node's 64 level-(L-2) sub-nodes, one per lane (Morton order: consecutive ranges)
                 const unsigned int c0 = cl_code(nx << L, ny << L, nz << L);
-                const int s0 = cl_start(cs, c0 + ((unsigned int)lane << (3 * l2)));
-                const int s1 = cl_start(cs, c0 + ((unsigned int)(lane + 1) << (3 * l2)));
+                const int s0 = cl_start_l(cs, l2, (c0 >> (3 * l2)) + (unsigned int)lane);
+                const int s1 = cl_start_l(cs, l2, (c0 >> (3 * l2)) + (unsigned int)lane + 1u);
                 const int sx = (nx << 2) | (((lane >> 3) & 1) << 1) | (lane & 1);
                 const int sy = (ny << 2) | (((lane >> 4) & 1) << 1) | ((lane >> 1) & 1);
                 const int sz = (nz << 2) | (((lane >> 5) & 1) << 1) | ((lane >> 2) & 1);
@@ -715,9 +736,14 @@ __global__ __launch_bounds__(64) void k_cl_core_far(const float4* __restrict__ s
 #define CL_NONE 0xFFFFFFFFFFFFFFFFull   // 'no candidate' (sorts after every weight, +inf included)
 
 __global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter, int* __restrict__ pt_b,
-                            double* __restrict__ pt_lb) {
+                            double* __restrict__ pt_lb, const double* __restrict__ core2, const float* __restrict__ stt,
+                            int4* __restrict__ aux) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { comp[i] = i; pt_b[i] = -1; pt_lb[i] = 0.0; }
+    if (i < n) {
+        comp[i] = i; pt_b[i] = -1; pt_lb[i] = 0.0;
+        const long long cb = __double_as_longlong(core2[i]);
+        aux[i] = make_int4((int)(cb & 0xFFFFFFFFll), (int)(cb >> 32), i, stt ? __float_as_int(stt[i]) : 0);
+    }
     if (i == 0) counter[1] = 0;
     if (i == 0) counter[0] = 0;
 }
@@ -784,7 +810,7 @@ __global__ void k_cl_b_purity_up(int n, int l, const unsigned int* __restrict__ 
     for (unsigned int ch = 0; ch < 8; ++ch) {
         const unsigned int ck = key * 8 + ch;                          // child key at level l-1
         const unsigned int c0 = ck << (3 * (l - 1));
-        if (cl_start(cs, c0) == cl_start(cs, c0 + (1u << (3 * (l - 1))))) continue;   // empty child
+        if (cl_start_l(cs, l - 1, c0 >> (3 * (l - 1))) == cl_start_l(cs, l - 1, (c0 >> (3 * (l - 1))) + 1u)) continue;   // empty child
         const int p = below[ck];
         if (p < 0) { pure = -1; break; }
         if (pure == -2) pure = p;
@@ -804,6 +830,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      const int* __restrict__ cell_comp, const unsigned int* __restrict__ cell_e,
                                                      const int* __restrict__ perm,
                                                      const double* __restrict__ core2, const int* __restrict__ comp,
+                                                     const int4* __restrict__ aux,
                                                      unsigned long long* __restrict__ best_w,
                                                      unsigned long long* __restrict__ pt_w,
                                                      unsigned long long* __restrict__ pt_d,
@@ -831,7 +858,8 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     unsigned int* st = stack + threadIdx.x;
     const ClGrid g = *gp;
     const float4 qf = spts[a];
-    const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = DIM >= 5 ? (double)stt[a] : 0.0;
+    const float qtf = DIM >= 5 ? stt[a] : 0.f;
+    const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = qtf;
     if (!far_list && pt_b[a] >= 0) return;           // candidate of an earlier round still valid (k_cl_b_seed)
     const int ca = comp[a];
     const double core_a = core2[a];
@@ -856,8 +884,10 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     // win a tie) instead of scanning the whole ball for the smallest id.
     double bw = INFINITY;          // best weight found by this point
     double bd2 = INFINITY;         // ... and that edge's squared pair distance
-    double cbest = INFINITY;       // best weight published for the whole component (refreshed now and then)
-    unsigned long long bkey = ~0ull;
+    double cbest = INFINITY;       // best weight published for the whole component (read again now and then)
+    int since_refresh = 64;        // ... first with the first node
+    unsigned long long bkey = ~0ull;   // ... and its id key -- computed only when an exact (w, d2) tie asks for it, and at the end
+    bool bkey_valid = true;
     int bb = -1;
     if (far_list && pt_b[a] >= 0) {
         bw = __longlong_as_double((long long)pt_w[a]);
@@ -865,7 +895,15 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
         bkey = pt_key[a];
         bb = pt_b[a];
     }
-    int since_refresh = 64;        // the component's published bound is read before the first node
+    // The slowest WAVE sets the launch time (1 234 waves on 1 024 SIMDs: nothing else hides a wave's stalls), and a wave pays for
+    // whatever any of its lanes does (per-thread stamps, round 3: the median wave of round 1 runs 180 us in which its slowest
+    // lane waits 6 us for node reads and spends 15-45 us in leaf scans -- the rest is other lanes' scans).  Hence:
+    //  * a node costs ONE memory round trip: the ranges of its eight children (nine consecutive entries of the level below: they
+    //    include the node's own range), its purity entry, its 4th-coordinate range and -- every 8th node and after a leaf scan --
+    //    the component's published bound are requested together;
+    //  * a leaf scan loads sixteen points per trip, each as two 16-byte records (coordinates; core distance, component, 5th
+    //    coordinate): no second trip for the survivors' core distances, none for ids (read only on an exact tie);
+    //  * a point of the own component, or farther than the best edge so far, is dropped by a float32 screen.
     const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
     const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
     for (int rr = 0; rr < nrx * nry; ++rr) {
@@ -882,62 +920,94 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             const double nd2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
             const double lb = fmax(lb_a, nd2);
             if (lb > bw || lb > cbest || (lb == bw && nd2 > bd2)) continue;
-            const unsigned int c0 = cl_code(x << l, y << l, z << l);
-            const int j0 = cl_start(cs, c0), j1 = cl_start(cs, c0 + (1u << (3 * l)));
+            const unsigned int c = cl_code(x << l, y << l, z << l) >> (3 * l);      // the node's number at its level
+            // ---- the node's reads, all in flight together ----
+            int bnd[9];
+            {
+                // children ranges: level l - 1, entries 8c .. 8c + 8 (cells: the reversed table); a cell reads its own two ends
+                const long long base = l == 0 ? (long long)CL_NCODES - c
+                                     : l == 1 ? (long long)CL_NCODES - 8ll * c
+                                              : (long long)(CL_NCODES + 1) + (long long)cl_lvl_off(l - 1) + 8ll * c;
+                const long long dir = l <= 1 ? -1 : 1;
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    long long at = base + dir * u;
+                    bnd[u] = cs[at < 0 ? 0 : at];
+                }
+            }
+            const bool has_pur = l < CL_PUR_LEVELS;
+            const size_t po = has_pur ? cl_pur_off(l) + c : 0;
+            const int pure = cell_comp[po];
+            const unsigned int erange = DIM >= 4 ? cell_e[po] : 0u;
+            // (the bound: in a late round a whole frame's threads belong to two or three components, and a read per node queues up
+            // behind the atomics on those few words)
+            const bool refresh = ++since_refresh >= 8;
+            unsigned long long cb = 0;
+            if (refresh) { cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); since_refresh = 0; }
+            // ---- use them ----
+            const int j0 = bnd[0], j1 = l == 0 ? bnd[1] : bnd[8];
+            if (refresh) cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
+            if (lb_a > cbest) { sp = 0; rr = nrx * nry; break; }      // this point can no longer win: stop
             if (j0 == j1) continue;
-            if (l < CL_PUR_LEVELS && cell_comp[cl_pur_off(l) + (c0 >> (3 * l))] == ca) continue;   // all ours
-            if (DIM >= 4 && l < CL_PUR_LEVELS) {
-                const double ed2 = nd2 + cl_e_gap2(cell_e[cl_pur_off(l) + (c0 >> (3 * l))], qe);
+            if (has_pur && pure == ca) continue;         // all ours
+            if (DIM >= 4 && has_pur) {
+                const double ed2 = nd2 + cl_e_gap2(erange, qe);
                 const double elb = fmax(lb_a, ed2);
                 if (elb > bw || elb > cbest || (elb == bw && ed2 > bd2)) continue;
             }
             if (l == 0 || j1 - j0 <= CL_LEAF) {
                 bool improved = false;
                 scanned += j1 - j0;
-                // eight points per trip: their component ids and coordinates are loaded together (independent loads in
-                // flight), the slowest lane of a wave sets the kernel time and a one-point-per-trip loop is pure latency
-                for (int jb = j0; jb < j1; jb += 8) {
-                    int cj[8];
-                    float4 pj[8];
+                // the float64 distance of the (exactly converted) float32 coordinates differs from the float32 evaluation by a few
+                // ulp, the threshold carries a 1e-5 margin: a point the screen drops has d2 > bw and could neither win nor tie
+                float thr = (float)bw * 1.00001f + 1e-30f;               // (float)(+inf) stays +inf
+                for (int jb = j0; jb < j1; jb += 16) {
+                    float4 pj[16];
+                    int4 xj[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 16; ++u) {
                         const int j = jb + u < j1 ? jb + u : j1 - 1;
-                        cj[u] = comp[j];
                         pj[u] = spts[j];
+                        xj[u] = aux[j];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 16; ++u) {
+                        const float fx = qf.x - pj[u].x, fy = qf.y - pj[u].y, fz = qf.z - pj[u].z;
+                        float sd = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                        if (DIM >= 4) { const float fe = qf.w - pj[u].w; sd = fmaf(fe, fe, sd); }
+                        if (DIM >= 5) { const float ft = qtf - __int_as_float(xj[u].w); sd = fmaf(ft, ft, sd); }
+                        if (!(sd <= thr) || xj[u].z == ca || jb + u >= j1) continue;
                         const int j = jb + u;
-                        if (j >= j1 || cj[u] == ca) continue;
-                        const double d2 = cl_d2<DIM>(qx, qy, qz, qe, qt, pj[u], stt, j);
+                        const double dx = qx - (double)pj[u].x, dy = qy - (double)pj[u].y, dz = qz - (double)pj[u].z;
+                        double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (DIM >= 4) { const double de = qe - (double)pj[u].w; d2 = d2 + de * de; }
+                        if (DIM >= 5) { const double dt = qt - (double)__int_as_float(xj[u].w); d2 = d2 + dt * dt; }
                         if (d2 > bw) continue;
-                        const double w = fmax(fmax(d2, core_a), core2[j]);
+                        const double cj2 = __longlong_as_double(((long long)xj[u].y << 32) | (unsigned int)xj[u].x);
+                        const double w = fmax(fmax(d2, core_a), cj2);
                         if (w > bw || (w == bw && d2 > bd2)) continue;
-                        const unsigned long long key = cl_edge_key(oa, perm[j]);
-                        if (w < bw || d2 < bd2 || key < bkey) { bw = w; bd2 = d2; bkey = key; bb = j; improved = true; }
+                        if (w < bw || d2 < bd2) {
+                            bw = w; bd2 = d2; bb = j; bkey_valid = false; improved = true;
+                            thr = (float)bw * 1.00001f + 1e-30f;
+                        } else {                         // same weight, same pair distance: the smaller id pair
+                            if (!bkey_valid) { bkey = cl_edge_key(oa, perm[bb]); bkey_valid = true; }
+                            const unsigned long long key = cl_edge_key(oa, perm[j]);
+                            if (key < bkey) { bkey = key; bb = j; }
+                        }
                     }
                 }
                 if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
-                since_refresh = 64;     // force a refresh below
+                since_refresh = 64;
+                continue;
             }
-            if (++since_refresh >= 16) {
-                const unsigned long long cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
-                since_refresh = 0;
-                if (lb_a > cbest) { sp = 0; rr = nrx * nry; break; }      // this point can no longer win: stop
-            }
-            if (l == 0 || j1 - j0 <= CL_LEAF) continue;
             const int l1 = l - 1;
             const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
             const int near = ox | (oy << 1) | (oz << 2);
-            int bnd[9];                                  // boundaries of the 8 child ranges, loaded together (see k_cl_core)
-#pragma unroll
-            for (int c = 0; c < 9; ++c) bnd[c] = cl_start(cs, c0 + ((unsigned int)c << (3 * l1)));
             unsigned int occupied = 0;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) occupied |= (bnd[c] != bnd[c + 1]) ? (1u << c) : 0u;
-            for (int c = 7; c >= 0; --c) {
-                const int ch = c ^ near;
+            for (int u = 0; u < 8; ++u) occupied |= (bnd[u] != bnd[u + 1]) ? (1u << u) : 0u;
+            for (int u = 7; u >= 0; --u) {
+                const int ch = u ^ near;
                 if (!((occupied >> ch) & 1u)) continue;
                 const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
                 const double cd2 = cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz);
@@ -947,6 +1017,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
             }
         }
     }
+    if (bb >= 0 && !bkey_valid) bkey = cl_edge_key(oa, perm[bb]);
     if (dbg_scan) dbg_scan[a] = (far_list ? dbg_scan[a] : 0) + scanned;
     if (bb >= 0 && bw <= cbest) {
         pt_w[a] = (unsigned long long)__double_as_longlong(bw);
@@ -991,7 +1062,7 @@ __global__ __launch_bounds__(64) void k_cl_b_search_blk(const float4* __restrict
     for (int e = blockIdx.x; e < n_entries; e += gridDim.x) {
         const int lv = (int)(entries[e] >> 30), i0 = (int)(entries[e] & 0x3FFFFFFFu);   // node level (0 .. 3), first query
         const unsigned int key1 = code_s[i0] >> (3 * lv);
-        const int iend = min(cl_start(cs, (key1 + 1u) << (3 * lv)), i0 + 64);
+        const int iend = min(cl_start_l(cs, lv, key1 + 1u), i0 + 64);
         const int a = i0 + lane;
         const bool active = a < iend;
         const int aa = active ? a : i0;
@@ -1026,8 +1097,8 @@ __global__ __launch_bounds__(64) void k_cl_b_search_blk(const float4* __restrict
             int j0 = 0, j1 = 0, pure = -1;
             if (nx >= 0 && ny >= 0 && nz >= 0 && nx < (CL_NX >> lv) && ny < (CL_NY >> lv) && nz < (CL_NZ >> lv)) {
                 const unsigned int c0 = cl_code(nx << lv, ny << lv, nz << lv);
-                j0 = cl_start(cs, c0);
-                j1 = cl_start(cs, c0 + (1u << (3 * lv)));
+                j0 = cl_start_l(cs, lv, c0 >> (3 * lv));
+                j1 = cl_start_l(cs, lv, (c0 >> (3 * lv)) + 1u);
                 if (j0 != j1) pure = cell_comp[cl_pur_off(lv) + (c0 >> (3 * lv))];
             }
             bnd[lane][0] = j0; bnd[lane][1] = j1; bnd[lane][2] = pure;
@@ -1185,7 +1256,7 @@ __global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __re
     mst_w[k] = best_w[c];
 }
 
-__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2, int* __restrict__ flags) {
+__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2, int* __restrict__ flags, int4* __restrict__ aux) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) flags[1] = flags[0] >= n - 1;    // read by every kernel of the NEXT round (stream order): rounds are queued in
                                                 // batches without a host read in between, a round after the last one is a no-op
@@ -1193,6 +1264,7 @@ __global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __rest
     int r = comp[i];
     while (parent2[r] != r) r = parent2[r];
     comp[i] = r;
+    aux[i].z = r;
 }
 
 __global__ void k_cl_iota(int n, int* p) {
@@ -1324,7 +1396,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_perm, 4 * n));
     VG_CHECK(hipMalloc(&h->d_spts, sizeof(float4) * n));
     VG_CHECK(hipMalloc(&h->d_st, 4 * n));
-    VG_CHECK(hipMalloc(&h->d_cell_start, 4 * (size_t)(CL_NCODES + 1)));
+    VG_CHECK(hipMalloc(&h->d_cell_start, 4 * ((size_t)(CL_NCODES + 1) + CL_LVL_TOTAL)));
     {
         size_t tot = 0;
         for (int l = 0; l < CL_PUR_LEVELS; ++l) tot += (size_t)CL_NCODES >> (3 * l);
@@ -1333,6 +1405,7 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     }
     VG_CHECK(hipMalloc(&h->d_core2, 8 * n));
     VG_CHECK(hipMalloc(&h->d_comp, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_aux, 16 * n));
     VG_CHECK(hipMalloc(&h->d_parent, 4 * n));
     VG_CHECK(hipMalloc(&h->d_parent2, 4 * n));
     VG_CHECK(hipMalloc(&h->d_best_w, 8 * n));
@@ -1374,7 +1447,7 @@ void vg_cluster_destroy(vg_cluster* h) {
     void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp, h->d_cell_e,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
                     h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_pt_lb, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
-                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp, h->d_entries, h->d_far, h->d_far_flag};
+                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp, h->d_entries, h->d_far, h->d_far_flag, h->d_aux};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(h->h_counter);
     delete h;
@@ -1403,6 +1476,7 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
                        h->d_st, h->d_cell_start);
     tb = h->temp_bytes;
     VG_CHECK(rocprim::inclusive_scan(h->d_temp, tb, h->d_cell_start, h->d_cell_start, (size_t)(CL_NCODES + 1), MinOp(), st));
+    hipLaunchKernelGGL(k_cl_levels, dim3((unsigned)((CL_LVL_TOTAL + 255) / 256)), dim3(256), 0, st, h->d_cell_start);
     VG_LAUNCH_CHECK();
     h->grid_n = n;
     return VG_OK;
@@ -1448,7 +1522,7 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
     static const int core_walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;  // (no work list then)
     if (mode == 0 || core_walk) {
         hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
         return;
     }
@@ -1457,7 +1531,7 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
                        h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, h->d_far, mode == 2 ? h->d_far_flag : (int*)nullptr);
     // the queries left over walk the tree from the edge they hold
     hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                       h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                        h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
                        mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr);
 }
@@ -1541,7 +1615,8 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
     if (d_core2) hipLaunchKernelGGL(k_cl_unsort_core, dim3(nb), dim3(256), 0, st, n, h->d_perm, h->d_core2, d_core2);
     VG_LAUNCH_CHECK();
     // ---- Boruvka ----
-    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b, h->d_pt_lb);
+    hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b, h->d_pt_lb, h->d_core2,
+                       dim >= 5 ? h->d_st : (const float*)nullptr, h->d_aux);
     // Rounds are queued in batches WITHOUT a host read in between: every round's kernels start with `if (flags[1]) return`,
     // and k_cl_b_compress sets flags[1] once the n - 1 edges are out, so a round queued after the last needed one costs a
     // dozen empty launches.  The edge count of every round is copied to its own pinned slot; the host reads them once per batch
@@ -1565,7 +1640,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent, flags);
         hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent, h->d_sel_a, h->d_sel_b, h->d_best_w,
                            h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, flags);
-        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags);
+        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags, h->d_aux);
         return hipMemcpyAsync(h->h_counter + ((r - 1) & 15), h->d_counter, 4, hipMemcpyDeviceToHost, st);
     };
     while (edges < n - 1) {
