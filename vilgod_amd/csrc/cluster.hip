@@ -37,7 +37,9 @@
 #define CL_NCODES (1 << 24)           // 9 + 9 + 6 bits
 #define CL_LMAX 6                     // coarsest Morton-contiguous level (25.6 m cubes): 8 x 8 x 1 roots
 #define CL_PUR_LEVELS 4               // purity tables for levels 0..3 (0.4 .. 3.2 m); levels 4..6 were measured: no gain
+#ifndef CL_LEAF
 #define CL_LEAF 48                    // nodes with at most this many points are scanned instead of subdivided
+#endif
 #define CL_FIRST_BATCH 6      // Boruvka rounds queued before the first host read of the edge counter
 #define CL_STACK 44      // DFS stack entries per thread (LDS): the walk never holds more than 1 + 7 * CL_LMAX = 43 nodes (a pop precedes every push of
                          // <= 8 children, level-0 nodes are never expanded); 44 KB per 256-thread block -> three blocks per CU instead of two
@@ -977,43 +979,72 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                         if (DIM >= 4) { const float fe = qf.w - pj[u].w; sd = fmaf(fe, fe, sd); }
                         if (DIM >= 5) { const float ft = qtf - __int_as_float(xj[u].w); sd = fmaf(ft, ft, sd); }
                         if (!(sd <= thr) || xj[u].z == ca || jb + u >= j1) continue;
+                        // (the survivors update the best edge by selects: inside this branch every further branch is paid by the
+                        // whole wave; only an exact (w, d2) tie -- rare -- goes on to compare ids)
                         const int j = jb + u;
                         const double dx = qx - (double)pj[u].x, dy = qy - (double)pj[u].y, dz = qz - (double)pj[u].z;
                         double d2 = (dx * dx + dy * dy) + dz * dz;
                         if (DIM >= 4) { const double de = qe - (double)pj[u].w; d2 = d2 + de * de; }
                         if (DIM >= 5) { const double dt = qt - (double)__int_as_float(xj[u].w); d2 = d2 + dt * dt; }
-                        if (d2 > bw) continue;
                         const double cj2 = __longlong_as_double(((long long)xj[u].y << 32) | (unsigned int)xj[u].x);
                         const double w = fmax(fmax(d2, core_a), cj2);
-                        if (w > bw || (w == bw && d2 > bd2)) continue;
-                        if (w < bw || d2 < bd2) {
-                            bw = w; bd2 = d2; bb = j; bkey_valid = false; improved = true;
-                            thr = (float)bw * 1.00001f + 1e-30f;
-                        } else {                         // same weight, same pair distance: the smaller id pair
+                        const bool better = w < bw || (w == bw && d2 < bd2);
+                        if (w == bw && d2 == bd2) {      // same weight, same pair distance: the smaller id pair
                             if (!bkey_valid) { bkey = cl_edge_key(oa, perm[bb]); bkey_valid = true; }
                             const unsigned long long key = cl_edge_key(oa, perm[j]);
                             if (key < bkey) { bkey = key; bb = j; }
                         }
+                        bw = better ? w : bw;
+                        bd2 = better ? d2 : bd2;
+                        bb = better ? j : bb;
+                        bkey_valid = bkey_valid && !better;
+                        improved = improved || better;
+                        thr = (float)bw * 1.00001f + 1e-30f;
                     }
                 }
                 if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
                 since_refresh = 64;
                 continue;
             }
+            // ---- children: nearest one pushed last.  Sibling boxes share their faces: two distances per axis serve all eight; the
+            // push is a store + a conditional count (no branch per child) ----
             const int l1 = l - 1;
             const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
             const int near = ox | (oy << 1) | (oz << 2);
-            unsigned int occupied = 0;
+            double ad[3][2];
+            {
+                const double s1 = CL_CELL * (double)(1 << l1);
+                const int nbx[3] = {CL_NX >> l1, CL_NY >> l1, CL_NZ >> l1};
+                const int c2[3] = {2 * x, 2 * y, 2 * z};
+                const double q3[3] = {qx, qy, qz}, o3[3] = {g.ox, g.oy, g.oz};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) occupied |= (bnd[u] != bnd[u + 1]) ? (1u << u) : 0u;
+                for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) {     // the same expressions as cl_box_d2, per axis
+                        const int cc = c2[ax] + hb;
+                        const double lo = o3[ax] + (double)cc * s1, hi = lo + s1;
+                        double d = 0.0;
+                        if (q3[ax] < lo && cc > 0) d = lo - q3[ax];
+                        else if (q3[ax] > hi && cc < nbx[ax] - 1) d = q3[ax] - hi;
+                        ad[ax][hb] = d;
+                    }
+            }
+#pragma unroll
             for (int u = 7; u >= 0; --u) {
                 const int ch = u ^ near;
-                if (!((occupied >> ch) & 1u)) continue;
-                const int nx = 2 * x + (ch & 1), ny = 2 * y + ((ch >> 1) & 1), nz = 2 * z + ((ch >> 2) & 1);
-                const double cd2 = cl_box_d2(g, qx, qy, qz, l1, nx, ny, nz);
+                const int hx = ch & 1, hy = (ch >> 1) & 1, hz = (ch >> 2) & 1;
+                const double dxx = hx ? ad[0][1] : ad[0][0], dyy = hy ? ad[1][1] : ad[1][0], dzz = hz ? ad[2][1] : ad[2][0];
+                double cd2 = 0.0;
+                cd2 += dxx * dxx;
+                cd2 += dyy * dyy;
+                cd2 += dzz * dzz;
                 const double clb = fmax(lb_a, cd2);
-                if (clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) continue;
-                if (sp < CL_STACK) st[(sp++) * 256] = cl_pack(l1, nx, ny, nz);
+                int lo_i = bnd[0], hi_i = bnd[1];        // bnd[ch], bnd[ch + 1] without dynamic register indexing
+#pragma unroll
+                for (int v = 1; v < 8; ++v) { lo_i = ch == v ? bnd[v] : lo_i; hi_i = ch == v ? bnd[v + 1] : hi_i; }
+                const bool keep = lo_i != hi_i && !(clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) && sp < CL_STACK;
+                st[sp * 256] = cl_pack(l1, 2 * x + hx, 2 * y + hy, 2 * z + hz);      // (slot sp is free: written, kept only if counted)
+                sp += keep ? 1 : 0;
             }
         }
     }
@@ -1521,7 +1552,8 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
     static const int mode = getenv("VG_CLUSTER_SEARCH_MODE") ? atoi(getenv("VG_CLUSTER_SEARCH_MODE")) : 0;
     static const int core_walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;  // (no work list then)
     if (mode == 0 || core_walk) {
-        hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+        const int nthreads = n;
+        hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(nthreads, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
         return;
