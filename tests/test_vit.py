@@ -297,6 +297,22 @@ def test_hip_folded_layernorm_other_widths(cuda, width, heads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n', [3, 37, 300])
+def test_hip_last_block_on_class_token_rows_only(cuda, n, monkeypatch):
+    """The fp16 tower runs the last block's out_proj / MLP on the class-token rows alone (the only rows ln_post reads, model.py:235-238;
+    VG_VIT_CLS_LAST=0 runs them on all n x T rows): a row's values do not depend on which rows share its GEMM tile, so the features
+    are the same numbers, not merely close ones."""
+    from vilgod_amd.clip_wrapper import VitEncoder
+    wd = cw.synthetic_vit_weights(2, **cw.VIT_B16)
+    x = torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(n)).to(cuda)
+    f_cls = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    monkeypatch.setenv('VG_VIT_CLS_LAST', '0')
+    f_all = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    assert torch.isfinite(f_cls).all()
+    assert torch.equal(f_cls, f_all), (f_cls - f_all).abs().max().item()
+
+
+@pytest.mark.gpu
 def test_hip_folded_layernorm_follows_a_replaced_weight(cuda):
     """The gamma-scaled weights / c1 / c2 of the folded LayerNorms are derived once per handle; vg_vit_set_weight on any tensor of a
     block invalidates them, the next encode rebuilds them: a handle whose ln_2 gain and c_fc bias were replaced after its first

@@ -773,7 +773,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const TI* __restrict__ x, con
 // TT: the token count as a constant too (197 for ViT-B/16: row clamps and key masks become per-thread constants), 0 = run-time T.
 template <bool TRACE = false, int NKB = 7, int TT = 0>
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
-                                                       int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr) {
+                                                       int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr,
+                                                       int q_tiles = 7) {
     const int T = TT ? TT : T_arg;
     long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = 0;      // TRACE: cycles per phase, summed over this wave's items
 #define AT_STAMP(i) if (TRACE) { const long long c_ = clock64(); tr[i] += c_ - tc; tc = c_; }
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     AT_STAMP(0)                                                        // K / V^T into LDS + barrier
     if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);      // in flight during the compute below
     AT_STAMP(1)                                                        // issue of the next item's loads
-    if (q0 < T) {
+    if (q0 < T && wave < q_tiles) {         // (q_tiles: query tiles wanted -- 1 in the last block, whose class-token row alone is used)
 
 
     f32x16 sacc[7];
@@ -1100,6 +1101,7 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
     bool gemm_x2 = getenv("VG_GEMM_X2") ? atoi(getenv("VG_GEMM_X2")) != 0 : false;   // projection GEMMs by k_gemm_f16_x2 (two workgroups per CU)
+    bool cls_last = !(getenv("VG_VIT_CLS_LAST") && atoi(getenv("VG_VIT_CLS_LAST")) == 0);   // last block: class-token rows only (see vg_vit_encode)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -2082,7 +2084,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
 #define AT4_LDS_BYTES ((AT_MAXT * AT_KLD + 64 * AT_VLD + 4 * 32 * AT_KLD) * 2)   // 79,872 B: two workgroups per CU
 template <int NKB = 7, int TT = 0>
 __global__ __launch_bounds__(256, 2) void k_attention_f16_w4(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
-                                                             int W, int heads, int ld, int n_items) {
+                                                             int W, int heads, int ld, int n_items, int q_tiles) {
     const int T = TT ? TT : T_arg;
     extern __shared__ __attribute__((aligned(16))) char at_smem[];
     f16* const Ks = (f16*)at_smem;
@@ -2139,7 +2141,7 @@ __global__ __launch_bounds__(256, 2) void k_attention_f16_w4(const f16* __restri
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int q0 = (wave + 4 * tt) * 32;
-            if (q0 >= T) continue;
+            if (q0 >= T || wave + 4 * tt >= q_tiles) continue;     // (q_tiles = 1 in the last block: the class-token row alone is used)
             // the tile's Q rows through the wave's LDS tile (coalesced rows in, MFMA fragments out); only this wave touches it
             f16x8 qf[4];
 #pragma unroll
@@ -2247,13 +2249,14 @@ __global__ __launch_bounds__(256, 2) void k_attention_f16_w4(const f16* __restri
 }
 
 template <bool TRACE>
-static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st) {
+static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st,
+                            int q_tiles = 7) {
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
     static const bool w4 = !(getenv("VG_ATT_W4") && atoi(getenv("VG_ATT_W4")) == 0);
     if (T == 197 && !TRACE && w4) {            // ViT-B/16: two 4-wave workgroups per CU
         VG_MAX_DYNAMIC_LDS((k_attention_f16_w4<7, 197>), AT4_LDS_BYTES);
-        hipLaunchKernelGGL((k_attention_f16_w4<7, 197>), dim3(items < 512 ? items : 512), dim3(256), AT4_LDS_BYTES, st, qkv, out, T, W, heads, ld, items);
+        hipLaunchKernelGGL((k_attention_f16_w4<7, 197>), dim3(items < 512 ? items : 512), dim3(256), AT4_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, q_tiles);
         VG_LAUNCH_CHECK();
         return VG_OK;
     }
@@ -2261,11 +2264,11 @@ static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, i
 #define VG_ATT(N)                                                                                                                  \
     case N: {                                                                                                                      \
         VG_MAX_DYNAMIC_LDS((k_attention_f16<TRACE, N>), AT_LDS_BYTES);                                                              \
-        hipLaunchKernelGGL((k_attention_f16<TRACE, N>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);   \
+        hipLaunchKernelGGL((k_attention_f16<TRACE, N>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);   \
         break; }
     if (T == 197 && !TRACE) {                  // ViT-B/16
         VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197>), AT_LDS_BYTES);
-        hipLaunchKernelGGL((k_attention_f16<false, 7, 197>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace);
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197>), grid, block, AT_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
         VG_LAUNCH_CHECK();
         return VG_OK;
     }
@@ -2409,6 +2412,17 @@ int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t 
     return VG_OK;
 }
 
+// The last block's class-token rows, compacted: hc[c] = h[c * T] (attention output, fp16), xc[c] = x[c * T] (residual stream, fp32);
+// rows n_crops .. Mc - 1 (padding of the GEMM row tile) are zeroed.  One workgroup per row.
+__global__ __launch_bounds__(256) void k_gather_cls(const f16* __restrict__ h, const float* __restrict__ x, f16* __restrict__ hc,
+                                                    float* __restrict__ xc, int n_crops, int T, int W) {
+    const int c = blockIdx.x;
+    for (int i = threadIdx.x; i < W; i += 256) {
+        hc[(size_t)c * W + i] = c < n_crops ? h[(size_t)c * T * W + i] : (f16)0.f;
+        xc[(size_t)c * W + i] = c < n_crops ? x[(size_t)c * T * W + i] : 0.f;
+    }
+}
+
 static int64_t pad128(int64_t m) { return (m + 255) / 256 * 256; }   // GEMM row tile (256)
 
 /* bytes of zero-initialised device workspace vg_vit_encode needs for n_crops */
@@ -2536,9 +2550,17 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         else
             rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld);
         if (rc) return rc;
+        // The LAST block: only the class token's row of its output is ever read (ln_post(x[:, 0, :]) @ proj, model.py:235-238), and
+        // after the attention every row is processed on its own (out_proj, ln_2, c_fc, QuickGELU, c_proj and the two residual adds).
+        // So the block computes all keys and values, the class token's attention row, and then runs its three remaining GEMMs on
+        // the n_crops class-token rows alone (compacted, padded to the row tile) instead of on n_crops x T rows: the same value
+        // per element -- a row's dot products do not depend on which rows share its tile -- for 1 / T of the work.
+        const int64_t Mc_ = pad128(n_crops);
+        const bool cls_fits = Mc_ * W * 16 + Mc_ * (W / 256) * 8 <= Mp * (3 * W + 256) * es;      // the compact buffers live in the qkv buffer
+        const bool cls_only = v->cls_last && fold && !rh && l == L - 1 && L > 1 && cls_fits;
         if (v->dtype == 1) {
             {
-                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st);
+                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st, cls_only ? 1 : 7);
                 if (rc) return rc;
             }
         } else {
@@ -2551,6 +2573,29 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             hipLaunchKernelGGL(k_attention_f32, dim3(n_crops * H), dim3(256), lds, st, (const float*)qkv, (float*)h, T, W, H);
         }
         VG_LAUNCH_CHECK();
+        if (cls_only) {
+            // compact buffers inside the qkv buffer (dead once the attention has run): residual rows, attention rows, fp16 copy, hidden
+            // activations, row statistics
+            const int64_t Mc = pad128(n_crops);
+            char* cb = (char*)qkv;
+            float* xc = (float*)cb;            cb += Mc * W * 4;
+            f16* hc = (f16*)cb;                cb += Mc * W * 2;
+            f16* x16c = (f16*)cb;              cb += Mc * W * 2;
+            f16* mlpc = (f16*)cb;              cb += Mc * 4 * W * 2;
+            LnPartial* lnc = (LnPartial*)cb;
+            hipLaunchKernelGGL(k_gather_cls, dim3((unsigned)Mc), dim3(256), 0, st, (const f16*)h, (const float*)x, hc, xc, n_crops, T, W);
+            VG_LAUNCH_CHECK();
+            rc = launch_gemm<EPI_BIAS_RESID, 2>(v, hc, wp[4], (const float*)wp[5], nullptr, xc, (int)Mc, W, W, st, 0, nullptr, lnc, x16c);
+            if (rc) return rc;
+            rc = launch_gemm<EPI_BIAS_GELU, 1>(v, x16c, fw2, f2c2, mlpc, nullptr, (int)Mc, 4 * W, W, st, 0, f2c1, lnc);
+            if (rc) return rc;
+            rc = launch_gemm<EPI_BIAS_RESID>(v, mlpc, wp[10], (const float*)wp[11], nullptr, xc, (int)Mc, W, 4 * W, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_head<float>), dim3(n_crops), dim3(256), W * sizeof(float), st, (const float*)xc, (const float*)need("ln_post.weight"),
+                               (const float*)need("ln_post.bias"), (const float*)need("proj"), d_feat, 1, W, v->out_dim);
+            VG_LAUNCH_CHECK();
+            return VG_OK;
+        }
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
            : fold ? launch_gemm<EPI_BIAS_RESID, 2>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, lnst, x16)
                   : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
