@@ -766,12 +766,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const TI* __restrict__ x, con
 #define AT_MAXT 224
 #define AT_KLD 72      // K rows: 64 + 8 halves
 #define AT_LDS_BYTES ((AT_MAXT * AT_KLD + 64 * 228 + 7 * 32 * AT_KLD) * 2)   // 93,696 B
+#define AT_LDS_BYTES_TR ((AT_MAXT * AT_KLD + AT_MAXT * AT_KLD + 7 * 32 * AT_KLD) * 2)   // 96,768 B (row-major V)
 #define AT_VLD 228     // V^T rows: 224 + 4 halves (456 B: 32 rows of a fragment read hit 32 different banks; the 8 x 8 transposed
                        // writes of a wave land 2-way conflicted)
 // NKB: number of 32-key blocks, ceil(T / 32), as a compile-time constant (7 for ViT-B/16's 197 tokens): with a run-time count every
 // key block sits behind its own branch (14 scheduling regions per item); with the constant the item is straight-line code.
 // TT: the token count as a constant too (197 for ViT-B/16: row clamps and key masks become per-thread constants), 0 = run-time T.
-template <bool TRACE = false, int NKB = 7, int TT = 0>
+typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
+// TR: V stays ROW-major in LDS (one 16-byte write per chunk, like K) and the O^T MFMAs' A operand -- V^T[d][8 consecutive keys] -- comes
+// from gfx950's transposing read: per group of 16 lanes ds_read_b64_tr_b16 takes a 4-key x 16-feature block (lane 4q + p of the group
+// supplies the address of key q, features 4p .. 4p + 3) and hands lane i feature i of the four keys.
+template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false>
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
                                                        int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr,
                                                        int q_tiles = 7) {
@@ -785,7 +790,10 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     // per-wave 32 x 64 tile (row stride AT_KLD): the wave's Q rows arrive coalesced (eight lanes per 128-byte row) and are re-read as
     // MFMA fragments (one row per lane); the output rows go the other way.  Only this wave touches it: LDS operations of one wave
     // execute in program order, no barrier needed.
-    f16* const Qs = Vt + 64 * AT_VLD + wave * 32 * AT_KLD;
+    f16* const Vs = Vt;                       // TR: [AT_MAXT][AT_KLD] rows instead of the transposed [64][AT_VLD] image
+    f16* const Qs = Vt + (TR ? AT_MAXT * AT_KLD : 64 * AT_VLD) + wave * 32 * AT_KLD;
+    const int tr_i = lane & 15, tr_g = lane >> 4;
+    const int tr_off = ((4 * (tr_g >> 1) + (tr_i >> 2)) * AT_KLD + 16 * (tr_g & 1) + 4 * (tr_i & 3)) * 2;      // bytes: + (kb*32 + 16s [+ 8]) rows, + dt*32 features
     const int crow = lane >> 3, cpart = lane & 7;                           // coalesced layout: row it * 8 + crow, 16-byte part
     const int r31 = lane & 31, hh = lane >> 5;
     const int q0 = wave * 32;
@@ -842,8 +850,11 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         const int c = tid + it * 448, key = c >> 3, part = c & 7;
         const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
         const f16x8 v = key < T ? vreg[it] : z;
+        if (TR) *(f16x8*)(Vs + key * AT_KLD + part * 8) = v;
+        else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
+            for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
+        }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) *(f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8) = qn[it];
@@ -935,8 +946,15 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     // A[d][k]: element j <-> key kb*32 + 16s + 8(j>>2) + 4hh + (j&3)
-                    const f16* vp = Vt + (dt * 32 + r31) * AT_VLD + kb * 32 + 16 * s + 4 * hh;
-                    f16x4 lo = *(const f16x4*)vp, hi = *(const f16x4*)(vp + 8);
+                    f16x4 lo, hi;
+                    if (TR) {
+                        const char* vb = (const char*)Vs + tr_off + ((kb * 32 + 16 * s) * AT_KLD + dt * 32) * 2;
+                        lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)vb));
+                        hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(vb + 8 * AT_KLD * 2)));
+                    } else {
+                        const f16* vp = Vt + (dt * 32 + r31) * AT_VLD + kb * 32 + 16 * s + 4 * hh;
+                        lo = *(const f16x4*)vp; hi = *(const f16x4*)(vp + 8);
+                    }
                     f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
                 }
@@ -2076,187 +2094,17 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
     return VG_OK;
 }
 
-// Two 4-wave workgroups per CU (k_attention_f16_w4): wave w owns the query tiles w and w + 4, one after the other.  The 7-wave
-// kernel above owns its CU alone (94 KB of LDS): while it stages an item's K / V^T and waits at its two barriers the matrix pipe
-// idles, and seven tiles on four SIMDs put two on the critical one whatever the layout (MFMA 19.6 % busy).  Here an item's staging
-// and barriers run under the other workgroup's MFMAs, and eight tile slots spread evenly over the SIMDs; nothing is prefetched
-// across items (the registers of a second set of K / V rows would cost the second workgroup).
-#define AT4_LDS_BYTES ((AT_MAXT * AT_KLD + 64 * AT_VLD + 4 * 32 * AT_KLD) * 2)   // 79,872 B: two workgroups per CU
-template <int NKB = 7, int TT = 0>
-__global__ __launch_bounds__(256, 2) void k_attention_f16_w4(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
-                                                             int W, int heads, int ld, int n_items, int q_tiles) {
-    const int T = TT ? TT : T_arg;
-    extern __shared__ __attribute__((aligned(16))) char at_smem[];
-    f16* const Ks = (f16*)at_smem;
-    f16* const Vt = Ks + AT_MAXT * AT_KLD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f16* const Qs = Vt + 64 * AT_VLD + wave * 32 * AT_KLD;
-    const int crow = lane >> 3, cpart = lane & 7;                           // coalesced layout: row it * 8 + crow, 16-byte part
-    const int r31 = lane & 31, hh = lane >> 5;
-    constexpr int nkb = NKB;                                          // == (T + 31) / 32, checked by the launcher
-    static_assert(AT_MAXT * 8 == 7 * 256, "staging split");
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int crop = item / heads, head = item - crop * heads;
-        const size_t row0 = (size_t)crop * T;
-        const f16* qbase = qkv + (size_t)crop * T * ld + head * 64;
-        const f16* kbase = qbase + W;
-        const f16* vbase = qbase + 2 * W;
-        // ---- this item's rows: all loads out back to back, branch-free (clamped row, zeroed by select when written to LDS) ----
-        f16x8 qn[2][4];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int qr = (wave + 4 * tt) * 32 + it * 8 + crow;
-                qn[tt][it] = *(const f16x8*)(qbase + (size_t)(qr < T ? qr : T - 1) * ld + cpart * 8);
-            }
-        {
-            uint4 kreg[7];
-            f16x8 vreg[7];
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int c = tid + it * 256, key = c >> 3, part = c & 7;
-                kreg[it] = *(const uint4*)(kbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
-            }
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int c = tid + it * 256, key = c >> 3, part = c & 7;
-                vreg[it] = *(const f16x8*)(vbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
-            }
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int c = tid + it * 256, key = c >> 3, part = c & 7;
-                *(uint4*)(Ks + key * AT_KLD + part * 8) = key < T ? kreg[it] : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const int c = tid + it * 256, key = c >> 3, part = c & 7;
-                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                const f16x8 v = key < T ? vreg[it] : z;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[(part * 8 + e) * AT_VLD + key] = v[e];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int q0 = (wave + 4 * tt) * 32;
-            if (q0 >= T || wave + 4 * tt >= q_tiles) continue;     // (q_tiles = 1 in the last block: the class-token row alone is used)
-            // the tile's Q rows through the wave's LDS tile (coalesced rows in, MFMA fragments out); only this wave touches it
-            f16x8 qf[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) *(f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8) = qn[tt][it];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(Qs + r31 * AT_KLD + s * 16 + hh * 8);
-            f32x16 sacc[7];
-#pragma unroll
-            for (int kb = 0; kb < 7; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-                if (kb < nkb) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + r31) * AT_KLD + s * 16 + hh * 8);
-                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
-                    }
-                }
-            }
-            // softmax over keys (scores scaled by 1/8 = dh^-0.5).  Only the last key block can hold keys >= T
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 7; ++kb) {
-                if (kb == nkb - 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (key >= T) sacc[kb][r] = -INFINITY;
-                    }
-                }
-                if (kb < nkb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float c2 = 0.125f * 1.4426950408889634f;
-            const float mc = -mx * c2;
-            float sum = 0.f;
-            const int tail = T - 32 * (nkb - 1);
-#pragma unroll
-            for (int kb = 0; kb < 7; ++kb) {
-                if (kb < nkb) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (kb < nkb - 1 || 8 * g < tail) {
-#pragma unroll
-                            for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, mc));      // raw v_exp_f32: exp2(-inf) = 0
-                                sacc[kb][r] = p;
-                                sum += p;
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 4 * g; r < 4 * g + 4; ++r) sacc[kb][r] = 0.f;
-                        }
-                    }
-                }
-            }
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            f32x16 oacc[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 7; ++kb) {
-                if (kb < nkb) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        if (kb == nkb - 1 && 16 * s >= tail) continue;         // k-step of keys that do not exist: P = 0 there
-                        f16x8 pf;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kb][8 * s + j];
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const f16* vp = Vt + (dt * 32 + r31) * AT_VLD + kb * 32 + 16 * s + 4 * hh;
-                            f16x4 lo = *(const f16x4*)vp, hi = *(const f16x4*)(vp + 8);
-                            f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            // output rows through the wave's tile: a lane's 4-feature pieces in, 16-byte parts of whole 128-byte rows out
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 h4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
-                    *(f16x4*)(Qs + r31 * AT_KLD + dt * 32 + 8 * g + 4 * hh) = h4;
-                }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int qr = q0 + it * 8 + crow;
-                const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
-                if (qr < T) *(f16x8*)(out + (row0 + qr) * (size_t)W + head * 64 + cpart * 8) = v;
-            }
-        }
-        __syncthreads();      // every wave is done with this item's K / V^T before the next item overwrites them
-    }
-}
-
 template <bool TRACE>
 static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st,
                             int q_tiles = 7) {
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
-    static const bool w4 = !(getenv("VG_ATT_W4") && atoi(getenv("VG_ATT_W4")) == 0);
-    if (T == 197 && !TRACE && w4) {            // ViT-B/16: two 4-wave workgroups per CU
-        VG_MAX_DYNAMIC_LDS((k_attention_f16_w4<7, 197>), AT4_LDS_BYTES);
-        hipLaunchKernelGGL((k_attention_f16_w4<7, 197>), dim3(items < 512 ? items : 512), dim3(256), AT4_LDS_BYTES, st, qkv, out, T, W, heads, ld, items, q_tiles);
+    // ViT-B/16: row-major V + transposing LDS reads (VG_ATT_TR=0: the transposed V image of rounds 1-2; same numbers, 1.6 % slower)
+    static const bool tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);
+    if (T == 197 && !TRACE && tr) {
+        const dim3 grid7(items < 256 ? items : 256);
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true>), AT_LDS_BYTES_TR);
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
         VG_LAUNCH_CHECK();
         return VG_OK;
     }
