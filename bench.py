@@ -545,7 +545,8 @@ def main():
                         'max_abs_probability_difference': round(worst, 5), 'clusters_compared': n, 'class_names_that_differ': flips,
                         'note': 'VG_VIT_RESID16=1 at vg_vit_create: the residual stream in fp16 like the reference\'s CUDA run (EPI_BIAS_RESID_H epilogue: '
                                 'half the read-modify-write bytes of out_proj / c_proj, no separate fp16 copy); NOT the default: against the fp32 oracle its '
-                                'probability error is ~2.7e-3 (fp32 stream: ~6e-4), north_star asks for 1e-3'}
+                                'probability error is ~2.7e-3 (fp32 stream: ~6e-4), north_star asks for 1e-3.  Since the default tower runs its last block on the '
+                                'class-token rows only (not implemented for this mode) the fp32 stream is also the faster one'}
             block('resid16', resid16)
             block('views6', shape_block(args.points, args.objects, 6, 'BASELINE config 3 as written: 150k points, 6 rendered views'))
             block('dense200k', shape_block(200_000, 120, args.views, 'BASELINE config 5 shape: dense 200k-point frames, ~120 objects, fp16 ViT'))
