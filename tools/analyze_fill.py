@@ -36,4 +36,11 @@ for i in range(int(t_end // 10e6) + 1):
     top = sorted(kt[i].items(), key=lambda kv: -kv[1])[:3]
     print(f'  {10 * i:4d}-{10 * i + 10:4d} ms: idle {slices[i]:5.2f} ms   ' + ', '.join(f'{k} {v:.1f}' for k, v in top))
 # when each frame's classification ends (k_head: once per frame)
-print('k_head ends (ms):', ' '.join(f'{e / 1e6:.1f}' for s, e, k in reg if k.startswith('k_head')))
+# the ViT passes: from a frame's k_embed_lnpre to its k_head (passes may overlap, two at a time)
+emb = sorted(s for s, e, k in reg if 'k_embed_lnpre' in k)
+heads = sorted(e for s, e, k in reg if 'k_head' in k)
+print('ViT pass starts (ms):', ' '.join(f'{t / 1e6:.1f}' for t in emb))
+print('ViT pass ends   (ms):', ' '.join(f'{t / 1e6:.1f}' for t in heads))
+last_gemm = max(e for s, e, k in reg if 'k_gemm' in k)
+print(f'last GEMM ends {last_gemm / 1e6:.1f} ms, last kernel of any kind {t_end / 1e6:.1f} ms; kernels after the last GEMM:',
+      ', '.join(sorted({k[:40] for s, e, k in reg if s > last_gemm})))

@@ -185,33 +185,77 @@ class PseudoLabelPipeline:
         ramp = os.environ.get('VILGOD_FILL_RAMP', '1') != '0' and n_workers > 1
         front_done = [threading.Event() for _ in range(min(n_workers, len(frames)))]
 
+        frame_log = [] if os.environ.get('VILGOD_FRAME_LOG') else None      # development aid: per-frame host timeline of the block
+        t_block = time.perf_counter()
+
         def run(worker, i, d_pts, mask, ev):
             gate = front_done[i] if ramp and i < len(front_done) else None
+            t_start = time.perf_counter()
+            t_front = [None]
+
+            def front():
+                t_front[0] = time.perf_counter()
+                if gate is not None:
+                    gate.set()
             try:
                 if gate is not None and i > 0:
                     front_done[i - 1].wait()
+                t_go = time.perf_counter()
                 with torch.cuda.stream(worker.stream):
                     worker.stream.wait_event(ev)
                     fs, res = worker.process_frame(d_pts, poses[i], ref_pose, fnr=first_fnr + i, mask=mask,
-                                                   before_classify=gate.set if gate is not None else None)
+                                                   before_classify=front if (gate is not None or frame_log is not None) else None)
                     probs = getattr(worker, 'last_probs', None)
                     worker.stream.synchronize()
             finally:
                 if gate is not None:
                     gate.set()                   # frames without valid clusters, errors: never leave the next worker waiting
+            if frame_log is not None:
+                frame_log.append((i, workers.index(worker), t_start - t_block, t_go - t_block, (t_front[0] or t_go) - t_block, time.perf_counter() - t_block))
             return fs, res, probs
 
-        futures = []
-        with torch.cuda.stream(main):
-            for i, pts in enumerate(frames):
-                d_pts = self.upload(pts)
-                mask = self.ground(d_pts)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                w = workers[i % n_workers]
-                futures.append(w.thread.submit(run, w, i, d_pts, mask, ev))
-            if after_ground is not None:
-                after_ground()         # every ground pass of the block is queued: e.g. hand the ground state to the next rank
+        # Frames are handed out in order to whichever worker is free (one shared queue), not dealt round-robin: the workers do not
+        # run in step -- the ones the ramp starts last meet a GPU already full of GEMM tiles and need 30-40 ms for a front stage that
+        # takes 12 alone -- and with a fixed deal the block ended when the slowest worker had worked off its share while the others
+        # sat idle (20-frame block: worker 5 began its second frame at 200 ms and its third at 286 of 340; same box, interleaved:
+        # 52.1 -> 60.3 frames/s in 20-frame blocks, 96-frame blocks unchanged).
+        from concurrent.futures import Future
+        import queue
+        futures = [Future() for _ in frames]
+        jobs = queue.Queue()
+
+        def drain(worker):
+            while True:
+                job = jobs.get()
+                if job is None:
+                    return
+                i, d_pts, mask, ev = job
+                if not futures[i].set_running_or_notify_cancel():
+                    continue
+                try:
+                    futures[i].set_result(run(worker, i, d_pts, mask, ev))
+                except BaseException as e:     # noqa: BLE001  (delivered through the frame's future)
+                    futures[i].set_exception(e)
+
+        drains = [w.thread.submit(drain, w) for w in workers[:min(n_workers, len(frames))]]
+        try:
+            with torch.cuda.stream(main):
+                for i, pts in enumerate(frames):
+                    d_pts = self.upload(pts)
+                    mask = self.ground(d_pts)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    jobs.put((i, d_pts, mask, ev))
+                if after_ground is not None:
+                    after_ground()         # every ground pass of the block is queued: e.g. hand the ground state to the next rank
+        except BaseException:
+            for _ in drains:
+                jobs.put(None)
+            for d in drains:                   # an upload / ground pass failed: let the frames already handed out finish, then re-raise
+                d.result()
+            raise
+        for _ in drains:
+            jobs.put(None)                     # one stop mark per draining worker, behind the last frame
         out, first_error = [], None
         try:
             for f in futures:                  # drain every worker even when one frame failed: nothing keeps running behind the caller's back
@@ -220,9 +264,16 @@ class PseudoLabelPipeline:
                 except BaseException as e:     # noqa: BLE001
                     first_error = first_error or e
         finally:
+            for d in drains:
+                d.result()                     # the workers' threads are free again before the caller goes on
             torch.cuda.current_stream(self.device).wait_stream(main)
         if first_error is not None:
             raise first_error
+        if frame_log is not None:
+            import sys
+            print('[frame log] frame worker: submitted  started  crops queued  done (ms since the block began)', file=sys.stderr)
+            for i, w, a, b, c, d in sorted(frame_log):
+                print(f'[frame log] {i:4d} {w:2d}: {1e3 * a:8.1f} {1e3 * b:8.1f} {1e3 * c:8.1f} {1e3 * d:8.1f}', file=sys.stderr)
         return out
 
     @staticmethod

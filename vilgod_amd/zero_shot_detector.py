@@ -148,15 +148,35 @@ class ZeroShotDetector:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(p.device))
 
-        def run(worker, f):
+        # The frames go, in order, to whichever worker is free (one shared queue; a worker's handles are only ever used on its own
+        # thread).  A fixed deal (frame i -> worker i % nw) ends when the slowest worker has worked off its share: the workers do not
+        # run in step (PseudoLabelPipeline.process_frames).
+        import queue
+        todo = queue.Queue()
+        for f in frames:
+            todo.put(f)
+
+        def drain(worker):
+            errors = []
             with torch.cuda.stream(worker.stream):
                 worker.stream.wait_event(ev)
-                body(worker, f)
-                worker.stream.synchronize()
+                while True:
+                    try:
+                        f = todo.get_nowait()
+                    except queue.Empty:
+                        break
+                    try:
+                        body(worker, f)
+                        worker.stream.synchronize()
+                    except BaseException as e:      # noqa: BLE001  (the other frames still run; the first error is raised below)
+                        errors.append(e)
+            return errors
 
-        # frame i -> worker i % nw, on that worker's own thread: its handles are never used by two threads at once
-        for fut in [workers[i % nw].thread.submit(run, workers[i % nw], f) for i, f in enumerate(frames)]:
-            fut.result()
+        errs = []
+        for fut in [w.thread.submit(drain, w) for w in workers[:nw]]:
+            errs.extend(fut.result())
+        if errs:
+            raise errs[0]
 
     def _exchange_states(self):
         """Every rank receives the serialised states of the frames it does not own (small pickled objects)."""
