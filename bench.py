@@ -18,9 +18,10 @@ frames (north_star).  The run is a real stream: every one of the W + K frames of
 cycling -- a new crop count almost every frame), handed over as a pinned HOST buffer (SURVEY 8d's clock: "raw points resident in
 host pinned memory" to "result dict on the host"; the copy to HBM is queued inside the timed region; `--input resident` uploads
 the K clouds before the clock starts instead and is reported as the `resident_input` block).  Each rank keeps `--inflight` frames
-(default 6) in flight on worker threads with their own streams and handles.  Before the W warm-up steps one untimed set-up block
-of min(K, 24) further distinct clouds brings the caching allocator to the steady state of a long-running stream (config.setup_frames;
-not steps of the metric).  The ViT runs as plain stream launches (default) or
+(default 6) in flight on worker threads with their own streams and handles.  Before the W warm-up steps an untimed set-up block
+of min(K, 24) further distinct clouds brings the caching allocator -- and a freshly leased box's first second of GPU load -- to the
+steady state of a long-running stream: repeated until two passes agree within 5 %, at most 6 times (config.setup_frames = frames
+run that way; not steps of the metric).  The ViT runs as plain stream launches (default) or
 as captured hipGraphs per crop-count bucket (`--vit-graph`; captures then happen INSIDE the timed region and are counted in
 `config.graphs_captured`).  The K timed frames include filling and draining the pipeline (small K therefore reads a little
 lower: the driver's K = 20 run vs the default K = 96).
@@ -304,13 +305,28 @@ def main():
     # process that needs a new size pays a device-synchronising hipMalloc inside the timed region: measured on K = 20, the metric's
     # block -- the first of the process -- read 55.4 frames/s while every later block of the same run (same frames, other pipeline
     # objects) read 57.8-59.2.  Model set-up like weight loading; reported as config.setup_frames.
+    # The block is repeated until two consecutive passes take the same time within 5 % (at most 6 passes): the first process on a
+    # freshly leased box runs its first 0.6-1.5 s of GPU work 2-4x slower than everything after it (measured: set-up passes of 575,
+    # 322, 325, 321 ms on such a box; with a single pass the timed block of a first process read 42-44 frames/s, the second process
+    # on the same box 54-60) -- a property of the box's first load, not of the steady stream the metric describes.
     n_setup = 0 if args.stage_times else min(K, 24)
+    setup_passes = 0
     if n_setup:
         setup_frames = [torch.from_numpy(synthetic.make_frame(900_001 + rank * 100_000 + i, args.points, n_objects=args.objects)).pin_memory()
                         for i in range(n_setup)]
-        run_steps(pipe, 0, n_setup, 0, src=setup_frames)
+        last = None
+        while setup_passes < 6:
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            run_steps(pipe, 0, n_setup, 0, src=setup_frames)
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t_s
+            pipe.new_sequence()
+            setup_passes += 1
+            if last is not None and abs(dt_s - last) <= 0.05 * last:
+                break
+            last = dt_s
         del setup_frames
-        pipe.new_sequence()
     run_steps(pipe, 0, W, 0)                                   # warm-up, also builds the worker handles
     comm_warmup()
     stage = {}
@@ -364,7 +380,7 @@ def main():
                              f'{world}-way in contiguous blocks' + (f', ground state by {args.ground_handoff}' if world > 1 else '') +
                              ', one all-gather of the score matrices'),
                 'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,
-                'setup_frames': n_setup,
+                'setup_frames': n_setup * setup_passes,
                 'distinct_frames': len({id(f) for f in frames[W:W + K]}), 'distinct_crop_counts': len({int(p.shape[0]) for _, _, p in outs}),
                 'input': ('pinned host buffers, H2D copy inside the timed region' if args.input == 'host' else 'resident in HBM before the timed region'),
                 'vit_launch': 'captured hipGraphs per crop-count bucket' if args.vit_graph else 'plain stream launches',
