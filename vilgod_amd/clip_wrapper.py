@@ -58,9 +58,14 @@ class VitEncoder:
 
     def _workspace(self, n):
         if self._ws is None or n > self._ws_crops:
-            nbytes = lib.vg_vit_workspace_bytes(self._h, n)
+            # sized for the next multiple of 64 crops: a stream of frames meets a slightly larger crop count every few frames, and
+            # every exact-size regrowth was a fresh ~1.5 GB allocation + fill on the worker's stream (and the old block stays in the
+            # caching allocator's pool)
+            cap = (n + 63) // 64 * 64
+            nbytes = lib.vg_vit_workspace_bytes(self._h, cap)
+            self._ws = None
             self._ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws_crops = n
+            self._ws_crops = cap
         return self._ws
 
     def profile(self, on=True):

@@ -224,20 +224,24 @@ class PseudoLabelPipeline:
         futures = [Future() for _ in frames]
         jobs = queue.Queue()
 
-        def drain(worker):
-            while True:
-                job = jobs.get()
-                if job is None:
-                    return
-                i, d_pts, mask, ev = job
-                if not futures[i].set_running_or_notify_cancel():
-                    continue
-                try:
-                    futures[i].set_result(run(worker, i, d_pts, mask, ev))
-                except BaseException as e:     # noqa: BLE001  (delivered through the frame's future)
-                    futures[i].set_exception(e)
+        # (the block's first n_workers frames still go one to each worker: a short warm-up block then exercises every worker's
+        # stream, allocator pool and ViT workspace)
+        n_active = min(n_workers, len(frames))
+        first = [queue.Queue() for _ in range(n_active)]
 
-        drains = [w.thread.submit(drain, w) for w in workers[:min(n_workers, len(frames))]]
+        def drain(worker, k):
+            job = first[k].get()
+            while job is not None:
+                i, d_pts, mask, ev = job
+                if futures[i].set_running_or_notify_cancel():
+                    try:
+                        futures[i].set_result(run(worker, i, d_pts, mask, ev))
+                    except BaseException as e:     # noqa: BLE001  (delivered through the frame's future)
+                        futures[i].set_exception(e)
+                job = jobs.get()
+
+        drains = [workers[k].thread.submit(drain, workers[k], k) for k in range(n_active)]
+        fed = 0
         try:
             with torch.cuda.stream(main):
                 for i, pts in enumerate(frames):
@@ -245,17 +249,18 @@ class PseudoLabelPipeline:
                     mask = self.ground(d_pts)
                     ev = torch.cuda.Event()
                     ev.record(main)
-                    jobs.put((i, d_pts, mask, ev))
+                    (first[i] if i < n_active else jobs).put((i, d_pts, mask, ev))
+                    fed = i + 1
                 if after_ground is not None:
                     after_ground()         # every ground pass of the block is queued: e.g. hand the ground state to the next rank
-        except BaseException:
+        finally:
+            for k in range(fed, n_active):
+                first[k].put(None)             # (only when an upload / ground pass failed before the first round was out)
             for _ in drains:
-                jobs.put(None)
-            for d in drains:                   # an upload / ground pass failed: let the frames already handed out finish, then re-raise
-                d.result()
-            raise
-        for _ in drains:
-            jobs.put(None)                     # one stop mark per draining worker, behind the last frame
+                jobs.put(None)                 # one stop mark per draining worker, behind the last frame
+            if fed < len(frames):
+                for d in drains:               # ... let the frames already handed out finish before the error goes up
+                    d.result()
         out, first_error = [], None
         try:
             for f in futures:                  # drain every worker even when one frame failed: nothing keeps running behind the caller's back
