@@ -428,11 +428,24 @@ class ZeroShotDetector:
                                                 min_percentile_pp_score=float(ecfg['min_percentile_pp_score']) if ecfg else 0.5)
             if 'filter_detections' in fused and fs.n_detections:
                 self._filter_frame(p, fnr)
+                if track_rows is not None:
+                    # the tracker's input (Detection.cluster_mass_center of the rows it will see): one small launch per frame, queued
+                    # here under other frames' GEMMs instead of 199 launches + read-backs at the start of track_clusters
+                    rows = np.flatnonzero(fs.valid) if track_rows == 'valid' else np.arange(fs.n_detections)
+                    if len(rows):
+                        d_index, d_seg = self._cluster_lists(fnr, rows)
+                        self._track_med[fnr] = (rows, p.cluster_medians(X, d_index, d_seg))
             if cls_ctx is not None and fs.n_detections and cls_ctx['key'] not in fs.cls:
                 self._classify_frame(p, fnr, cls_ctx)
 
         fused = getattr(self, '_fused', {})
         cls_ctx = self._classification_context(**fused['classification']) if 'classification' in fused else None
+        track_rows = None
+        active = list(self.cfg.pipeline_active)
+        if 'filter_detections' in fused and 'track_clusters' in active and self.world_size == 1:
+            targs = [t['args'] or {} for t in self.cfg.pipeline if t['name'] == 'track_clusters']
+            track_rows = 'valid' if (targs and targs[0].get('valid_only', False)) else 'all'
+        self._track_med = {}
         self._for_frames(todo, body, prepare=lambda f: (self._ref_and_nonground(f), self._entropy_full(f)))
         if todo:
             self.sync_lidar_frames()
@@ -621,7 +634,10 @@ class ZeroShotDetector:
         with self._part('track.medians_queue'):
             for fs in self.lidar_frame_list:
                 rows = np.flatnonzero(fs.valid) if valid_only else np.arange(fs.n_detections)
-                if len(rows):
+                pre = getattr(self, '_track_med', {}).pop(fs.fnr, None)
+                if pre is not None and np.array_equal(pre[0], rows):
+                    pending.append((fs, rows, pre[1]))                   # queued by the frame pass (spatial_clustering's body)
+                elif len(rows):
                     X = self._ref_and_nonground(fs.fnr)[1]
                     d_index, d_seg = self._cluster_lists(fs.fnr, rows)
                     pending.append((fs, rows, self.pipe.cluster_medians(X, d_index, d_seg)))
