@@ -23,6 +23,11 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
 int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
                   int K, int ldc, void* stream);
 
+/* k_gemm_f16_pp64 with the folded LayerNorm's consumer epilogue (epi 0 bias, 1 bias + QuickGELU) on caller-supplied row statistics
+ * d_stats [M, K/256] (mean, m2) float pairs and d_c1 [N]: A/B against vg_gemm on the same operands (tools/bench_gemm_ln.py) */
+int vg_gemm_ln_consumer(int epi, const void* d_X, const void* d_Wt, const float* d_bias, const float* d_c1, const void* d_stats,
+                        void* d_C, int M, int N, int K, void* stream);
+
 /* vg_attention (include/vilgod_hip.h) with cycle stamps: with d_trace != NULL the traced build runs and writes, per
  * (workgroup of the persistent grid min(n_crops*heads, 256), wave 0..6), eight int64 cycle sums: staging + barrier, next-item load
  * issue, S^T MFMA issue, max pass, exp pass, P/V^T/O^T issue, output, end barrier. */

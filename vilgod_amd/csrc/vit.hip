@@ -2511,6 +2511,16 @@ int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_b
     return VG_OK;
 }
 
+/* k_gemm_f16_pp64 with the folded LayerNorm's CONSUMER epilogue (LN = 1; epi 0 bias, 1 bias + QuickGELU) on caller-supplied row
+ * statistics: d_stats [M, K/256] (mean, m2) pairs, d_c1 [N]; for A/B runs against vg_gemm on the same operands */
+int vg_gemm_ln_consumer(int epi, const void* d_X, const void* d_Wt, const float* d_bias, const float* d_c1, const void* d_stats,
+                        void* d_C, int M, int N, int K, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (epi == 0) return launch_gemm_pp64<EPI_BIAS, false, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, N, st, nullptr, d_c1, (LnPartial*)d_stats);
+    if (epi == 1) return launch_gemm_pp64<EPI_BIAS_GELU, false, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, N, st, nullptr, d_c1, (LnPartial*)d_stats);
+    return VG_ERR_ARG;
+}
+
 int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
                   int K, int ldc, void* stream) {
     hipStream_t st = (hipStream_t)stream;
