@@ -145,7 +145,8 @@ def test_dense_frames_six_views_in_flight_equal_sequential(cuda):
 def test_f16_pipeline_agrees_with_f32_pipeline_on_150k_frames(cuda):
     """The benchmarked fp16 pipeline against the fp32 (oracle-pinned, test_pipeline_matches_oracle_20k) pipeline on three synthetic
     150k-point frames: everything before the ViT is the same code -> ground set, clusters, valid flags and boxes EQUAL; per-crop
-    probabilities within 2e-3; a view's top-1 class may flip only where the fp32 margin between its two best classes is inside
+    probabilities within 1.5e-3 (measured 1.35e-3; north_star's 1e-3 is the fp32 mode's bound, asserted in
+    test_pipeline_matches_oracle_20k and test_integration.py); a view's top-1 class may flip only where the fp32 margin between its two best classes is inside
     that error bound, and a cluster's final name only through such a view.  Flips are counted and printed."""
     from vilgod_amd.pipeline import PseudoLabelPipeline
     from vilgod_amd.clip_wrapper import ClipWrapper
@@ -167,11 +168,11 @@ def test_f16_pipeline_agrees_with_f32_pipeline_on_150k_frames(cuda):
         assert pa.shape == pb.shape and pa.shape[0] == 4 * int(fa.valid.sum())
         err = np.abs(pa - pb).max()
         worst = max(worst, float(err))
-        assert err <= 2e-3, err
+        assert err <= 1.5e-3, err
         srt = np.sort(pb, axis=1)
         margin = srt[:, -1] - srt[:, -2]
         flip = pa.argmax(1) != pb.argmax(1)
-        assert (margin[flip] <= 2 * 2e-3).all(), margin[flip]
+        assert (margin[flip] <= 2 * 1.5e-3).all(), margin[flip]
         ea, eb = fa.cls[p16.cls_key], fb.cls[p32.cls_key]
         rows = np.flatnonzero(fa.valid)
         names_differ = np.array([str(ea['name'][r]) != str(eb['name'][r]) for r in rows])
@@ -184,7 +185,7 @@ def test_f16_pipeline_agrees_with_f32_pipeline_on_150k_frames(cuda):
         # clusters without a flipped view: same name, final score (mean probability of the winning views) within the bound
         quiet = ~has_flip & ~names_differ
         fa_, fb_ = np.asarray(ea['final'])[rows].astype(np.float64), np.asarray(eb['final'])[rows].astype(np.float64)
-        assert np.abs(fa_[quiet] - fb_[quiet]).max() <= 2e-3
+        assert np.abs(fa_[quiet] - fb_[quiet]).max() <= 1.5e-3
         if not names_differ.any():
             assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
     print(f'f16 vs f32 pipeline, 3 x 150k frames: max |dp| {worst:.2e}; top-1 flips {n_view_flips}/{n_views} views '

@@ -173,6 +173,27 @@ def test_hip_attention_alone(cuda, n_crops, T):
 
 
 @pytest.mark.gpu
+def test_hip_attention_transposing_reads_equal_transposed_image(cuda, monkeypatch):
+    """T = 197: the default kernel (row-major V in LDS, V^T fragments by ds_read_b64_tr_b16) and the rounds-1-2 kernel (V written
+    transposed, VG_ATT_TR=0; the switch is read per call) run the same MFMAs on the same operands: outputs bit-identical."""
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    W, H, T, n_crops = 768, 12, 197, 9
+    ld = 3 * W + 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.zeros(n_crops * T, ld, dtype=torch.float16)
+    qkv[:, :3 * W] = (torch.randn(n_crops * T, 3 * W, generator=g) * torch.tensor([1.5] * W + [1.0] * W + [2.0] * W)).half()
+    d_qkv = qkv.to(cuda)
+    outs = []
+    for tr in ('1', '0'):
+        monkeypatch.setenv('VG_ATT_TR', tr)
+        out = torch.zeros(n_crops * T, W, dtype=torch.float16, device=cuda)
+        check(lib.vg_attention(ptr(d_qkv), ptr(out), n_crops, T, W, H, ld, stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert outs[0].abs().max().item() > 0 and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
 def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
     """The fp16 tower (the benchmarked mode: fp16 GEMM operands / activations, fp32 accumulate, LayerNorm and residual stream
     in fp32) against the fp32 oracle (pinned to the reference's model.py) on crops the RENDERER produced -- through the

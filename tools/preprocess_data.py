@@ -100,8 +100,13 @@ def main(argv=None):
     if shard == 'auto':
         names = getattr(dataset, 'sequence_names', None)
         shard = 'sequences' if (world > 1 and names is not None and len(names) >= world) else 'frames'
-    if isinstance(dev, dict):
-        dev['shard'] = shard                                # (the stage dispatcher reads the resolved choice)
+    # the stage dispatcher reads the RESOLVED choice: written back into the config itself (cfg.get('device', {}) is a detached dict
+    # when the config has no device section, and the dispatcher's own default is 'auto', which it must never resolve on its own)
+    try:
+        dev['shard'] = shard
+        cfg['device'] = dev
+    except Exception:           # noqa: BLE001  (a read-only config object)
+        pass
     by_sequence = world > 1 and shard == 'sequences'
     logger.info(f'ranks: {world}; sharding: {shard}')
     if by_sequence:

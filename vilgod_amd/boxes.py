@@ -144,9 +144,14 @@ class BoxWorkerPool:
             try:
                 try:
                     status, val = self._exchange(self.procs[slot], req)
-                except (BrokenPipeError, EOFError, OSError, ValueError):
-                    # the helper died (or the pipe's framing is lost): a fresh child process, the request once more; if that fails
-                    # too the boxes are computed here, by the same function the helper runs
+                except (BrokenPipeError, EOFError, OSError, ValueError) as e1:
+                    # the helper died (or the pipe's framing is lost): a fresh child process, the request once more.  If that helper
+                    # dies too the request itself is what kills them (qhull on a degenerate cluster, memory): it must NOT be computed in
+                    # this -- the GPU pipeline's -- process, which the helpers exist to isolate; the caller gets a clear error.
+                    import logging
+                    log = logging.getLogger('vilgod_amd.boxes')
+                    log.warning('box helper %d ended (%s: %s); respawning and retrying a request of %d clusters',
+                                slot, type(e1).__name__, e1, len(req[1]) - 1)
                     try:
                         self.procs[slot].kill()
                     except Exception:       # noqa: BLE001
@@ -155,8 +160,18 @@ class BoxWorkerPool:
                     self.respawned += 1
                     try:
                         status, val = self._exchange(self.procs[slot], req)
-                    except (BrokenPipeError, EOFError, OSError, ValueError):
-                        status, val = 'ok', reference_boxes_packed(*req)
+                    except (BrokenPipeError, EOFError, OSError, ValueError) as e2:
+                        try:
+                            self.procs[slot].kill()
+                        except Exception:   # noqa: BLE001
+                            pass
+                        self.procs[slot] = self._spawn()
+                        self.respawned += 1
+                        log.error('box helper %d ended again on the same request (%d clusters, %d points): giving up on it', slot,
+                                  len(req[1]) - 1, len(req[0]))
+                        raise RuntimeError(f'reference box fit: two helper processes ended on the same request ({len(req[1]) - 1} clusters, '
+                                           f'{len(req[0])} points; {type(e2).__name__}: {e2}); run with device.box_workers=0 to fit in-process '
+                                           f"or device.box_mode='fast' for the GPU boxes") from e2
                 if status != 'ok':
                     raise RuntimeError(f'box helper process: {val}')
                 fut.set_result(val)

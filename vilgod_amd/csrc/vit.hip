@@ -807,37 +807,40 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     f16x8 qf[4], qn[4];
     uint4 kreg[4];
     f16x8 vreg[4];
+    // Per-lane element offsets inside an item, 32-bit and item-invariant (an item's rows span < T * ld elements): the item's base is a
+    // wave-uniform 64-bit pointer, so a load is SGPR base + VGPR offset and nothing 64-bit per lane lives across the item loop (the
+    // size_t row products did: 256 VGPRs + a spilled pair in the TR instantiation, round 3).
+    unsigned qoff[4], kvoff[4], ooff[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int qr = q0 + it * 8 + crow;
+        qoff[it] = (unsigned)((qr < T ? qr : T - 1) * ld + cpart * 8);
+        ooff[it] = (unsigned)(qr * W + cpart * 8);
+        const int c = tid + it * 448, key = c >> 3, part = c & 7;
+        kvoff[it] = (unsigned)((key < T ? key : T - 1) * ld + part * 8);
+    }
     auto fetch = [&](int item) {
         const int crop = item / heads, head = item - crop * heads;
         const f16* qbase = qkv + (size_t)crop * T * ld + head * 64;
         const f16* kbase = qbase + W;
         const f16* vbase = qbase + 2 * W;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int qr = q0 + it * 8 + crow;
-            qn[it] = *(const f16x8*)(qbase + (size_t)(qr < T ? qr : T - 1) * ld + cpart * 8);
-        }
+        for (int it = 0; it < 4; ++it) qn[it] = *(const f16x8*)(qbase + qoff[it]);
+        // K and V rows: eight lanes cover one 128-byte row (clamped row, zeroed by select when written to LDS).  For V the transpose
+        // (TR = false) happens on the LDS-write side, 2-way bank-conflicted.  One key per lane (conflict-free writes, but 64 rows x 16 B
+        // per load instruction) kept the waves that issue last waiting ~3.5 k cycles per item on the address path: 151 -> 146 us per
+        // launch; a 16-key x 64-byte pattern (conflict-free writes, 16 rows per instruction) measured 149 us.
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = tid + it * 448, key = c >> 3, part = c & 7;
-            kreg[it] = *(const uint4*)(kbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
-        }
-        // V rows are fetched like the K rows (eight lanes cover one 128-byte row); the transpose happens on the LDS-write side,
-        // 2-way bank-conflicted.  One key per lane (conflict-free writes, but 64 rows x 16 B per load instruction) kept the waves
-        // that issue last waiting ~3.5 k cycles per item on the address path: 151 -> 146 us per launch; a 16-key x 64-byte
-        // pattern (conflict-free writes, 16 rows per instruction) measured 149 us.
+        for (int it = 0; it < 4; ++it) kreg[it] = *(const uint4*)(kbase + kvoff[it]);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int c = tid + it * 448, key = c >> 3, part = c & 7;
-            vreg[it] = *(const f16x8*)(vbase + (size_t)(key < T ? key : T - 1) * ld + part * 8);
-        }
+        for (int it = 0; it < 4; ++it) vreg[it] = *(const f16x8*)(vbase + kvoff[it]);
     };
     int item = blockIdx.x;
     if (item < n_items) fetch(item);
     for (; item < n_items; item += gridDim.x) {
     if (TRACE) tc = clock64();
     const int crop = item / heads, head = item - crop * heads;
-    const size_t row0 = (size_t)crop * T;
+    f16* const obase = out + (size_t)crop * T * W + head * 64;
     // K -> LDS rows (zero beyond T)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     for (int it = 0; it < 4; ++it) {
         const int qr = q0 + it * 8 + crow;
         const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
-        if (qr < T) *(f16x8*)(out + (row0 + qr) * (size_t)W + head * 64 + cpart * 8) = v;
+        if (qr < T) *(f16x8*)(obase + ooff[it]) = v;
     }
     }
     AT_STAMP(6)                                                        // scaled output (waits for the O^T MFMAs) + stores issued
@@ -1674,7 +1677,7 @@ static int gemm_chunk_tiles_256(int ntn) {
 //   * 160 KB of LDS do not hold two K-step-64 rings of X AND W.  In a 4-wave workgroup every W row is read by exactly ONE wave
 //     (wave wn owns columns [64 wn, +64)), so W does not need LDS at all: each lane loads its own MFMA fragments from global
 //     memory (L2-resident weights; 16 rows x 64 B per instruction), one K-tile ahead, straight into registers.  X (read by all four
-//     waves) goes through a 3-stage LDS ring (3 x 16 KB) filled by LDS-DMA as before.  96 KB per CU.
+//     waves) goes through a 4-stage LDS ring (X2_NST x 16 KB) filled by LDS-DMA as before: 66.5 KB static per workgroup, ~133 KB per CU.
 //   * The fragment reads are software-pipelined across K-tiles: every MFMA group is followed by the ds_read of a fragment the
 //     group after next needs, so the only point a wave waits at is the one barrier per K-tile (placed after the last read of
 //     the current stage; the other workgroup's waves have the pipe meanwhile).
@@ -2100,7 +2103,8 @@ static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, i
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
     // ViT-B/16: row-major V + transposing LDS reads (VG_ATT_TR=0: the transposed V image of rounds 1-2; same numbers, 1.6 % slower)
-    static const bool tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);
+    const char* tr_env = getenv("VG_ATT_TR");           // read per call: tests run both paths in one process and compare them bit for bit
+    const bool tr = !(tr_env && atoi(tr_env) == 0);
     if (T == 197 && !TRACE && tr) {
         const dim3 grid7(items < 256 ? items : 256);
         VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true>), AT_LDS_BYTES_TR);
@@ -2404,7 +2408,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         // the n_crops class-token rows alone (compacted, padded to the row tile) instead of on n_crops x T rows: the same value
         // per element -- a row's dot products do not depend on which rows share its tile -- for 1 / T of the work.
         const int64_t Mc_ = pad128(n_crops);
-        const bool cls_fits = Mc_ * W * 16 + Mc_ * (W / 256) * 8 <= Mp * (3 * W + 256) * es;      // the compact buffers live in the qkv buffer
+        const bool cls_fits = Mc_ * W * 16 + Mc_ * (W / 64) * 8 <= Mp * (3 * W + 256) * es;       // the compact buffers live in the qkv buffer
+                                                                                                   // (statistics sized like vg_vit_workspace_bytes: W / 64 partials per row, k_gemm_f16_x2's count)
         const bool cls_only = v->cls_last && fold && !rh && l == L - 1 && L > 1 && cls_fits;
         if (v->dtype == 1) {
             {

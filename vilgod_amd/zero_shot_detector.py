@@ -43,7 +43,14 @@ class ZeroShotDetector:
         self.lenght = dataset.sequence_length          # (sic) attribute name of the reference, :31
         self.rank, self.world_size = vdist.world()
         dev = cfg.get('device', {}) if hasattr(cfg, 'get') else {}
-        if dev.get('shard', 'auto') == 'sequences':         # (tools/preprocess_data.py resolves `auto` before it builds the detector)
+        shard = dev.get('shard', 'auto')
+        if self.world_size > 1 and shard not in ('frames', 'sequences'):
+            # `auto` depends on the number of sequences of the run, which only the caller knows (tools/preprocess_data.py resolves it
+            # and writes it back into cfg.device).  Guessing here could leave this rank sharding frames -- and waiting in collectives --
+            # while the caller deals whole sequences to the ranks: a hang.  Fail loudly instead.
+            raise ValueError(f"device.shard={shard!r} is unresolved with {self.world_size} ranks: pass 'frames' or 'sequences' "
+                             "(tools/preprocess_data.py resolves 'auto' before it builds the detector)")
+        if shard == 'sequences':
             self.rank, self.world_size = 0, 1            # whole sequences per rank (tools/preprocess_data.py): nothing is exchanged inside one
         if pipeline is None:
             margs = [t for t in cfg.pipeline if t['name'] == 'mask_ground_points']
