@@ -59,7 +59,11 @@ int vg_to_origin(const float* d_ego, const int32_t* d_point_cluster, int n, cons
  * out_kind 0: uint8 [n,224,224,3] (the arrays given to PIL)   1: f32 [n,3,224,224]   2: f16 same
  *          3: f32 [n,110,110], one channel of get_img()'s output before the resize (parity tests)
  *          4: f16 [n*196,768] patch rows (= im2col of kind 2 for 16x16 patches), the A operand of the ViT-B/16
- *             patch-embedding GEMM; vg_vit_encode input_kind 2 consumes it directly. */
+ *             patch-embedding GEMM; vg_vit_encode input_kind 2 consumes it directly.
+ *          5: f16 [n*196,256] SINGLE-CHANNEL patch rows: value = uint8 level / 256 (exact), column = i*16 + j.  The three channels of
+ *             a crop are one image (src/utils/mv_utils.py:36) and the per-channel normalisation (third_party/CLIP/clip/clip.py:79-86)
+ *             is affine, so vg_vit_encode input_kind 3 folds both into a K = 256 patch-embedding weight: a third of kind 4's bytes
+ *             (d_lut's normalisation entries are not read for this kind). */
 int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clusters, const float* d_view_rot,
                     int n_views, const float* d_lut, void* d_out, int out_kind, void* stream);
 
@@ -82,11 +86,18 @@ void vg_vit_destroy(vg_vit* v);
 /* one tensor by its reference state_dict name without the 'visual.' prefix (model.py:206-221,171-183);
  * h_data: HOST float32.  Synchronous (hipMalloc + copy); not on the per-frame path. */
 int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t numel);
+/* The per-channel input normalisation (x / 255 - mean_c) / std_c that input_kind 3 folds into the patch embedding; HOST float[3] each.
+ * Default: CLIP's preprocess constants (third_party/CLIP/clip/clip.py:85). */
+int vg_vit_set_input_norm(vg_vit* v, const float* h_mean3, const float* h_std3);
 /* bytes of device workspace for n_crops; the caller zero-fills it once. */
 int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops);
 /* d_crops: [n,3,res,res] CHW, input_kind 0 = float32, 1 = float16 (what vg_render_crops out_kind 1/2
  * writes); input_kind 2 = f16 patch rows [n*(res/patch)^2, 3*patch^2] (vg_render_crops out_kind 4, fp16 mode only;
- * row count must be padded by the caller to a multiple of 256 rows of readable memory).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
+ * row count must be padded by the caller to a multiple of 256 rows of readable memory); input_kind 3 = f16 single-channel patch rows
+ * [n*(res/patch)^2, patch^2] holding level / 256 (vg_render_crops out_kind 5, fp16 mode, patch^2 % 128 == 0): the patch embedding
+ * (model.py:223-226 after clip.py:79-86's Normalize) runs as a K = patch^2 GEMM on W1[n,p] = 256/255 sum_c conv1[n,c,p] / std_c with
+ * the constant - sum_c mean_c / std_c sum_p conv1[n,c,p] added through the positional table; built once per handle at the first such
+ * encode (allocates and synchronises: not inside a stream capture).  d_feat: [n,out_dim] float32 = encode_image output (before normalisation). */
 int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                   void* stream);
 /* Measurement hooks (bench.py `roofline`): HIP event pairs around every projection-GEMM launch of

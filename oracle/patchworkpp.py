@@ -57,13 +57,18 @@ def load():
         _lib.pw_get_patch_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.pw_eig3.argtypes = [ctypes.c_void_p] * 3
         _lib.pw_default_params.argtypes = [ctypes.c_void_p]
+        _lib.pw_set_numeric_model.argtypes = [ctypes.c_void_p, ctypes.c_int]
     return _lib
 
 
 class patchworkpp:
-    def __init__(self, params):
+    def __init__(self, params, numeric_model=0):
+        """numeric_model: 0 = float64 fixed-order sums (default; what the HIP kernels reproduce bit for bit), 1 / 2 = the float32
+        two-pass arithmetic of patchworkpp.cpp:55-62 with scalar / 8-lane summation order (sensitivity study, see the .cpp header)."""
         self._lib = load()
         self._h = ctypes.c_void_p(self._lib.pw_create(ctypes.byref(params)))
+        if self._lib.pw_set_numeric_model(self._h, int(numeric_model)):
+            raise ValueError(f'numeric_model {numeric_model}')
         self._pts = None
         self._mask = None
 

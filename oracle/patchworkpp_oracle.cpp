@@ -22,6 +22,15 @@
 //   * the 3x3 decomposition is a cyclic Jacobi eigen-solver in float64 (8 sweeps), eigenvalues sorted
 //     descending, results rounded to float32 (normal_, singular_values_ are VectorXf in the reference)
 //   * everything is compiled with -ffp-contract=off.
+//
+// Round 4: two further numeric models, selectable per object with pw_set_numeric_model (default 0 = the model above, which the HIP
+// kernels reproduce).  They restate what patchworkpp.cpp:55-62 asks Eigen for -- float32 throughout: column means, the centred
+// matrix, centred^T * centred, the division by n - 1, a float 3x3 decomposition -- with the two summation orders a build of Eigen
+// plausibly uses:  1 = element after element (scalar code),  2 = eight running partial sums combined at the end (an AVX packet
+// reduction).  Neither is claimed to be Eigen bit for bit (its reduction order depends on the build's SIMD width, JacobiSVD has its
+// own sweep rule); they exist to MEASURE how far the ground set and the adaptive state move when the plane arithmetic changes from
+// "float, order A" to "float, order B" to "double, fixed order" -- i.e. what a user switching from pypatchworkpp can expect, and
+// what two builds of the reference itself differ by (tests/test_ground.py::test_oracle_numeric_models_bound).
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -159,6 +168,84 @@ void estimate_plane(const Sums9& S, int n, Plane& pl) {
     pl.d = -(double)dot;                                                                            // :75
 }
 
+// ---- float32 models (numeric_model 1 / 2) -------------------------------------------------------
+inline float fsum(const float* v, int n, int stride, int model) {
+    if (model == 1) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += v[(size_t)i * stride];
+        return s;
+    }
+    float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < n; ++i) l[i & 7] += v[(size_t)i * stride];
+    return ((l[0] + l[4]) + (l[2] + l[6])) + ((l[1] + l[5]) + (l[3] + l[7]));
+}
+inline float fdot(const float* a, const float* b, int n, int model) {          // columns of the centred [n,3] matrix (stride 3)
+    if (model == 1) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += a[(size_t)i * 3] * b[(size_t)i * 3];
+        return s;
+    }
+    float l[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < n; ++i) l[i & 7] += a[(size_t)i * 3] * b[(size_t)i * 3];
+    return ((l[0] + l[4]) + (l[2] + l[6])) + ((l[1] + l[5]) + (l[3] + l[7]));
+}
+// cyclic Jacobi in float32 (the decomposition of a float matrix, patchworkpp.cpp:62), same rotation order as eig3
+void eig3f(const float A_in[3][3], float w[3], float V[3][3]) {
+    float A[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = A_in[i][j]; V[i][j] = (i == j) ? 1.f : 0.f; }
+    const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int r = 0; r < 3; ++r) {
+            const int p = P[r], q = Q[r];
+            const float apq = A[p][q];
+            if (!(fabsf(apq) > 1e-37f)) continue;
+            const float theta = (A[q][q] - A[p][p]) / (2.0f * apq);
+            const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+            const float c = 1.f / sqrtf(t * t + 1.f), sn = t * c;
+            const float app = A[p][p], aqq = A[q][q];
+            A[p][p] = app - t * apq;
+            A[q][q] = aqq + t * apq;
+            A[p][q] = A[q][p] = 0.f;
+            const int k = 3 - p - q;
+            const float akp = A[k][p], akq = A[k][q];
+            A[k][p] = A[p][k] = c * akp - sn * akq;
+            A[k][q] = A[q][k] = sn * akp + c * akq;
+            for (int i = 0; i < 3; ++i) {
+                const float vip = V[i][p], viq = V[i][q];
+                V[i][p] = c * vip - sn * viq;
+                V[i][q] = sn * vip + c * viq;
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+    const int a[3] = {0, 0, 1}, b[3] = {1, 2, 2};
+    for (int r = 0; r < 3; ++r) {
+        const int i = a[r], j = b[r];
+        if (w[i] < w[j]) {
+            float tw = w[i]; w[i] = w[j]; w[j] = tw;
+            for (int m = 0; m < 3; ++m) { float tv = V[m][i]; V[m][i] = V[m][j]; V[m][j] = tv; }
+        }
+    }
+}
+// estimate_plane, patchworkpp.cpp:48-76, in float32 as written there: xyz = the selected points [n,3] in selection order
+void estimate_plane_f32(std::vector<float>& xyz, int model, Plane& pl) {
+    const int n = (int)(xyz.size() / 3);
+    if (n == 0) return;                                                          // :50
+    float mean[3];
+    for (int c = 0; c < 3; ++c) mean[c] = fsum(xyz.data() + c, n, 3, model) / (float)n;     // colwise().mean(), :57
+    for (int i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) xyz[(size_t)i * 3 + c] -= mean[c];   // centered, :57
+    const float dn1 = (float)(double)(n - 1);                                    // `/ double(rows - 1)` on a float matrix, :58
+    float C[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = a; b < 3; ++b) C[a][b] = C[b][a] = fdot(xyz.data() + a, xyz.data() + b, n, model) / dn1;
+    float w[3], V[3][3];
+    eig3f(C, w, V);
+    for (int i = 0; i < 3; ++i) { pl.mean[i] = mean[i]; pl.sv[i] = fabsf(w[i]); pl.normal[i] = V[i][2]; }
+    if (pl.normal[2] < 0) for (int i = 0; i < 3; ++i) pl.normal[i] = -pl.normal[i];
+    float dot = (pl.normal[0] * pl.mean[0] + pl.normal[1] * pl.mean[1]) + pl.normal[2] * pl.mean[2];
+    pl.d = -(double)dot;
+}
+
 // calc_point_to_plane_d, patchworkpp.cpp:552-555 (float products and sums, then + double d)
 inline double plane_dist(const Plane& pl, float x, float y, float z) {
     float f = (pl.normal[0] * x + pl.normal[1] * y) + pl.normal[2] * z;
@@ -186,6 +273,8 @@ struct Oracle {
     std::vector<double> upd_flat[4], upd_elev[4];
     // per-patch diagnostics of the last frame (504 x {n, n_ground, normal, mean, sv, decision})
     std::vector<float> patch_info;
+    int numeric_model = 0;     // 0: float64 SUM256 one-pass (what the HIP kernels reproduce); 1 / 2: float32 two-pass, scalar / 8-lane order
+    std::vector<float> sel;    // the selected points of one plane fit (models 1 / 2)
 
     explicit Oracle(const PwParams& pp) : p(pp) {           // patchworkpp.h:116-146
         double z2 = (7 * p.min_range + p.max_range) / 8.0;
@@ -275,9 +364,14 @@ struct Oracle {
                         for (int it = 0; it < p.num_iter; ++it) {
                             double thr = seed_threshold(zone, P, alive, p.th_seeds_v);
                             acc->clear(); int cnt = 0;
+                            sel.clear();
                             for (int i = 0; i < np; ++i)
-                                if (alive[i] && (double)P[i].z < thr) { acc->add(i, P[i].x, P[i].y, P[i].z); cnt++; }
-                            estimate_plane(acc->finish(), cnt, pl);
+                                if (alive[i] && (double)P[i].z < thr) {
+                                    if (numeric_model) { sel.push_back(P[i].x); sel.push_back(P[i].y); sel.push_back(P[i].z); }
+                                    else acc->add(i, P[i].x, P[i].y, P[i].z);
+                                    cnt++;
+                                }
+                            if (numeric_model) estimate_plane_f32(sel, numeric_model, pl); else estimate_plane(acc->finish(), cnt, pl);
                             if (zone == 0 && (double)pl.normal[2] < p.uprightness_thr) {
                                 for (int i = 0; i < np; ++i)
                                     if (alive[i] && fabs(plane_dist(pl, P[i].x, P[i].y, P[i].z)) < p.th_dist_v) alive[i] = 0;
@@ -287,22 +381,30 @@ struct Oracle {
                     {
                         double thr = seed_threshold(zone, P, alive, p.th_seeds);
                         acc->clear(); int cnt = 0;
+                        sel.clear();
                         for (int i = 0; i < np; ++i)
-                            if (alive[i] && (double)P[i].z < thr) { acc->add(i, P[i].x, P[i].y, P[i].z); cnt++; }
-                        estimate_plane(acc->finish(), cnt, pl);
+                            if (alive[i] && (double)P[i].z < thr) {
+                                if (numeric_model) { sel.push_back(P[i].x); sel.push_back(P[i].y); sel.push_back(P[i].z); }
+                                else acc->add(i, P[i].x, P[i].y, P[i].z);
+                                cnt++;
+                            }
+                        if (numeric_model) estimate_plane_f32(sel, numeric_model, pl); else estimate_plane(acc->finish(), cnt, pl);
                     }
                     std::vector<int> dst;
                     for (int it = 0; it < p.num_iter; ++it) {
                         acc->clear(); int cnt = 0;
                         dst.clear();
+                        sel.clear();
                         for (int i = 0; i < np; ++i) {
                             if (!alive[i]) continue;
                             if (plane_dist(pl, P[i].x, P[i].y, P[i].z) < p.th_dist) {
-                                acc->add(i, P[i].x, P[i].y, P[i].z); cnt++;
+                                if (numeric_model) { sel.push_back(P[i].x); sel.push_back(P[i].y); sel.push_back(P[i].z); }
+                                else acc->add(i, P[i].x, P[i].y, P[i].z);
+                                cnt++;
                                 if (it == p.num_iter - 1) dst.push_back(P[i].idx);
                             }
                         }
-                        estimate_plane(acc->finish(), cnt, pl);
+                        if (numeric_model) estimate_plane_f32(sel, numeric_model, pl); else estimate_plane(acc->finish(), cnt, pl);
                     }
                     // ---- GLE, :212-283 ----
                     const double uprightness = pl.normal[2], elevation = pl.mean[2];
@@ -392,6 +494,14 @@ void pw_destroy(void* h) { delete (Oracle*)h; }
  * ground_mask: [n] 1 = ground (the index set getGround() returns, pointcloud_utils.py:53-56). */
 void pw_estimate(void* h, const float* pts, int n, int stride, uint8_t* ground_mask) {
     ((Oracle*)h)->estimate(pts, n, stride, ground_mask);
+}
+
+/* numeric model of the plane fits (see the header): 0 = float64 SUM256 (default; the HIP kernels' model), 1 = float32 two-pass with
+ * element-after-element sums, 2 = float32 two-pass with eight running partial sums.  Returns 0, or 1 for an unknown model. */
+int pw_set_numeric_model(void* h, int model) {
+    if (model < 0 || model > 2) return 1;
+    ((Oracle*)h)->numeric_model = model;
+    return 0;
 }
 
 /* adaptive state after the last frame: sensor_height, elevation_thr[4], flatness_thr[4], sizes of the 8 stores */

@@ -250,3 +250,23 @@ def test_hip_patch16_output_equals_im2col_of_f16_crops(cuda, golden):
     assert not patches[n * 196:].any()
     enc = VitEncoder(cw.synthetic_vit_weights(0, **cw.VIT_B16), dtype='f16', device=cuda)
     assert torch.equal(enc.encode(crops), enc.encode_patches(patches, n))
+
+
+@pytest.mark.gpu
+def test_hip_single_channel_patch_rows_equal_the_uint8_crops(cuda, golden):
+    """out='patch16c1' (the default renderer -> tower hand-over since round 4): row crop*196 + py*14 + px, column i*16 + j holds
+    level / 256 of pixel (py*16 + i, px*16 + j) -- EXACTLY the uint8 crop the reference hands to PIL (every channel of it: the three
+    are one image, mv_utils.py:36), no normalisation applied; padding rows zero."""
+    from vilgod_amd.projection import RealisticProjection
+    g = golden
+    clusters = [g[f'pts_{i}'] for i in range(n_cases(g))]
+    pts, seg = _pack(clusters, cuda)
+    proj = RealisticProjection({}, device=cuda)
+    u8 = proj.render_frame(pts, None, seg, np.eye(4), out='u8')                 # [n,224,224,3]
+    rows = proj.render_frame(pts, None, seg, np.eye(4), out='patch16c1')
+    n = u8.shape[0]
+    assert rows.shape == ((n * 196 + 255) // 256 * 256, 256) and rows.dtype == torch.float16
+    assert torch.equal(u8[..., 0], u8[..., 1]) and torch.equal(u8[..., 0], u8[..., 2])
+    want = (u8[..., 0].float() / 256.0).reshape(n, 14, 16, 14, 16).permute(0, 1, 3, 2, 4).reshape(n * 196, 256)
+    assert torch.equal(rows[:n * 196].float(), want)
+    assert not rows[n * 196:].any()

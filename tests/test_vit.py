@@ -194,10 +194,12 @@ def test_hip_attention_transposing_reads_equal_transposed_image(cuda, monkeypatc
 
 
 @pytest.mark.gpu
-def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
+@pytest.mark.parametrize('rows', ['patch16c1', 'patch16'])
+def test_hip_vit_b16_f16_error_on_rendered_crops(cuda, rows):
     """The fp16 tower (the benchmarked mode: fp16 GEMM operands / activations, fp32 accumulate, LayerNorm and residual stream
     in fp32) against the fp32 oracle (pinned to the reference's model.py) on crops the RENDERER produced -- through the
-    production path (patch rows written by the renderer, no CHW crop in between).  north_star's tolerance for the fp32 path is
+    production path (patch rows written by the renderer, no CHW crop in between: 'patch16c1' = single-channel rows + the folded
+    K = 256 patch embedding, the default; 'patch16' = three normalised channels, K = 768).  north_star's tolerance for the fp32 path is
     1e-3 on the probabilities; the fp16 mode is asserted at <= 2e-3 max probability error and <= 1e-3 relative L2 feature
     error (measured ~6e-4 / ~3.5e-4), top-1 identical wherever the oracle's margin exceeds twice that bound."""
     from vilgod_amd import synthetic
@@ -225,7 +227,7 @@ def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
     proj = RealisticProjection(dict(depth_bias=0.2, obj_ratio=0.8, bg_clr=0.0, resolution=112, depth=8,
                                     gaussian_kernel=dict(sigma=3, zsigma=1)), device=cuda)
     crops32 = proj.render_frame(d_X, d_index, d_seg, np.eye(4), out='f32')
-    patches = proj.render_frame(d_X, d_index, d_seg, np.eye(4), out='patch16')
+    patches = proj.render_frame(d_X, d_index, d_seg, np.eye(4), out=rows)
     n = crops32.shape[0]
     assert n == 24 and float(crops32.std()) > 0.05
     wd = cw.synthetic_vit_weights(0, **cw.VIT_B16)
@@ -237,7 +239,7 @@ def test_hip_vit_b16_f16_error_on_rendered_crops(cuda):
     f, probs, top1 = f.cpu(), probs.cpu(), top1.cpu().numpy()
     rel = ((f - f_want).norm() / f_want.norm()).item()
     perr = (probs - p_want).abs().max().item()
-    print(f'f16 tower on {n} rendered crops: feature rel L2 {rel:.2e}, max prob err {perr:.2e}')
+    print(f'f16 tower on {n} rendered crops ({rows}): feature rel L2 {rel:.2e}, max prob err {perr:.2e}')
     assert rel <= 1e-3 and perr <= 1e-3            # north_star's bound for the fp32 logits, met by the fp16 tower too (measured 4-6e-4)
     srt = np.sort(p_want.numpy(), axis=1)
     sure = (srt[:, -1] - srt[:, -2]) > 4e-3

@@ -33,6 +33,9 @@ class VitEncoder:
         check(lib.vg_vit_create(ctypes.byref(h), cfg['width'], cfg['layers'], cfg['heads'], cfg['patch'],
                                 cfg['resolution'], cfg['output_dim'], DTYPES[dtype]), 'vg_vit_create')
         self._h = h
+        # the per-channel normalisation the single-channel patch rows fold into the patch embedding: the renderer's own constants
+        from .projection import CLIP_MEAN, CLIP_STD
+        check(lib.vg_vit_set_input_norm(h, (ctypes.c_float * 3)(*CLIP_MEAN), (ctypes.c_float * 3)(*CLIP_STD)), 'vg_vit_set_input_norm')
         with torch.cuda.device(self.device):
             for name, t in weights.items():
                 t = t.detach().to(torch.float32).contiguous().cpu()
@@ -94,12 +97,14 @@ class VitEncoder:
 
 
 def _encode_patches(self, patches, n, stream=None):
-    """patches: f16 [rows>=n*196 (multiple of 256), 768] from RealisticProjection.render_frame(out='patch16')."""
-    assert patches.is_cuda and patches.dtype == torch.float16 and self.dtype == 'f16'
+    """patches: f16 [rows>=n*196 (multiple of 256), 768] from RealisticProjection.render_frame(out='patch16'), or [rows, 256]
+    single-channel rows from out='patch16c1' (the tower folds the three identical channels and their normalisation, input_kind 3)."""
+    assert patches.is_cuda and patches.dtype == torch.float16 and self.dtype == 'f16' and patches.shape[1] in (768, 256)
     feat = torch.empty((n, self.cfg['output_dim']), dtype=torch.float32, device=patches.device)
     if n:
         ws = self._workspace(n)
-        check(lib.vg_vit_encode(self._h, ptr(patches), 2, n, ptr(ws), ptr(feat), stream_ptr(stream)), 'vg_vit_encode')
+        kind = 2 if patches.shape[1] == 768 else 3
+        check(lib.vg_vit_encode(self._h, ptr(patches), kind, n, ptr(ws), ptr(feat), stream_ptr(stream)), 'vg_vit_encode')
     return feat
 
 
@@ -116,9 +121,10 @@ class GraphClassifier:
                         # graph per exact count would be captured (~150 nodes + instantiate) for most frames.  The rows of the
                         # padding crops hold finite data of an earlier frame; their outputs are never read (<= 7 crops of ~330: ~1 %)
 
-    def __init__(self, encoder, text_features, max_crops=512, max_graphs=32):
-        assert encoder.dtype == 'f16' and encoder.cfg['patch'] == 16 and encoder.cfg['resolution'] == 224
+    def __init__(self, encoder, text_features, max_crops=512, max_graphs=32, patch_width=256):
+        assert encoder.dtype == 'f16' and encoder.cfg['patch'] == 16 and encoder.cfg['resolution'] == 224 and patch_width in (256, 768)
         self.enc, self.text = encoder, text_features
+        self.patch_width = int(patch_width)          # 256: single-channel rows (render 'patch16c1', input_kind 3); 768: 'patch16
         self.device = encoder.device
         self.max_graphs = int(max_graphs)
         self._cache = ctypes.c_void_p()
@@ -137,7 +143,7 @@ class GraphClassifier:
         self.cap = (int(n) + self.BUCKET - 1) // self.BUCKET * self.BUCKET
         rows = (self.cap * 196 + 255) // 256 * 256
         K = self.text.shape[0]
-        self.patches = torch.zeros((rows, 768), dtype=torch.float16, device=self.device)
+        self.patches = torch.zeros((rows, self.patch_width), dtype=torch.float16, device=self.device)
         self.ws = torch.zeros(int(lib.vg_vit_workspace_bytes(self.enc._h, self.cap)), dtype=torch.uint8, device=self.device)
         self.feat = torch.empty((self.cap, self.enc.cfg['output_dim']), dtype=torch.float32, device=self.device)
         self.probs = torch.empty((self.cap, K), dtype=torch.float32, device=self.device)
@@ -162,7 +168,7 @@ class GraphClassifier:
             assert text_features.shape == self.text.shape
             self.text = text_features                # (its pointer is part of the graph key: new features -> new graphs)
         nb = min(self.cap, (n + self.BUCKET - 1) // self.BUCKET * self.BUCKET)
-        check(lib.vg_vit_classify_graph(self.enc._h, self._cache, ptr(self.patches), 2, nb, ptr(self.ws), ptr(self.feat), ptr(self.text),
+        check(lib.vg_vit_classify_graph(self.enc._h, self._cache, ptr(self.patches), 2 if self.patch_width == 768 else 3, nb, ptr(self.ws), ptr(self.feat), ptr(self.text),
                                         self.feat.shape[1], self.text.shape[0], ptr(self.probs), ptr(self.top1), ptr(self.score),
                                         stream_ptr()), 'vg_vit_classify_graph')
         return self.probs[:n], self.top1[:n], self.score[:n]

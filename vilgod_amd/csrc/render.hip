@@ -184,6 +184,10 @@ struct RenderArgs {
                            // 3: f32 [n,110,110] = one channel of get_img() before the resize
                            // 4: f16 patch rows [n*196, 768] = the im2col of kind 2 for 16x16 patches (ViT-B/16 input of
                            //    the patch-embedding GEMM: row = crop*196 + py*14 + px, column = ch*256 + i*16 + j)
+                           // 5: f16 SINGLE-CHANNEL patch rows [n*196, 256]: column = i*16 + j, value = uint8 level * 2^-8 (exact in fp16).
+                           //    The three channels of a crop are the same image (mv_utils.py:36) and differ only by the per-channel
+                           //    normalisation (clip.py:79-86), which is affine: vg_vit_encode input_kind 3 folds it and the channel sum
+                           //    into a K = 256 conv1 weight + a per-feature constant.  A third of kind 4's bytes.
 };
 
 __device__ __forceinline__ void quantise_point(float px, float py, float pz, const float* pc, float prange,
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
             iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
             u[e] = (unsigned char)iv;
         }
-        if (a.out_kind == 4) {
+        if (a.out_kind >= 4) {
             // patch rows: stage the quantised image in LDS (the 112 x 112 float slice buffer is free now and holds exactly
             // 224 x 224 bytes); the stores happen below in OUTPUT order so that they leave as whole 128-byte lines
             *(unsigned int*)((unsigned char*)S + i * OUT + j0) = (unsigned int)u[0] | ((unsigned int)u[1] << 8) | ((unsigned int)u[2] << 16) |
@@ -483,6 +487,25 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
             *(uint2*)(ob + (size_t)p * 768 + rem * 4) = pk;
         }
     }
+    if (a.out_kind == 5) {
+        // single-channel patch rows: 64 items of 4 pixels per patch row, so one wave instruction writes one whole 512-byte row
+        __syncthreads();
+        const unsigned char* U = (const unsigned char*)S;
+        __half* ob = (__half*)a.out + crop * 196 * 256;
+        for (int q = tid; q < 196 * 64; q += RT) {
+            const int p = q >> 6, rem = q & 63;
+            const int pi = rem >> 2, pj4 = rem & 3;
+            const int py = p / 14, px = p - py * 14;
+            const unsigned int u4 = *(const unsigned int*)(U + (py * 16 + pi) * OUT + px * 16 + pj4 * 4);
+            const float sc = 0.00390625f;                               // 2^-8: level / 256 is exact in fp16
+            __half2 h01 = __floats2half2_rn((float)(u4 & 255u) * sc, (float)((u4 >> 8) & 255u) * sc);
+            __half2 h23 = __floats2half2_rn((float)((u4 >> 16) & 255u) * sc, (float)(u4 >> 24) * sc);
+            uint2 pk;
+            pk.x = *(unsigned int*)&h01;
+            pk.y = *(unsigned int*)&h23;
+            *(uint2*)(ob + (size_t)p * 256 + rem * 4) = pk;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -529,7 +552,7 @@ int vg_to_origin(const float* d_ego, const int32_t* d_point_cluster, int n, cons
 int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clusters, const float* d_view_rot,
                     int n_views, const float* d_lut, void* d_out, int out_kind, void* stream) {
     if (n_clusters <= 0 || n_views <= 0) return VG_OK;
-    if (!d_origin || !d_seg_off || !d_view_rot || !d_lut || !d_out || out_kind < 0 || out_kind > 4)
+    if (!d_origin || !d_seg_off || !d_view_rot || !d_lut || !d_out || out_kind < 0 || out_kind > 5)
         return VG_ERR_ARG;
     const size_t lds_bytes = (size_t)(GR * GR + GR * GO) * sizeof(float);
     VG_MAX_DYNAMIC_LDS(k_render, lds_bytes);

@@ -1123,6 +1123,7 @@ struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
     bool gemm_x2 = getenv("VG_GEMM_X2") ? atoi(getenv("VG_GEMM_X2")) != 0 : false;   // projection GEMMs by k_gemm_f16_x2 (two workgroups per CU)
     bool cls_last = !(getenv("VG_VIT_CLS_LAST") && atoi(getenv("VG_VIT_CLS_LAST")) == 0);   // last block: class-token rows only (see vg_vit_encode)
+    bool gemm_ri = !(getenv("VG_GEMM_RI") && atoi(getenv("VG_GEMM_RI")) == 0);             // residual GEMMs: accumulators start from the residual tile (k_gemm_f16_pp64 RI; 0 = read-modify-write epilogue)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1139,6 +1140,10 @@ struct vg_vit {
     // "#c1", "#c2" and are rebuilt when any of their inputs is set again.
     bool ln_fold = false;
     std::atomic<bool> fold_ready{false}, warmed{false};
+    // single-channel patch rows (vg_vit_encode input_kind 3): per-channel input normalisation the fold assumes (clip.py:79-86; set by
+    // vg_vit_set_input_norm) and the readiness of "conv1.weight#1ch" / "positional_embedding#1ch" (vit_fold_conv1)
+    float in_mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, in_std[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    std::atomic<bool> conv1_ready{false};
     // bumped whenever a device tensor the kernels read is replaced (vg_vit_set_weight, vit_fold_ln): part of the captured graphs'
     // key, so a graph that holds pointers to freed weights is never replayed
     std::atomic<uint64_t> weights_gen{0};
@@ -1367,7 +1372,14 @@ __device__ __forceinline__ float row256_sum(float v) {          // sum over the 
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 
-template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
+// RI ("residual as the accumulators' initial value", EPI_BIAS_RESID only, round 4): every lane loads the residual elements of its
+// accumulator registers -- a float4 per 16 x 16 block: four consecutive features of one token -- in the PROLOGUE, in front of the first
+// LDS-DMA pieces, whose landing the wave waits for anyway; the MFMAs then accumulate on top of the residual and the epilogue is
+// write-only (stage, full-row stores of the fp32 stream, the fp16 copy and the row statistics).  Without it the epilogue is two
+// dependent rounds of {8 residual loads, wait, add, store} per 128-row half with the matrix pipe idle: 35 k cycles per tile against
+// 7 k for a write-only fp16 tile.  The sum is resid + sum_k x w (fp32, the residual rounded into the chain first) + bias instead of
+// (sum_k x w + bias) + resid: fp32 rounding order only.
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0, bool RI = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
@@ -1422,11 +1434,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
         }
     };
     f32x4 acc[TN][TM];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r15 = lane & 15, q4 = lane >> 4;
+    if (RI && EPI == EPI_BIAS_RESID) {
+        // lane (r15, q4), block (ni, mi): token m0 + grp*128 + mi*16 + r15, features n0 + wn*64 + ni*16 + 4*q4 .. +3
+        const float* rp = resid + (size_t)(m0 + grp * 128 + r15) * ldc + n0 + wn * 64 + 4 * q4;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = *(const f32x4*)(rp + (size_t)mi * 16 * ldc + ni * 16);
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int swz = (r15 >> 1) & 7;
     const int xo0 = (grp * 128 + r15) * 128 + ((q4 ^ swz) << 4), xo1 = (grp * 128 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int wo0 = (wn * 64 + r15) * 128 + ((q4 ^ swz) << 4), wo1 = (wn * 64 + r15) * 128 + (((4 + q4) ^ swz) << 4);
@@ -1449,6 +1470,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     issue_x(0);
     if (grp == 1) { issue_w(0, 0); issue_w(1, 0); } else issue_w(0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RI && EPI == EPI_BIAS_RESID) {
+        // the loads were issued in front of the pieces: landed.  Tell the compiler's wait-count bookkeeping HERE (a use of every
+        // accumulator), so that it does not place a wait for them in front of the K loop's first MFMA, where it would merge into a
+        // per-iteration vmcnt that drains the LDS-DMA pieces in flight (guide section 5, "mixing load kinds in one k-loop")
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(acc[ni][mi]));
+    }
     if (LN == 1 && tid < BM) {                     // the partials were requested before the first pieces: no extra wait here
         float ms = 0.f, m2 = 0.f;
 #pragma unroll
@@ -1609,7 +1639,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
             for (int p8 = 0; p8 < 2; ++p8) {
                 // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
                 float4 x4[8];
-                if (EPI == EPI_BIAS_RESID) {
+                if (EPI == EPI_BIAS_RESID && !RI) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int m = (p8 * 8 + q) * 8 + rr;
@@ -1622,7 +1652,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
                     float4 v = *(const float4*)(smem + m * 1024 + j * 16);
                     const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
                     if (EPI == EPI_BIAS_RESID) {
-                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
+                        if (!RI) { v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w; }
                         *(float4*)(resid + off) = v;
                         if (LN == 2) {
                             // this wave holds the row's 256 columns of the tile: fp16 copy for the next GEMM + the row's partial statistics
@@ -1978,14 +2008,14 @@ static int launch_gemm_x2(const void* X, const void* Wt, const float* bias, void
     return VG_OK;
 }
 
-template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0, bool RI = false>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
                             f16* ln_x16 = nullptr) {
     if (M % 256 || N % 256 || K % 64 || K / 64 < 2) return VG_ERR_ARG;
     if (LN == 1 && (K % 256 || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
     if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST, LN>;
+    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST, LN, RI>;
     const int lds = 5 * 32768;
     VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
@@ -2079,6 +2109,10 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                 if (v->gemm_x2 && K % 256 == 0 && (LN != 1 || K / 64 <= X2_LN_MAXP))
                     return launch_gemm_x2<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
                 if (v->gemm_x2 && LN != 0) return VG_ERR_ARG;       // (the two kernels keep different partial statistics)
+                if constexpr (EPI == EPI_BIAS_RESID) {
+                    if (v->gemm_ri)       // residual tile as the accumulators' initial value, write-only epilogue (k_gemm_f16_pp64, RI)
+                        return launch_gemm_pp64<EPI, false, false, LN, true>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
+                }
                 return launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
             }
         }
@@ -2198,7 +2232,76 @@ static int vit_fold_ln(vg_vit* v, hipStream_t st) {
     return VG_OK;
 }
 
+// Single-channel patch embedding (mv_utils.py:36: the three channels of a rendered crop are one image).  With the crop's
+// uint8 level u, channel c of the reference's input is (u / 255 - mean_c) / std_c (clip.py:79-86), so
+//   conv1(x)[n] = sum_p (u_p / 256) * W1[n,p] + b1[n],   W1[n,p] = (256 / 255) * sum_c conv1[n,c,p] / std_c,
+//                                                        b1[n]   = - sum_c (mean_c / std_c) * sum_p conv1[n,c,p]
+// -- exact in real arithmetic; the renderer hands over u / 256 (exact in fp16), W1 is rounded to fp16 once from the fp32 sum.
+// b1 is added to the positional embedding of the 196 patch tokens (k_embed_lnpre adds that table to the GEMM's rows anyway).
+// One workgroup per output feature n, fixed summation order, double accumulation.
+__global__ __launch_bounds__(256) void k_conv1_fold(const float* __restrict__ conv1, const float* __restrict__ pos, f16* __restrict__ W1,
+                                                    float* __restrict__ pos1, int W, int T, int pp, float m0, float m1, float m2,
+                                                    float s0, float s1, float s2) {
+    __shared__ double sh[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* w = conv1 + (size_t)n * 3 * pp;
+    double acc = 0.0;
+    for (int p = tid; p < pp; p += 256) {
+        const double a = (double)w[p], b = (double)w[pp + p], c = (double)w[2 * pp + p];
+        W1[(size_t)n * pp + p] = (f16)(float)((256.0 / 255.0) * (a / (double)s0 + b / (double)s1 + c / (double)s2));
+        acc += a * ((double)m0 / (double)s0) + b * ((double)m1 / (double)s1) + c * ((double)m2 / (double)s2);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    const float b1 = (float)(-sh[0]);
+    for (int t = tid; t < T; t += 256) pos1[(size_t)t * W + n] = pos[(size_t)t * W + n] + (t > 0 ? b1 : 0.f);
+}
+
+/* Derived tensors of the single-channel patch embedding, once per handle (again after conv1.weight / positional_embedding /
+ * the input normalisation changed).  Allocates and synchronises like vit_fold_ln: not inside a stream capture. */
+static int vit_fold_conv1(vg_vit* v, hipStream_t st) {
+    if (v->conv1_ready.load()) return VG_OK;
+    std::lock_guard<std::mutex> lock(v->mtx);
+    if (v->conv1_ready.load()) return VG_OK;
+    auto it32 = v->w32.find("conv1.weight");
+    const float* pos = (const float*)vit_w(v, "positional_embedding");
+    if (v->dtype != 1 || it32 == v->w32.end() || !pos) return VG_ERR_ARG;
+    const int W = v->width, pp = v->patch * v->patch;
+    for (const char* nm : {"conv1.weight#1ch", "positional_embedding#1ch"}) {
+        auto old = v->w.find(nm);
+        if (old != v->w.end()) { (void)hipFree(old->second); v->w.erase(old); }
+    }
+    void *w1 = nullptr, *p1 = nullptr;
+    VG_CHECK(hipMalloc(&w1, (size_t)W * pp * 2));
+    VG_CHECK(hipMalloc(&p1, (size_t)v->T * W * 4));
+    hipLaunchKernelGGL(k_conv1_fold, dim3(W), dim3(256), 0, st, (const float*)it32->second, pos, (f16*)w1, (float*)p1, W, v->T, pp,
+                       v->in_mean[0], v->in_mean[1], v->in_mean[2], v->in_std[0], v->in_std[1], v->in_std[2]);
+    VG_LAUNCH_CHECK();
+    v->w["conv1.weight#1ch"] = w1;
+    v->w["positional_embedding#1ch"] = p1;
+    VG_CHECK(hipStreamSynchronize(st));
+    v->weights_gen.fetch_add(1);
+    v->conv1_ready.store(true);
+    return VG_OK;
+}
+
 extern "C" {
+
+/* per-channel input normalisation (x / 255 - mean_c) / std_c that the single-channel patch rows (input_kind 3) fold into the patch
+ * embedding; default: CLIP's constants (clip.py:79-86). */
+int vg_vit_set_input_norm(vg_vit* v, const float* h_mean3, const float* h_std3) {
+    if (!v || !h_mean3 || !h_std3) return VG_ERR_ARG;
+    for (int c = 0; c < 3; ++c) {
+        if (!(h_std3[c] > 0.f)) return VG_ERR_ARG;
+        v->in_mean[c] = h_mean3[c]; v->in_std[c] = h_std3[c];
+    }
+    v->conv1_ready.store(false);
+    return VG_OK;
+}
 
 int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int resolution, int out_dim, int dtype) {
     if (!out || width % 128 || width > 1024 || heads * 64 != width || resolution % patch || dtype < 0 || dtype > 1)
@@ -2236,6 +2339,17 @@ int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t 
     if (it != v->w.end()) {
         (void)hipFree(it->second);
         v->w.erase(it);
+    }
+    if (v->dtype == 1 && (n == "conv1.weight" || n == "positional_embedding")) {
+        v->conv1_ready.store(false);             // the single-channel patch embedding's derived tensors are rebuilt at the next encode
+        if (n == "conv1.weight") {
+            auto o = v->w32.find(n);
+            if (o != v->w32.end()) { (void)hipFree(o->second); v->w32.erase(o); }
+            void* d32 = nullptr;
+            VG_CHECK(hipMalloc(&d32, (size_t)numel * 4));
+            VG_CHECK(hipMemcpy(d32, h_data, (size_t)numel * 4, hipMemcpyHostToDevice));
+            v->w32[n] = d32;
+        }
     }
     if (v->ln_fold && n.find("transformer.resblocks.") == 0) {
         v->fold_ready.store(false);              // a block's tensor changed: the folded LayerNorm tensors are rebuilt at the next encode
@@ -2295,8 +2409,9 @@ int64_t vg_vit_workspace_bytes(const vg_vit* v, int n_crops) {
 /* input_kind 0: f32 CHW crops [n,3,res,res]; 1: f16 CHW crops; d_feat: [n,out_dim] f32 */
 int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, void* d_workspace, float* d_feat,
                   void* stream) {
-    if (!v || !d_crops || !d_workspace || !d_feat || n_crops <= 0 || input_kind < 0 || input_kind > 2) return VG_ERR_ARG;
-    if (input_kind == 2 && v->dtype != 1) return VG_ERR_ARG;
+    if (!v || !d_crops || !d_workspace || !d_feat || n_crops <= 0 || input_kind < 0 || input_kind > 3) return VG_ERR_ARG;
+    if (input_kind >= 2 && v->dtype != 1) return VG_ERR_ARG;
+    if (input_kind == 3 && (v->patch * v->patch) % 128) return VG_ERR_ARG;       // K of the folded patch embedding: two 64-wide K-tiles at least
     hipStream_t st = (hipStream_t)stream;
     const int W = v->width, T = v->T, L = v->layers, H = v->heads;
     const int64_t M = (int64_t)n_crops * T, Mp = pad128(M), es = v->dtype == 1 ? 2 : 4;
@@ -2316,6 +2431,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     f16* x16 = (f16*)ws;              if (fold) ws += Mp * W * 2;
     LnPartial* lnst = (LnPartial*)ws;
     if (fold) { const int frc = vit_fold_ln(v, st); if (frc) return frc; }
+    if (input_kind == 3) { const int frc = vit_fold_conv1(v, st); if (frc) return frc; }
 
     auto need = [&](const std::string& n) -> void* {
         auto it = v->w.find(n);
@@ -2329,7 +2445,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             return VG_ERR_ARG;
         }
     // im2col (skipped when the renderer already wrote patch rows)
-    if (input_kind == 2) patches = const_cast<void*>(d_crops);
+    if (input_kind >= 2) patches = const_cast<void*>(d_crops);
     else {
         int blocks = (int)((P * Kp + 255) / 256);
         if (blocks > 65535 * 8) blocks = 65535 * 8;
@@ -2346,14 +2462,18 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         }
         VG_LAUNCH_CHECK();
     }
-    int rc = launch_gemm<EPI_NONE_F32>(v, patches, need("conv1.weight"), nullptr, pe, nullptr, (int)Pp, W, (int)Kp, st);
+    // input_kind 3: single-channel patch rows [P, patch^2] times the folded K = patch^2 weight; its constant rides in the positional table
+    const float* pos_tab = (const float*)need(input_kind == 3 ? "positional_embedding#1ch" : "positional_embedding");
+    int rc = input_kind == 3 ? launch_gemm<EPI_NONE_F32>(v, patches, need("conv1.weight#1ch"), nullptr, pe, nullptr, (int)Pp, W, v->patch * v->patch, st)
+                             : launch_gemm<EPI_NONE_F32>(v, patches, need("conv1.weight"), nullptr, pe, nullptr, (int)Pp, W, (int)Kp, st);
     if (rc) return rc;
+    if (!pos_tab) return VG_ERR_ARG;
     const bool rh = v->resid_h;
     bool ln1_done = false;
     f16* xh = (f16*)x;                // the residual stream lives in the same workspace region, as fp16 when `rh`
     if (rh)
         hipLaunchKernelGGL((k_embed_lnpre<f16>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
-                           (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
+                           pos_tab, (const float*)need("ln_pre.weight"),
                            (const float*)need("ln_pre.bias"), xh, (int)M, T, W, (int)Mp);
     else {
         // fp16 tower: ln_1 of block 0 is computed by the same kernel (writes h next to x)
@@ -2362,7 +2482,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         const float* lb1 = ln1_done ? (const float*)need("transformer.resblocks.0.ln_1.bias") : nullptr;
         if (ln1_done && (!lw1 || !lb1)) return VG_ERR_ARG;
         hipLaunchKernelGGL((k_embed_lnpre<float>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
-                           (const float*)need("positional_embedding"), (const float*)need("ln_pre.weight"),
+                           pos_tab, (const float*)need("ln_pre.weight"),
                            (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp, lw1, lb1, ln1_done ? (f16*)h : (f16*)nullptr);
     }
     VG_LAUNCH_CHECK();
@@ -2670,11 +2790,12 @@ int vg_vit_classify_graph(vg_vit* v, vg_graph_cache* c, const void* d_crops, int
     if (!v || !c || n_crops <= 0 || !stream) return VG_ERR_ARG;          // capture needs a real (non-default) stream
     // the first encode of a process runs as plain launches: it sets the kernels' dynamic-LDS attributes (hipFuncSetAttribute), which
     // must not happen inside a capture
-    // (per handle, and the other threads wait for it: it also builds the handle's derived tensors, vit_fold_ln)
-    if (!v->warmed.load() || (v->ln_fold && !v->fold_ready.load())) {
+    // (per handle, and the other threads wait for it: it also builds the handle's derived tensors, vit_fold_ln / vit_fold_conv1)
+    const auto cold = [&]() { return !v->warmed.load() || (v->ln_fold && !v->fold_ready.load()) || (input_kind == 3 && !v->conv1_ready.load()); };
+    if (cold()) {
         static std::mutex warm_mtx;
         std::lock_guard<std::mutex> lock(warm_mtx);
-        if (!v->warmed.load() || (v->ln_fold && !v->fold_ready.load())) {
+        if (cold()) {
             int rc = vg_vit_encode(v, d_crops, input_kind, n_crops, d_workspace, d_feat, stream);
             if (!rc) rc = vg_clip_scores(d_feat, n_crops, dim, d_text, n_classes, d_probs, d_top1, d_top1_score, stream);
             if (!rc) VG_CHECK(hipStreamSynchronize((hipStream_t)stream));

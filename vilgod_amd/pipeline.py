@@ -102,6 +102,7 @@ class PseudoLabelPipeline:
         # (clip_wrapper.GraphClassifier).  Off by default: with several frames in flight the launch overhead is already hidden
         # (bench.py `hipgraph_loop`: captured == plain launches within noise) and a real stream keeps meeting new crop counts.
         self.vit_graph = bool(vit_graph)
+        self.patch_1ch = os.environ.get('VILGOD_PATCH_1CH', '1') != '0'      # renderer -> tower hand-over as single-channel patch rows
         self._graph_cls = None
         self._ground_stream = None
         # frames in flight: the ViT passes of the workers take turns in arrival order (see classify); shared by the worker clones
@@ -385,18 +386,21 @@ class PseudoLabelPipeline:
         enc = self.clip.encoder
         if self.vit_dtype == 'f16' and enc.cfg['patch'] == 16 and enc.cfg['resolution'] == 224:
             # the renderer writes the patch-embedding GEMM's A operand directly (no CHW crops, no im2col pass)
+            # (single-channel rows by default: the crop's three channels are one image, the tower folds their normalisation into a
+            # K = 256 patch embedding -- a third of the bytes the renderer writes and the GEMM reads; VILGOD_PATCH_1CH=0: 768-wide rows)
             from .clip_wrapper import clip_scores, GraphClassifier
+            pmode = 'patch16c1' if self.patch_1ch else 'patch16'
             if self.vit_graph and n > 0 and torch.cuda.current_stream(self.device).cuda_stream != 0:
                 # captured loop: the ViT encode + scores replay as one hipGraph (per crop count) on this worker's persistent buffers;
                 # the outputs are cloned because the buffers are rewritten by the worker's next frame
                 if self._graph_cls is None:
-                    self._graph_cls = GraphClassifier(enc, self.clip.text_features, max_crops=max(512, n))
+                    self._graph_cls = GraphClassifier(enc, self.clip.text_features, max_crops=max(512, n), patch_width=256 if self.patch_1ch else 768)
                 g = self._graph_cls
-                self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16', out_buf=g.patch_buffer(n))
+                self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out=pmode, out_buf=g.patch_buffer(n))
                 with self._vit_in_turn():
                     probs, top1, score = g.classify(n, self.clip.text_features)
                 return probs.clone(), top1.clone(), score.clone()
-            patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='patch16')
+            patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out=pmode)
             with self._vit_in_turn():
                 return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
         crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='f16' if self.vit_dtype == 'f16' else 'f32')

@@ -18,7 +18,7 @@ from ._lib import lib, ptr, stream_ptr, check
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # third_party/CLIP/clip/clip.py:85
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
-OUT_U8, OUT_F32, OUT_F16, OUT_RAW110, OUT_PATCH16 = 0, 1, 2, 3, 4
+OUT_U8, OUT_F32, OUT_F16, OUT_RAW110, OUT_PATCH16, OUT_PATCH16_1CH = 0, 1, 2, 3, 4, 5
 
 # the 4 views hard-coded at mv_utils.py:134-141 plus the two commented-out ones (:139-140) that
 # make up the 2x3 grid of waymo.yaml:97-102 (BASELINE config "6-view render")
@@ -88,7 +88,7 @@ class RealisticProjection:
         index: [Ptot] int32 packed cluster point indices (cluster after cluster) or None;
         seg_off: [C+1] int32 CUDA; transform_to_ego: 4x4 float64 (numpy or tensor).
         Returns crops for all C*V (cluster-major, like torch.cat of get_img results)."""
-        kind = {'u8': OUT_U8, 'f32': OUT_F32, 'f16': OUT_F16, 'raw110': OUT_RAW110, 'patch16': OUT_PATCH16}[out]
+        kind = {'u8': OUT_U8, 'f32': OUT_F32, 'f16': OUT_F16, 'raw110': OUT_RAW110, 'patch16': OUT_PATCH16, 'patch16c1': OUT_PATCH16_1CH}[out]
         dev = points.device
         n_clusters = seg_off.numel() - 1
         ptot = int(index.numel()) if index is not None else int(points.shape[0])
@@ -100,17 +100,20 @@ class RealisticProjection:
             result = torch.empty((n, 3, 224, 224), dtype=torch.float32, device=dev)
         elif kind == OUT_F16:
             result = torch.empty((n, 3, 224, 224), dtype=torch.float16, device=dev)
-        elif kind == OUT_PATCH16:
+        elif kind in (OUT_PATCH16, OUT_PATCH16_1CH):
             # ViT-B/16 patch rows; rows padded to the GEMM's 256-row tile (padding rows are never written: zeros, or -- in a
-            # caller-owned persistent buffer `out_buf` -- finite rows of an earlier frame; GEMM rows are independent)
+            # caller-owned persistent buffer `out_buf` -- finite rows of an earlier frame; GEMM rows are independent).
+            # 'patch16c1': ONE channel per row (256 columns, level / 256): the crop's three channels are the same image
+            # (mv_utils.py:36); the tower folds the per-channel normalisation into its patch embedding (vg_vit_encode input_kind 3)
             rows = (n * 196 + 255) // 256 * 256
+            width = 768 if kind == OUT_PATCH16 else 256
             if out_buf is not None:
-                assert out_buf.dtype == torch.float16 and out_buf.shape[1] == 768 and out_buf.shape[0] >= rows
+                assert out_buf.dtype == torch.float16 and out_buf.shape[1] == width and out_buf.shape[0] >= rows
                 result = out_buf
             else:
                 # the renderer writes every one of the n * 196 patch rows: only the <= 255 rows of tile padding need zeros
                 # (a zero-fill of the whole buffer was 96 MB per frame)
-                result = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+                result = torch.empty((rows, width), dtype=torch.float16, device=dev)
                 result[n * 196:].zero_()
         else:
             result = torch.empty((n, 110, 110), dtype=torch.float32, device=dev)
