@@ -361,7 +361,8 @@ def test_hip_folded_layernorm_follows_a_replaced_weight(cuda):
 
 
 @pytest.mark.gpu
-def test_hip_captured_classification_equals_plain_launches(cuda):
+@pytest.mark.parametrize('width', [256, 768])
+def test_hip_captured_classification_equals_plain_launches(cuda, width):
     """BASELINE config 5's hipGraph loop: vg_vit_classify_graph (one captured graph per crop count, replayed) returns bit for bit
     what the plain launches of vg_vit_encode + vg_clip_scores return, for new crop counts (capture) and repeated ones (replay),
     on a worker stream with persistent buffers."""
@@ -370,13 +371,16 @@ def test_hip_captured_classification_equals_plain_launches(cuda):
     text = cw.synthetic_text_features(0, 24, 512).to(cuda)
     enc = VitEncoder(wd, dtype='f16', device=cuda)
     plain = enc.view()
-    g = GraphClassifier(enc, text, max_crops=16)
+    g = GraphClassifier(enc, text, max_crops=16, patch_width=width)       # 256: single-channel rows (level / 256), 768: normalised channels
     gen = torch.Generator().manual_seed(5)
     stream = torch.cuda.Stream(device=cuda)
     with torch.cuda.stream(stream):
         for n in [5, 9, 5, 16, 9, 5, 20]:                     # 20 > capacity: buffers grow, graphs are rebuilt
             rows = (n * 196 + 255) // 256 * 256
-            p = (torch.randn(rows, 768, generator=gen) * 0.8).half().to(cuda)
+            if width == 768:
+                p = (torch.randn(rows, 768, generator=gen) * 0.8).half().to(cuda)
+            else:
+                p = (torch.randint(0, 256, (rows, 256), generator=gen).float() / 256.0).half().to(cuda)
             g.patch_buffer(n)[:rows].copy_(p)
             probs, top1, score = [t.clone() for t in g.classify(n)]
             want = clip_scores(plain.encode_patches(p, n), text)

@@ -826,8 +826,13 @@ __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
     return ((unsigned long long)lo << 32) | hi;
 }
 
-template <int DIM>
-__global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
+// NT: threads per workgroup.  The walk is bound by its longest dependent chain, not by a CU's resources, and its workgroup's size decides
+// how many CUs a launch OCCUPIES: a CU that holds any wave of this kernel cannot take a projection-GEMM tile of another frame's ViT pass
+// (that workgroup needs all 160 KB of LDS and every vector register), and the dispatcher deals workgroups round-robin over the CUs:
+// 309 workgroups of 256 threads sit on all 256 CUs for the launch's ~300 us, 155 of 512 threads on 155 (two waves per SIMD either way:
+// 172 registers, 88 KB of stack per CU).  FAR: the far_list / far_flag entry paths of the cooperative search (development build).
+template <int DIM, int NT = 256, bool FAR = false>
+__global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                      const ClGrid* __restrict__ gp, const int* __restrict__ cs,
                                                      const int* __restrict__ cell_comp, const unsigned int* __restrict__ cell_e,
                                                      const int* __restrict__ perm,
@@ -840,12 +845,13 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
                                                      double* __restrict__ pt_lb, int* __restrict__ dbg_scan, const int* __restrict__ flags,
                                                      const int* __restrict__ far_list, const int* __restrict__ far_flag) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
-    __shared__ unsigned int stack[CL_STACK * 256];
+    __shared__ unsigned int stack[CL_STACK * NT];
     // far_list != NULL: only the queries the cooperative search (k_cl_b_search_blk) could not finish inside its shell, each
     // starting from the best edge it found there (pt_w / pt_d / pt_key / pt_b hold it; pt_b = -1: none)
     // (far_flag instead of far_list: the same queries, but each in the lane its point index maps to -- 64 hard walks packed into
     // one wave diverge and run one after the other, spread over all waves they run side by side)
     int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!FAR) { far_list = nullptr; far_flag = nullptr; }
     if (far_list) {
         if (a >= flags[4]) return;
         a = far_list[a];
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
         sp = 1;
         while (sp > 0) {
             int l, x, y, z;
-            cl_unpack(st[(--sp) * 256], l, x, y, z);
+            cl_unpack(st[(--sp) * NT], l, x, y, z);
             // every edge into this node weighs at least lb; it must be able to tie or beat both bounds (ALU only)
             const double nd2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
             const double lb = fmax(lb_a, nd2);
@@ -1043,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
 #pragma unroll
                 for (int v = 1; v < 8; ++v) { lo_i = ch == v ? bnd[v] : lo_i; hi_i = ch == v ? bnd[v + 1] : hi_i; }
                 const bool keep = lo_i != hi_i && !(clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) && sp < CL_STACK;
-                st[sp * 256] = cl_pack(l1, 2 * x + hx, 2 * y + hy, 2 * z + hz);      // (slot sp is free: written, kept only if counted)
+                st[sp * NT] = cl_pack(l1, 2 * x + hx, 2 * y + hy, 2 * z + hz);      // (slot sp is free: written, kept only if counted)
                 sp += keep ? 1 : 0;
             }
         }
@@ -1065,6 +1071,7 @@ __global__ __launch_bounds__(256) void k_cl_b_search(const float4* __restrict__ 
     }
 }
 
+#ifdef VG_DEV      // measured slower than the walk alone: kept for the A/B tools only, untested in the product
 // Cooperative nearest-foreign search of a Boruvka round (same layout as k_cl_core_blk: one wave per (0.8 m node, 64 queries),
 // lane = query, the 27 neighbour nodes staged in LDS by coalesced loads: coordinates as float64, component id, squared core
 // distance, original id).  A lane keeps the best edge (w, d2, key) it has met under the walk's strict order.  Everything outside
@@ -1222,6 +1229,7 @@ __global__ __launch_bounds__(64) void k_cl_b_search_blk(const float4* __restrict
 }
 
 // per component: smallest w (atomicMin in the search), then smallest d2 among those, then smallest id key among those
+#endif  // VG_DEV
 __global__ void k_cl_b_select_d(int n, const int* __restrict__ comp, const unsigned long long* __restrict__ best_w,
                                 const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_d,
                                 unsigned long long* __restrict__ best_d, const int* __restrict__ flags) {
@@ -1546,26 +1554,35 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
 }
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
-    // VG_CLUSTER_SEARCH_MODE (A/B aid): 0 = the tree walk alone, 1 = cooperative search, leftovers walk as a compacted list,
-    // 2 = cooperative search, leftovers walk in place.  Default 0: measured on 150k-point frames the cooperative search + the
-    // leftover walks take longer than the walk alone
+    // VG_CLUSTER_SEARCH_NT (A/B aid): threads per workgroup of the walk, 256 or 512 (default: see k_cl_b_search)
+    const char* nt_env = getenv("VG_CLUSTER_SEARCH_NT");          // (read per launch: the A/B tool switches it inside one process)
+    const int nt = nt_env ? atoi(nt_env) : 512;
+#ifdef VG_DEV
+    // VG_CLUSTER_SEARCH_MODE (A/B aid, development build): 0 = the tree walk alone, 1 = cooperative search, leftovers walk as a compacted
+    // list, 2 = cooperative search, leftovers walk in place.  Measured on 150k-point frames the cooperative search + the leftover walks
+    // take longer than the walk alone
     static const int mode = getenv("VG_CLUSTER_SEARCH_MODE") ? atoi(getenv("VG_CLUSTER_SEARCH_MODE")) : 0;
     static const int core_walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;  // (no work list then)
-    if (mode == 0 || core_walk) {
-        const int nthreads = n;
-        hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(nthreads, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+    if (mode != 0 && !core_walk) {
+        hipLaunchKernelGGL((k_cl_b_search_blk<DIM>), dim3(std::min(n, 16384)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
+                           h->d_code_s, h->d_entries, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_pt_key,
+                           h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, h->d_far, mode == 2 ? h->d_far_flag : (int*)nullptr);
+        // the queries left over walk the tree from the edge they hold
+        hipLaunchKernelGGL((k_cl_b_search<DIM, 256, true>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
+                           mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr);
         return;
     }
-    hipLaunchKernelGGL((k_cl_b_search_blk<DIM>), dim3(std::min(n, 16384)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
-                       h->d_code_s, h->d_entries, h->d_cell_comp, h->d_perm, h->d_core2, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_pt_key,
-                       h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, h->d_far, mode == 2 ? h->d_far_flag : (int*)nullptr);
-    // the queries left over walk the tree from the edge they hold
-    hipLaunchKernelGGL((k_cl_b_search<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                       h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                       h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
-                       mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr);
+#endif
+    if (nt == 512)
+        hipLaunchKernelGGL((k_cl_b_search<DIM, 512>), dim3(vg_div_up(n, 512)), dim3(512), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((k_cl_b_search<DIM, 256>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
 }
 
 extern "C" {

@@ -1123,7 +1123,6 @@ struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
     bool gemm_x2 = getenv("VG_GEMM_X2") ? atoi(getenv("VG_GEMM_X2")) != 0 : false;   // projection GEMMs by k_gemm_f16_x2 (two workgroups per CU)
     bool cls_last = !(getenv("VG_VIT_CLS_LAST") && atoi(getenv("VG_VIT_CLS_LAST")) == 0);   // last block: class-token rows only (see vg_vit_encode)
-    bool gemm_ri = !(getenv("VG_GEMM_RI") && atoi(getenv("VG_GEMM_RI")) == 0);             // residual GEMMs: accumulators start from the residual tile (k_gemm_f16_pp64 RI; 0 = read-modify-write epilogue)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1372,14 +1371,12 @@ __device__ __forceinline__ float row256_sum(float v) {          // sum over the 
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 
-// RI ("residual as the accumulators' initial value", EPI_BIAS_RESID only, round 4): every lane loads the residual elements of its
-// accumulator registers -- a float4 per 16 x 16 block: four consecutive features of one token -- in the PROLOGUE, in front of the first
-// LDS-DMA pieces, whose landing the wave waits for anyway; the MFMAs then accumulate on top of the residual and the epilogue is
-// write-only (stage, full-row stores of the fp32 stream, the fp16 copy and the row statistics).  Without it the epilogue is two
-// dependent rounds of {8 residual loads, wait, add, store} per 128-row half with the matrix pipe idle: 35 k cycles per tile against
-// 7 k for a write-only fp16 tile.  The sum is resid + sum_k x w (fp32, the residual rounded into the chain first) + bias instead of
-// (sum_k x w + bias) + resid: fp32 rounding order only.
-template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0, bool RI = false>
+// Measured and dropped (round 4): "RI" -- every lane loads the residual elements of its accumulator registers in the prologue, in
+// front of the first LDS-DMA pieces, the MFMAs accumulate on top and the epilogue is write-only.  Launches interleaved on one box at
+// M = 66560: out_proj 188 vs 177 us and c_proj 382 vs 366 us with the residual stream out of the memory-side cache (as in the
+// pipeline), 157 vs 156 / 362 vs 360 with it cached; whole pipeline 65.1 vs 65.0 frames/s.  The residual epilogue is bound by the bytes
+// all CUs move at the same time (510 MB per launch), not by the latency of its load -> add -> store rounds.
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
@@ -1434,20 +1431,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
         }
     };
     f32x4 acc[TN][TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r15 = lane & 15, q4 = lane >> 4;
-    if (RI && EPI == EPI_BIAS_RESID) {
-        // lane (r15, q4), block (ni, mi): token m0 + grp*128 + mi*16 + r15, features n0 + wn*64 + ni*16 + 4*q4 .. +3
-        const float* rp = resid + (size_t)(m0 + grp * 128 + r15) * ldc + n0 + wn * 64 + 4 * q4;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) acc[ni][mi] = *(const f32x4*)(rp + (size_t)mi * 16 * ldc + ni * 16);
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     const int swz = (r15 >> 1) & 7;
     const int xo0 = (grp * 128 + r15) * 128 + ((q4 ^ swz) << 4), xo1 = (grp * 128 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int wo0 = (wn * 64 + r15) * 128 + ((q4 ^ swz) << 4), wo1 = (wn * 64 + r15) * 128 + (((4 + q4) ^ swz) << 4);
@@ -1470,15 +1458,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     issue_x(0);
     if (grp == 1) { issue_w(0, 0); issue_w(1, 0); } else issue_w(0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (RI && EPI == EPI_BIAS_RESID) {
-        // the loads were issued in front of the pieces: landed.  Tell the compiler's wait-count bookkeeping HERE (a use of every
-        // accumulator), so that it does not place a wait for them in front of the K loop's first MFMA, where it would merge into a
-        // per-iteration vmcnt that drains the LDS-DMA pieces in flight (guide section 5, "mixing load kinds in one k-loop")
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) asm volatile("" : "+v"(acc[ni][mi]));
-    }
     if (LN == 1 && tid < BM) {                     // the partials were requested before the first pieces: no extra wait here
         float ms = 0.f, m2 = 0.f;
 #pragma unroll
@@ -1639,7 +1618,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
             for (int p8 = 0; p8 < 2; ++p8) {
                 // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
                 float4 x4[8];
-                if (EPI == EPI_BIAS_RESID && !RI) {
+                if (EPI == EPI_BIAS_RESID) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int m = (p8 * 8 + q) * 8 + rr;
@@ -1652,7 +1631,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
                     float4 v = *(const float4*)(smem + m * 1024 + j * 16);
                     const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
                     if (EPI == EPI_BIAS_RESID) {
-                        if (!RI) { v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w; }
+                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
                         *(float4*)(resid + off) = v;
                         if (LN == 2) {
                             // this wave holds the row's 256 columns of the tile: fp16 copy for the next GEMM + the row's partial statistics
@@ -2008,14 +1987,14 @@ static int launch_gemm_x2(const void* X, const void* Wt, const float* bias, void
     return VG_OK;
 }
 
-template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0, bool RI = false>
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
                             f16* ln_x16 = nullptr) {
     if (M % 256 || N % 256 || K % 64 || K / 64 < 2) return VG_ERR_ARG;
     if (LN == 1 && (K % 256 || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
     if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST, LN, RI>;
+    auto kern = k_gemm_f16_pp64<EPI, TRACE, PERSIST, LN>;
     const int lds = 5 * 32768;
     VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
@@ -2109,10 +2088,6 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                 if (v->gemm_x2 && K % 256 == 0 && (LN != 1 || K / 64 <= X2_LN_MAXP))
                     return launch_gemm_x2<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
                 if (v->gemm_x2 && LN != 0) return VG_ERR_ARG;       // (the two kernels keep different partial statistics)
-                if constexpr (EPI == EPI_BIAS_RESID) {
-                    if (v->gemm_ri)       // residual tile as the accumulators' initial value, write-only epilogue (k_gemm_f16_pp64, RI)
-                        return launch_gemm_pp64<EPI, false, false, LN, true>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
-                }
                 return launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
             }
         }
