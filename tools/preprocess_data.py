@@ -112,6 +112,7 @@ def main(argv=None):
     if by_sequence:
         result_path.mkdir(parents=True, exist_ok=True)      # every rank writes the pickles of its own sequences
     starts = []                                             # (sequence number, offsets into detection_results / indices) of this rank's sequences
+    t_loop = time.perf_counter()
     for seq_no, sequence_name in enumerate(dataset.next_sequence()):
         if by_sequence and seq_no % world != rank:
             continue
@@ -161,6 +162,13 @@ def main(argv=None):
         gc.collect()
         torch.cuda.empty_cache()
 
+    # the last sequence's state pickle may still be on its way to disk (background writer, vilgod_amd/zero_shot_detector.py): the
+    # sequence loop -- and its clock -- ends when it has landed
+    from vilgod_amd import zero_shot_detector as _zsd
+    t_wait = time.perf_counter()
+    _zsd.wait_state_writes()
+    LAST_RUN['state_write_wait_seconds'] = time.perf_counter() - t_wait
+    LAST_RUN['loop_seconds'] = time.perf_counter() - t_loop
     if result_data is not None:
         detection_results = result_data
     elif by_sequence:

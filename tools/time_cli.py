@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
-"""Wall time of the entry point (tools/preprocess_data.py, default 9-stage list) on one synthetic sequence WITHOUT a Python profiler
+"""Wall time of the entry point (tools/preprocess_data.py, default 9-stage list) on synthetic sequences WITHOUT a Python profiler
 (tools/profile_cli.py runs under cProfile, which slows the host-heavy stages disproportionately).
-    python tools/time_cli.py [frames=199] [points=150000] [key=value ...]"""
+    [SEQUENCES=1] python tools/time_cli.py [frames=199] [points=150000] [key=value ...]"""
 import logging, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import preprocess_data  # noqa: E402
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 199
 points = int(sys.argv[2]) if len(sys.argv) > 2 else 150_000
+nseq = int(os.environ.get('SEQUENCES', '1'))
 with tempfile.TemporaryDirectory() as root:
     logging.disable(logging.INFO)
     preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}', f'dataset.SYNTHETIC.frames_per_sequence={frames}',
-                          f'dataset.SYNTHETIC.points_per_frame={points}', 'dataset.SYNTHETIC.n_sequences=1', 'end_sequence=0',
-                          f'device.max_points={points + 1024}', 'paths.clip_model=/nonexistent'] + sys.argv[3:])
-seq = preprocess_data.LAST_RUN['sequences'][0]
-print(f"frames {seq['frames']}  {1000 * seq['seconds'] / seq['frames']:.2f} ms per frame  ({seq['frames'] / seq['seconds']:.2f} frames/s)  " +
+                          f'dataset.SYNTHETIC.points_per_frame={points}', f'dataset.SYNTHETIC.n_sequences={nseq}', f'end_sequence={nseq - 1}',
+                          f'device.max_points={2 * points}', 'paths.clip_model=/nonexistent'] + sys.argv[3:])
+run = preprocess_data.LAST_RUN
+tot_f = sum(q['frames'] for q in run['sequences'])
+tot_s = sum(q['seconds'] for q in run['sequences']) + run.get('state_write_wait_seconds', 0.0)
+print(f"{len(run['sequences'])} sequence(s), {tot_f} frames: {1000 * tot_s / tot_f:.2f} ms per frame = {tot_f / tot_s:.2f} frames/s "
+      f"(sequence clocks + {run.get('state_write_wait_seconds', 0.0):.3f} s waiting for the last background state write)")
+for seq in run['sequences']:
+  print(f"frames {seq['frames']}  {1000 * seq['seconds'] / seq['frames']:.2f} ms per frame  ({seq['frames'] / seq['seconds']:.2f} frames/s)  " +
       '  '.join(f'{k} {v:.2f}' for k, v in seq['stage_ms_per_frame'].items()))
-if seq.get('detail_ms'):
+  if seq.get('detail_ms'):
     print('parts (ms per frame): ' + '  '.join(f"{k} {v / seq['frames']:.3f}" for k, v in seq['detail_ms'].items()))

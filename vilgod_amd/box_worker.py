@@ -1,6 +1,8 @@
-"""Helper process of box_mode='reference' (vilgod_amd/boxes.py): reads length-prefixed pickled requests
-(xy_packed [P,2] float32, seg, zmin, zmax) on stdin, answers the [C,7] boxes on stdout.  Imports numpy / scipy only -- never the
-GPU runtime.  Started by boxes.BoxWorkerPool as `python -m vilgod_amd.box_worker`; ends when stdin closes."""
+"""Helper process of box_mode='reference' (vilgod_amd/boxes.py): reads length-prefixed pickled requests on stdin, answers on stdout.
+  (xy_packed [P,2] float32, seg, zmin, zmax)                                   -> [C,7] static boxes (boxes.reference_boxes_packed)
+  ('moving_boxes', xyz_packed [P,3] float32, seg, directions, to_ego, centers3) -> [n,7] boxes of one moving track (tracking.moving_boxes)
+Imports numpy / scipy only -- never the GPU runtime.  Started by boxes.BoxWorkerPool as `python -m vilgod_amd.box_worker`; ends when
+stdin closes."""
 import pickle
 import struct
 import sys
@@ -8,6 +10,8 @@ import sys
 
 def main():
     from vilgod_amd.boxes import reference_boxes_packed
+    from vilgod_amd.tracking import moving_boxes_packed
+    named = {'moving_boxes': moving_boxes_packed}
     rd, wr = sys.stdin.buffer, sys.stdout.buffer
     while True:
         head = rd.read(8)
@@ -16,7 +20,7 @@ def main():
         (n,) = struct.unpack('<q', head)
         req = pickle.loads(rd.read(n))
         try:
-            ans = ('ok', reference_boxes_packed(*req))
+            ans = ('ok', named[req[0]](*req[1:]) if isinstance(req[0], str) else reference_boxes_packed(*req))
         except Exception as e:          # noqa: BLE001  (reported to the caller, which raises)
             ans = ('error', f'{type(e).__name__}: {e}')
         blob = pickle.dumps(ans, protocol=pickle.HIGHEST_PROTOCOL)

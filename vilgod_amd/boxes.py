@@ -150,8 +150,11 @@ class BoxWorkerPool:
                     # this -- the GPU pipeline's -- process, which the helpers exist to isolate; the caller gets a clear error.
                     import logging
                     log = logging.getLogger('vilgod_amd.boxes')
-                    log.warning('box helper %d ended (%s: %s); respawning and retrying a request of %d clusters',
-                                slot, type(e1).__name__, e1, len(req[1]) - 1)
+                    what = req[0] if isinstance(req[0], str) else 'static boxes'
+                    seg_ = req[2] if isinstance(req[0], str) else req[1]
+                    pts_ = req[1] if isinstance(req[0], str) else req[0]
+                    log.warning('box helper %d ended (%s: %s); respawning and retrying a request (%s, %d clusters)',
+                                slot, type(e1).__name__, e1, what, len(seg_) - 1)
                     try:
                         self.procs[slot].kill()
                     except Exception:       # noqa: BLE001
@@ -167,10 +170,10 @@ class BoxWorkerPool:
                             pass
                         self.procs[slot] = self._spawn()
                         self.respawned += 1
-                        log.error('box helper %d ended again on the same request (%d clusters, %d points): giving up on it', slot,
-                                  len(req[1]) - 1, len(req[0]))
-                        raise RuntimeError(f'reference box fit: two helper processes ended on the same request ({len(req[1]) - 1} clusters, '
-                                           f'{len(req[0])} points; {type(e2).__name__}: {e2}); run with device.box_workers=0 to fit in-process '
+                        log.error('box helper %d ended again on the same request (%s, %d clusters, %d points): giving up on it', slot,
+                                  what, len(seg_) - 1, len(pts_))
+                        raise RuntimeError(f'reference box fit: two helper processes ended on the same request ({what}, {len(seg_) - 1} clusters, '
+                                           f'{len(pts_)} points; {type(e2).__name__}: {e2}); run with device.box_workers=0 to fit in-process '
                                            f"or device.box_mode='fast' for the GPU boxes") from e2
                 if status != 'ok':
                     raise RuntimeError(f'box helper process: {val}')
@@ -243,6 +246,19 @@ def submit_reference_boxes(xy_host, index, seg, zmin, zmax, n_procs=4):
     if n_procs <= 0 or len(seg) <= 1:
         return _Done(reference_boxes_packed(xy_packed, seg, zmin, zmax))
     return _pool(n_procs).submit(xy_packed, seg, zmin, zmax)
+
+
+def submit_moving_boxes(points_list, directions, to_ego_list, centers3, n_procs=4):
+    """tracking.moving_boxes of ONE track in a helper process -> object with .result() -> [n,7].  The cluster points of the track's
+    entries travel packed ([P,3] float32 + offsets); everything is evaluated by the same function on the same numpy, so the boxes are
+    the ones the in-process call returns.  n_procs = 0 (or no pool): computed in the calling thread."""
+    from .tracking import moving_boxes, moving_boxes_packed
+    if n_procs <= 0:
+        return _Done(moving_boxes(points_list, directions, to_ego_list, centers3=centers3))
+    seg = np.r_[0, np.cumsum([len(p) for p in points_list])].astype(np.int64)
+    xyz = np.ascontiguousarray(np.concatenate([p[:, :3] for p in points_list]))
+    return _pool(n_procs).submit('moving_boxes', xyz, seg, np.asarray(directions), np.asarray(to_ego_list),
+                                 None if centers3 is None else np.asarray(centers3))
 
 
 def reference_boxes(xy_host, index, seg, zmin, zmax):

@@ -57,17 +57,17 @@ class EntropyScorer:
             need.add(f)
         return sorted(need)
 
-    def score_sequence(self, X_list, queries=None, mapper=None):
-        """X_list: per frame CUDA float32 [n,>=3] (`points_ref_wo_ground`; entries of frames that are not needed may be
-        None).  -> {fnr: float64 CUDA tensor [n] of entropy scores} for the `queries` (default: every frame; then a
-        list).  Every frame's grid is built once and queried by all the frames whose window contains it.
-        mapper(items, fn): runs fn(grid_model, item) for the items on several handles / streams at once
-        (PseudoLabelPipeline.map_workers); target frames are independent, every (query, column) row has one writer."""
+    def plan(self, X_list, queries=None):
+        """The work of `score_sequence` laid out so that it can also run piecewise (the stage dispatcher streams it through the frame
+        pass): per-query count buffers, the spatially coherent query order, and for every TARGET frame j the (query, row) pairs that
+        count their neighbours in it.  -> dict."""
         L = len(X_list)
         as_list = queries is None
         queries = list(range(L)) if queries is None else sorted(queries)
         wins = {f: window(f, L, self.n_neighbouring_frames) for f in queries}
         used = {f: wins[f][0][::self.skip] for f in queries}         # pointcloud_utils.py:81 idx_list[::skip]
+        if any(len(u) < 2 for u in used.values()):
+            raise NotImplementedError('entropy scores need at least two neighbouring frames')
         # queries run in a spatially coherent order (4 x 4-cell columns of the 0.4 m grid): a wave's 64 query points then read the
         # same few cells of the target grid, whatever order the data set stores its points in; the scores are put back at the end
         order = {f: spatial_order(X_list[f]) for f in queries}
@@ -78,27 +78,39 @@ class EntropyScorer:
         for f in queries:
             for col, j in enumerate(used[f]):
                 users.setdefault(j, []).append((f, col))
-        def one_target(model, j):
-            model.grid(X_list[j])
-            for f, col in users[j]:
-                model.ball_count(Xq[f], self.r2, self.cap, out=counts[f][col])
+        return dict(X_list=X_list, L=L, as_list=as_list, queries=queries, wins=wins, used=used, order=order, Xq=Xq, counts=counts, users=users)
 
+    def run_target(self, model, plan, j):
+        """Grid of target frame j (on `model`'s handle, current stream) and the neighbour counts of every query frame whose window holds it."""
+        model.grid(plan['X_list'][j])
+        for f, col in plan['users'][j]:
+            model.ball_count(plan['Xq'][f], self.r2, self.cap, out=plan['counts'][f][col])
+
+    def finish_query(self, plan, f):
+        """Entropy scores of query frame f once all targets of its window have run: float64 CUDA [n] in the frame's point order."""
+        frames, seek = plan['wins'][f]
+        used = plan['used'][f]
+        seek_row = used.index(frames[seek]) if frames[seek] in used else -1
+        X = plan['X_list'][f]
+        n = X.shape[0]
+        H = torch.empty(n, dtype=torch.float64, device=X.device)
+        check(lib.vg_entropy_scores(ptr(plan['counts'][f]), len(used), n, seek_row, ptr(H), stream_ptr()), 'vg_entropy_scores')
+        return torch.empty_like(H).index_copy_(0, plan['order'][f], H)          # back to the frame's point order
+
+    def score_sequence(self, X_list, queries=None, mapper=None):
+        """X_list: per frame CUDA float32 [n,>=3] (`points_ref_wo_ground`; entries of frames that are not needed may be
+        None).  -> {fnr: float64 CUDA tensor [n] of entropy scores} for the `queries` (default: every frame; then a
+        list).  Every frame's grid is built once and queried by all the frames whose window contains it.
+        mapper(items, fn): runs fn(grid_model, item) for the items on several handles / streams at once
+        (PseudoLabelPipeline.map_workers); target frames are independent, every (query, column) row has one writer."""
+        plan = self.plan(X_list, queries)
         if mapper is None:
-            for j in sorted(users):
-                one_target(self.grid_model, j)
+            for j in sorted(plan['users']):
+                self.run_target(self.grid_model, plan, j)
         else:
-            mapper(sorted(users), one_target)
-        out = {}
-        for f in queries:
-            frames, seek = wins[f]
-            seek_row = used[f].index(frames[seek]) if frames[seek] in used[f] else -1
-            n = X_list[f].shape[0]
-            H = torch.empty(n, dtype=torch.float64, device=X_list[f].device)
-            if len(used[f]) < 2:
-                raise NotImplementedError('entropy scores need at least two neighbouring frames')
-            check(lib.vg_entropy_scores(ptr(counts[f]), len(used[f]), n, seek_row, ptr(H), stream_ptr()), 'vg_entropy_scores')
-            out[f] = torch.empty_like(H).index_copy_(0, order[f], H)          # back to the frame's point order
-        return [out[f] for f in range(L)] if as_list else out
+            mapper(sorted(plan['users']), lambda model, j: self.run_target(model, plan, j))
+        out = {f: self.finish_query(plan, f) for f in plan['queries']}
+        return [out[f] for f in range(plan['L'])] if plan['as_list'] else out
 
     @staticmethod
     def reduce(H):

@@ -337,6 +337,12 @@ def moving_boxes(points_list, directions, to_ego_list, top_k=3, centers3=None):
     return boxes
 
 
+def moving_boxes_packed(xyz, seg, directions, to_ego, centers3):
+    """moving_boxes on packed cluster points ([P,3] + offsets): the helper-process form (vilgod_amd/box_worker.py)."""
+    pts = [xyz[seg[i]:seg[i + 1]] for i in range(len(seg) - 1)]
+    return moving_boxes(pts, list(directions), list(to_ego), centers3=None if centers3 is None else list(centers3))
+
+
 class DetectionTable:
     """Mutable per-detection state shared by all tracks that hold the detection (the far-match rule can put one detection into
     two tracks, and upstream mutates the one Detection object from both): box, static_track, valid, class name / score.
@@ -357,22 +363,24 @@ def _entry_set(tab, t, i, field, value):
         getattr(tab, field)[t.source[i]] = value
 
 
-def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=None, static_box_of=None, median_of=None):
+def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=None, static_box_of=None, median_of=None,
+                    moving_async=None):
     """The track branch of fit_bounding_boxes_simple for every valid track, in track order: boxes and `static_track` flags of
     the entries (into `tab` for real detections, into the track for its clones) and `track.static`.
     points_of(key) -> cluster points [n,>=3]; static_of(key) -> Detection.static (the entropy flag); to_ego_of(fnr) -> 4x4;
-    rectangle(xy) -> (corners, rz, area), or static_box_of(key) -> the finished static box (the GPU kernel's, vg_cluster_boxes)."""
+    rectangle(xy) -> (corners, rz, area), or static_box_of(key) -> the finished static box (the GPU kernel's, vg_cluster_boxes).
+    moving_async(points_list, directions, to_ego_list, centers3) -> object with .result(): the moving tracks' boxes computed
+    elsewhere (helper processes, boxes.submit_moving_boxes) while this thread goes on with the next track.  What a track needs is
+    decided first for all tracks (nothing of it reads `tab`); the entries are then written in track order, as before -- one detection
+    can sit in two tracks (far-match rule), and the later track's values must win."""
     sbox = (lambda k, p: np.array(static_box_of(k), dtype=np.float64)) if static_box_of is not None else (lambda k, p: static_box(p, rectangle))
     need_pts = static_box_of is None                     # the finished static boxes make the points of static tracks unnecessary
+    plan = []
     for t in tracker.tracks_valid:
         n = len(t)
         pts = [points_of(k) for k in t.source] if need_pts else [None] * n
-        t.clone_box = [None] * n
-        t.clone_static_track = [None] * n
-        t.clone_valid = [True] * n
         if all(static_of(k) for k in t.source):
-            for i in range(n):
-                _entry_set(tab, t, i, 'box', sbox(t.source[i], pts[i]))
+            plan.append((t, pts, 'static', None))
             continue
         # median_of(key) -> np.median(cluster points, axis=0) (the medians track_clusters already has: vg_cluster_medians)
         if median_of is not None:
@@ -387,7 +395,24 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=Non
         if dirs:
             if pts[0] is None:
                 pts = [points_of(k) for k in t.source]
-            boxes = moving_boxes(pts, dirs, [to_ego_of(f) for f in t.frames], centers3=[m[:3] for m in med] if med is not None else None)
+            c3 = [m[:3] for m in med] if med is not None else None
+            egos = [to_ego_of(f) for f in t.frames]
+            if moving_async is not None:
+                plan.append((t, None, 'moving', moving_async(pts, dirs, egos, c3)))
+            else:
+                plan.append((t, None, 'moving', moving_boxes(pts, dirs, egos, centers3=c3)))
+        else:
+            plan.append((t, pts, 'still', None))
+    for t, pts, kind, res in plan:
+        n = len(t)
+        t.clone_box = [None] * n
+        t.clone_static_track = [None] * n
+        t.clone_valid = [True] * n
+        if kind == 'static':
+            for i in range(n):
+                _entry_set(tab, t, i, 'box', sbox(t.source[i], pts[i]))
+        elif kind == 'moving':
+            boxes = res.result() if hasattr(res, 'result') else res
             for i in range(n):
                 _entry_set(tab, t, i, 'box', boxes[i])
                 _entry_set(tab, t, i, 'static_track', False)

@@ -37,6 +37,36 @@ from .frame_state import FrameState, pack_clusters, vote
 from .pipeline import PseudoLabelPipeline
 
 
+# The sequence-state pickle (zero_shot_detector.py:105-114 of the reference) of a 199-frame Waymo-shape sequence is ~200 MB of numpy
+# arrays: ~0.4 s of pickle.dump, nearly all of it in write() calls that release the interpreter lock.  It is handed to ONE background
+# thread (device.async_state_write, default on) so that the next sequence's GPU pass starts meanwhile; the data are the detached
+# per-detection dicts of FrameState.serialize (later stages never touch them).  At most one write is outstanding; tools/preprocess_data.py
+# waits for the last one before it returns, and a detector that is about to LOAD a file waits for any write of that file first.
+_STATE_WRITER = {'pool': None, 'pending': None}
+
+
+def _write_state_file(path, data):
+    tmp = str(path) + '.tmp'
+    with open(tmp, 'wb') as fp:
+        pickle.dump(data, fp, protocol=pickle.HIGHEST_PROTOCOL)
+    os.replace(tmp, path)                                # readers never see a half-written file
+
+
+def wait_state_writes():
+    """Blocks until the outstanding background state write (if any) is on disk; re-raises its error."""
+    fut, _STATE_WRITER['pending'] = _STATE_WRITER['pending'], None
+    if fut is not None:
+        fut.result()
+
+
+def _submit_state_write(path, data):
+    from concurrent.futures import ThreadPoolExecutor
+    wait_state_writes()
+    if _STATE_WRITER['pool'] is None:
+        _STATE_WRITER['pool'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vilgod-state-writer')
+    _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_file, path, data)
+
+
 class ZeroShotDetector:
     def __init__(self, dataset, name, cfg, logger, cluster_model=None, clip_model=None, pipeline=None):
         self.cfg, self.name, self.dataset, self.logger = cfg, name, dataset, logger
@@ -71,14 +101,17 @@ class ZeroShotDetector:
         self._ent = {}                                   # fnr -> (kept entropy scores, indices), own + halo frames
         self.n_workers = int(dev.get('frames_in_flight', 6))
         self.sync_every_stage = bool(dev.get('sync_every_stage', False))
+        self.async_state_write = bool(dev.get('async_state_write', True)) and not self.sync_every_stage
         self.stage_ms = {}                               # stage name -> ms per (own) frame of the last process()
         self.detail_ms = {}                              # VILGOD_STAGE_DETAIL=1: wall ms of the parts of the host-heavy stages (whole sequence)
         self._detail_on = os.environ.get('VILGOD_STAGE_DETAIL', '0') == '1'
         self._dirty = False
         self._snapshot, self._frozen = None, False       # serialised frames as of the last stage that synchronises (propagate_labels)
+        self._written_early = False                      # the frozen snapshot is already with the background writer
         self.tracker = None                              # vilgod_amd.tracking.Tracker after track_clusters (in memory only, like upstream)
         self._tab = None                                 # tracking.DetectionTable shared by fit_bounding_boxes_simple / propagate_labels
         self._host_X = {}                                # fnr -> points_ref_wo_ground on the host (tracking stages are host logic)
+        self._host_X3 = {}                               # fnr -> its x, y, z columns, contiguous (the track branch of the box stage)
         self._box_prefetch = {}                          # fnr -> (rows, future of their static boxes), filled by `classification`
         self.init_lidar_frames()
         try:
@@ -136,11 +169,14 @@ class ZeroShotDetector:
         dev = self.pipe.device
         return torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32)).to(dev), torch.from_numpy(seg).to(dev)
 
-    def _for_frames(self, frames, body, prepare=None):
+    def _for_frames(self, frames, body, prepare=None, in_order=None):
         """Run `body(pipe, fnr)` for every frame -- sequentially on the caller's stream, or, with device.frames_in_flight > 1,
         on worker threads that own a stream and their own handles (cluster buffers, ViT workspace): `prepare(fnr)` is then
         called for all frames first on the caller's stream (device data the bodies share), followed by one event the workers
-        wait for.  Bodies of different frames touch different FrameState objects."""
+        wait for.  Bodies of different frames touch different FrameState objects.
+        in_order(fnr): called on the CALLER's thread for every frame, in the order of `frames`, as soon as that frame and all frames
+        before it are done -- sequential consumers of the frame pass (the tracker) run there while the workers are busy with later
+        frames, instead of as a stage of their own afterwards."""
         frames = list(frames)
         nw = min(self.n_workers, len(frames))
         if prepare is not None:
@@ -149,6 +185,8 @@ class ZeroShotDetector:
         if nw <= 1:
             for f in frames:
                 body(self.pipe, f)
+                if in_order is not None:
+                    in_order(f)
             return
         p = self.pipe
         workers = p._ensure_workers(nw)
@@ -159,7 +197,7 @@ class ZeroShotDetector:
         # thread).  A fixed deal (frame i -> worker i % nw) ends when the slowest worker has worked off its share: the workers do not
         # run in step (PseudoLabelPipeline.process_frames).
         import queue
-        todo = queue.Queue()
+        todo, done = queue.Queue(), queue.Queue()
         for f in frames:
             todo.put(f)
 
@@ -175,13 +213,31 @@ class ZeroShotDetector:
                     try:
                         body(worker, f)
                         worker.stream.synchronize()
+                        done.put((f, True))
                     except BaseException as e:      # noqa: BLE001  (the other frames still run; the first error is raised below)
                         errors.append(e)
+                        done.put((f, False))
             return errors
 
+        futs = [w.thread.submit(drain, w) for w in workers[:nw]]
         errs = []
-        for fut in [w.thread.submit(drain, w) for w in workers[:nw]]:
-            errs.extend(fut.result())
+        if in_order is not None:
+            # frames finish out of order (whichever worker is free takes the next one): hand them on in the order of `frames`
+            finished, nxt, broken = {}, 0, False
+            for _ in range(len(frames)):
+                f, ok = done.get()
+                finished[f] = ok
+                while nxt < len(frames) and frames[nxt] in finished:
+                    broken = broken or not finished[frames[nxt]]
+                    if not broken:
+                        try:
+                            in_order(frames[nxt])
+                        except BaseException as e:      # noqa: BLE001
+                            errs.append(e)
+                            broken = True
+                    nxt += 1
+        for fut in futs:
+            errs = fut.result() + errs
         if errs:
             raise errs[0]
 
@@ -209,6 +265,7 @@ class ZeroShotDetector:
                 return                                   # several ranks: written once per run, after the gather (process())
             if not final:
                 self._snapshot, self._frozen = None, False   # a stage synchronised: the live state is what the file holds from here on
+                self._written_early = False                  # (and a file written from an earlier freeze is out of date)
             if not self.sync_every_stage and not final:
                 self._dirty = True                       # one write at the end of process() instead of one per stage
                 return
@@ -219,12 +276,20 @@ class ZeroShotDetector:
                 if self.rank != 0:
                     self._dirty = False
                     return
+            if final and snapshot is not None and getattr(self, '_written_early', False):
+                self._dirty = False                      # propagate_labels handed exactly this snapshot to the background writer already
+                return
             with self._part('state.serialize'):
                 data = snapshot if snapshot is not None else [f.serialize for f in self.lidar_frame_list]
-            with self._part('state.pickle'), open(path, 'wb') as fp:
-                pickle.dump(data, fp, protocol=pickle.HIGHEST_PROTOCOL)
+            with self._part('state.pickle'):
+                if final and self.async_state_write:
+                    _submit_state_write(path, data)      # (the one write at the end of process(): in the background, see _STATE_WRITER)
+                else:
+                    wait_state_writes()
+                    _write_state_file(path, data)
             self._dirty = False
         elif mode == 'load':
+            wait_state_writes()                          # (a background write of this very file may still be running)
             if path.exists():
                 with open(path, 'rb') as fp:
                     data = pickle.load(fp)
@@ -441,7 +506,9 @@ class ZeroShotDetector:
                     rows = np.flatnonzero(fs.valid) if track_rows == 'valid' else np.arange(fs.n_detections)
                     if len(rows):
                         d_index, d_seg = self._cluster_lists(fnr, rows)
-                        self._track_med[fnr] = (rows, p.cluster_medians(X, d_index, d_seg))
+                        self._track_med[fnr] = (rows, p.cluster_medians(X, d_index, d_seg).cpu().numpy())    # (host: the worker syncs anyway)
+                    else:
+                        self._track_med[fnr] = (rows, None)
             if cls_ctx is not None and fs.n_detections and cls_ctx['key'] not in fs.cls:
                 self._classify_frame(p, fnr, cls_ctx)
 
@@ -453,7 +520,19 @@ class ZeroShotDetector:
             targs = [t['args'] or {} for t in self.cfg.pipeline if t['name'] == 'track_clusters']
             track_rows = 'valid' if (targs and targs[0].get('valid_only', False)) else 'all'
         self._track_med = {}
-        self._for_frames(todo, body, prepare=lambda f: (self._ref_and_nonground(f), self._entropy_full(f)))
+        # the tracker as a streaming consumer of the frame pass (round 4): it is sequential over the frames and pure host logic on a few
+        # hundred cluster medians per frame (~1 ms), so it runs on this thread, frame by frame in order, while the workers process the
+        # later frames -- instead of ~1 ms per frame with the GPU idle afterwards.  Same inputs, same order, same tracker; the
+        # track_clusters stage then finds its work done.  Only when every frame of the sequence goes through this pass.
+        stream_tracker = (track_rows is not None and len(todo) == self.lenght and todo == list(range(self.lenght))
+                          and getattr(self, '_stream_tracker_ok', True))
+        self._streamed = None
+        if stream_tracker:
+            self._streamed = self._new_tracker()
+            self._streamed_rows = track_rows
+            self._med, self._cnt = {}, {}
+        self._for_frames(todo, body, prepare=lambda f: (self._ref_and_nonground(f), self._entropy_full(f)),
+                         in_order=self._track_frame if stream_tracker else None)
         if todo:
             self.sync_lidar_frames()
 
@@ -624,17 +703,19 @@ class ZeroShotDetector:
         """zero_shot_detector.py:298-327.  The tracker is sequential over the whole sequence and lives in memory only (upstream
         never writes `tid`); with several ranks every rank first receives all frame states and runs the same deterministic
         tracker, so the later stages can stay sharded."""
-        from .tracking import Tracker
         valid_only = kwargs.get('valid_only', False)
         self._exchange_states()
-        tcfg = self.cfg.preprocessor.tracking.cluster
-        assign = tcfg['assignment'] if isinstance(tcfg, dict) else tcfg.assignment
-        if (assign['method'] if isinstance(assign, dict) else assign.method) != 'assign_detections_greedy':
-            raise NotImplementedError('tracking.cluster.assignment.method: only assign_detections_greedy (the shipped configuration)')
-        g = (lambda k, d=None: tcfg.get(k, d)) if hasattr(tcfg, 'get') else (lambda k, d=None: getattr(tcfg, k, d))
-        self.tracker = Tracker(mode=g('mode', 'cluster_center'), max_distance=(assign['max_distance'] if isinstance(assign, dict) else assign.max_distance),
-                               min_length=g('min_length', 5), max_missed=g('max_missed', 3))
         self._tab = None
+        streamed = getattr(self, '_streamed', None)
+        if streamed is not None and self._streamed_rows == ('valid' if valid_only else 'all'):
+            # the frame pass fed the tracker frame by frame (spatial_clustering, _track_frame): nothing left but to close the open tracks
+            self.tracker, self._streamed = streamed, None
+            with self._part('track.tracker'):
+                self.tracker.finish()
+            self.logger.info(f'  tracks: {len(self.tracker.tracks)} ({sum(len(t) >= self.tracker.min_length for t in self.tracker.tracks)} of length >= {self.tracker.min_length})')
+            return
+        self._streamed = None
+        self.tracker = self._new_tracker()
         # Detection.cluster_mass_center (objects.py:121-123) of every detection the tracker sees: one kernel launch per frame
         # (vg_cluster_medians, exact np.median semantics), queued for all frames before the first result is read back
         med, cnt, pending = {}, {}, []
@@ -655,7 +736,7 @@ class ZeroShotDetector:
             for fs, rows, d_med in pending:
                 keys = [(fs.fnr, int(r)) for r in rows]
                 if keys:
-                    m = d_med.cpu().numpy()
+                    m = d_med if isinstance(d_med, np.ndarray) else d_med.cpu().numpy()
                     for j, k in enumerate(keys):
                         med[k], cnt[k] = m[j], int(fs.seg_off[k[1] + 1] - fs.seg_off[k[1]])
                 centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
@@ -663,9 +744,33 @@ class ZeroShotDetector:
             self.tracker.finish()
         self.logger.info(f'  tracks: {len(self.tracker.tracks)} ({sum(len(t) >= self.tracker.min_length for t in self.tracker.tracks)} of length >= {self.tracker.min_length})')
 
+    def _new_tracker(self):
+        from .tracking import Tracker
+        tcfg = self.cfg.preprocessor.tracking.cluster
+        assign = tcfg['assignment'] if isinstance(tcfg, dict) else tcfg.assignment
+        if (assign['method'] if isinstance(assign, dict) else assign.method) != 'assign_detections_greedy':
+            raise NotImplementedError('tracking.cluster.assignment.method: only assign_detections_greedy (the shipped configuration)')
+        g = (lambda k, d=None: tcfg.get(k, d)) if hasattr(tcfg, 'get') else (lambda k, d=None: getattr(tcfg, k, d))
+        return Tracker(mode=g('mode', 'cluster_center'), max_distance=(assign['max_distance'] if isinstance(assign, dict) else assign.max_distance),
+                       min_length=g('min_length', 5), max_missed=g('max_missed', 3))
+
+    def _track_frame(self, fnr):
+        """One frame into the streaming tracker (frames arrive in order, on the dispatcher's thread): Tracker.next of track_clusters."""
+        fs = self.lidar_frame_list[fnr]
+        rows, m = self._track_med.pop(fnr, (np.zeros(0, np.int64), None))
+        keys = [(fnr, int(r)) for r in rows]
+        med, cnt = self._med, self._cnt
+        for j, k in enumerate(keys):
+            med[k], cnt[k] = m[j], int(fs.seg_off[k[1] + 1] - fs.seg_off[k[1]])
+        centers = np.array([med[k] for k in keys]) if keys else np.zeros((0, 5), np.float32)
+        self._streamed.next(fnr, keys, centers, [cnt[k] for k in keys], lambda k: (med[k], cnt[k]))
+
     def _cluster_points_host(self, key):
         fnr, row = key
-        return self._points_host(fnr)[self.lidar_frame_list[fnr].cluster_index(row)]
+        x3 = self._host_X3.get(fnr)
+        if x3 is None:                                   # x, y, z of the frame's points, contiguous: the gathers below read 12-byte rows
+            x3 = self._host_X3[fnr] = np.ascontiguousarray(self._points_host(fnr)[:, :3])
+        return x3.take(self.lidar_frame_list[fnr].cluster_index(row), axis=0)
 
     def _fit_boxes_tracked(self, valid_only):
         """The track branch of fit_bounding_boxes_simple (zero_shot_detector.py:463-684): the per-detection rectangle boxes come
@@ -693,9 +798,16 @@ class ZeroShotDetector:
                     tab.valid[(fs.fnr, r)] = bool(fs.valid[r])
         med = getattr(self, '_med', None) or {}
         with self._part('boxes.fit_track_boxes'):
+            # the moving tracks' boxes (per entry: a dozen small numpy calls, ~70 us) are computed by the box helper processes, track
+            # by track, while this thread gathers the next track's points; same function, same numpy -> same boxes
+            from . import boxes as _boxes
+            nproc = self.pipe.box_workers if self.pipe.box_mode == 'reference' else 0
+            self._host_X3 = {}
             fit_track_boxes(self.tracker, tab, self._cluster_points_host, lambda k: bool(self.lidar_frame_list[k[0]].static[k[1]]),
                             lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__,
-                            median_of=(med.__getitem__ if med else None))
+                            median_of=(med.__getitem__ if med else None),
+                            moving_async=(lambda p, d, e, c: _boxes.submit_moving_boxes(p, d, e, c, n_procs=nproc)) if nproc > 0 else None)
+            self._host_X3 = {}
         self._tab = tab
         with self._part('boxes.write_back'):
             self._write_back_tracked()
@@ -747,6 +859,11 @@ class ZeroShotDetector:
             if self.rank == 0:
                 with self._part('propagate.snapshot'):
                     self._snapshot = [f.serialize for f in self.lidar_frame_list]
+                if self.async_state_write:
+                    # what the file will hold is final from here on (no later stage of the reference synchronises): the background
+                    # writer starts now, under the label propagation and the evaluation, instead of at the end of process()
+                    _submit_state_write(self.sequence_data_dir_path / f'{self.name}{self.cfg.postfix.sequence_data}', self._snapshot)
+                    self._written_early = True
         with self._part('propagate.logic'):
             propagate_labels(self.tracker, tab, lambda k: len(self.lidar_frame_list[k[0]].cluster_index(k[1])), self.dataset.class_names,
                              min_length=kwargs.get('min_length', 5))
