@@ -189,3 +189,75 @@ def test_box_helper_pool_survives_a_dead_helper():
         assert all(np.array_equal(f.result(), want) for f in futs)
     finally:
         pool.close()
+
+
+def _frame_state_with_results(seed=0):
+    from vilgod_amd.frame_state import FrameState, pack_clusters
+    rng = np.random.default_rng(seed)
+    fs = FrameState(3, np.eye(4), np.eye(4))
+    labels = rng.integers(-1, 7, 400)
+    fs.set_clusters(*pack_clusters(labels, rng.random(400), 0.1))
+    C = fs.n_detections
+    fs.ground_point_indices = np.sort(rng.choice(1000, 300, replace=False))
+    fs.entropy_scores, fs.entropy_indices = rng.random(50), np.sort(rng.choice(400, 50, replace=False))
+    fs.valid = rng.random(C) > 0.3
+    fs.filtered = True
+    fs.static = rng.random(C) > 0.5
+    fs.static_track[:] = rng.integers(-1, 2, C)
+    fs.boxes = rng.random((C, 7))
+    fs.boxes[0] = np.nan
+    names = np.array(['Background', 'Cyclist', 'Pedestrian', 'Vehicle'], dtype=object)
+    which = fs.valid.copy()
+    n = int(which.sum())
+    fs.set_classes('clip', which, names[rng.integers(0, 4, (n, 4))], names[rng.integers(0, 4, (n, 4))], rng.random((n, 4)).astype(np.float32),
+                   names[rng.integers(0, 4, n)], rng.random(n).astype(np.float32))
+    fs.set_final_score('clip', int(np.flatnonzero(which)[0]), 0.7)            # a propagated python-float score
+    return fs
+
+
+def _same(a, b):
+    if isinstance(a, dict):
+        return isinstance(b, dict) and list(a) == list(b) and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)):
+        return type(a) is type(b) and len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray):
+        return isinstance(b, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=a.dtype.kind == 'f')
+    return type(a) is type(b) and (a == b or (a != a and b != b))
+
+
+def test_frame_state_compact_form_serialises_identically_and_is_detached():
+    """FrameState.compact() -> from_compact().serialize (what the state-writer process does) gives the dict FrameState.serialize gives:
+    same keys in the same order, same value types (numpy bool / numpy str / float32-vs-python-float scores) and values; and later
+    in-place changes of the live state (what propagate_labels does) do not reach a compact form taken before them."""
+    from vilgod_amd.frame_state import FrameState
+    fs = _frame_state_with_results()
+    want = fs.serialize
+    c = fs.compact()
+    assert _same(FrameState.from_compact(c).serialize, want)
+    fs.boxes[1] = 5.0
+    fs.valid[:] = False
+    fs.static_track[:] = 1
+    fs.cls['clip']['name'][np.flatnonzero(fs.cls['clip']['has'])[0]] = 'Vehicle'
+    fs.set_final_score('clip', int(np.flatnonzero(fs.cls['clip']['has'])[1]), 1.0)
+    assert _same(FrameState.from_compact(c).serialize, want)
+    assert not _same(fs.serialize, want)
+
+
+def test_state_writer_process_writes_the_reference_layout(tmp_path):
+    """python -m vilgod_amd.state_writer (the helper process of device.async_state_write) on compact frame states: the file holds
+    exactly [FrameState.serialize ...], appears under its final name only when complete, and a second request is served too."""
+    import pickle
+    from vilgod_amd import zero_shot_detector as zsd
+    frames = [_frame_state_with_results(s) for s in range(3)]
+    want = [f.serialize for f in frames]
+    try:
+        for name in ('a.pkl', 'b.pkl'):
+            path = tmp_path / name
+            zsd._submit_state_write(path, [f.compact() for f in frames])
+            zsd.wait_state_writes()
+            assert zsd._STATE_WRITER['proc'] is not None and zsd._STATE_WRITER['proc'].poll() is None     # served by the helper, which lives on
+            with open(path, 'rb') as fp:
+                assert _same(pickle.load(fp), want)
+            assert not (tmp_path / (name + '.tmp')).exists()
+    finally:
+        zsd.shutdown_state_writer()

@@ -113,54 +113,113 @@ def main(argv=None):
         result_path.mkdir(parents=True, exist_ok=True)      # every rank writes the pickles of its own sequences
     starts = []                                             # (sequence number, offsets into detection_results / indices) of this rank's sequences
     t_loop = time.perf_counter()
+    gen_seconds = 0.0
+    if os.environ.get('VILGOD_SWITCH_INTERVAL'):
+        sys.setswitchinterval(float(os.environ['VILGOD_SWITCH_INTERVAL']))
+    # Sequences overlap (device.overlap_sequences, default on; one rank per sequence): the host-only tail of a sequence's stage list --
+    # track boxes, label propagation, result dicts, the pickles -- runs on a background thread while the NEXT sequence's GPU stages
+    # run on this one (ZeroShotDetector.split_stages).  The order of everything that is written or returned is the sequences' order.
+    pending = []                                            # at most one: (thread, box with the error, finish())
+
+    def finish_pending():
+        while pending:
+            th, err, fin = pending.pop(0)
+            th.join()
+            if err:
+                raise err[0]
+            fin()
+
     for seq_no, sequence_name in enumerate(dataset.next_sequence()):
         if by_sequence and seq_no % world != rank:
             continue
-        starts.append((seq_no, len(detection_results), len(indices)))
         if result_data is not None:
+            starts.append((seq_no, len(detection_results), len(indices)))
             indices.extend(dataset.sequence_indices)        # (upstream leaves this empty and falls back to dataset.index_mapping)
             continue
         result_file = result_path / f'{sequence_name}.pkl'
         indices_file = result_path / f'{sequence_name}_indices.pkl'
         if cfg.use_cached_results and 'evaluate_sequence' in cfg.pipeline_active and result_file.exists():
+            finish_pending()
+            starts.append((seq_no, len(detection_results), len(indices)))
             with result_file.open('rb') as f:
                 detection_results.extend(pickle.load(f))
             with indices_file.open('rb') as f:
                 indices.extend(pickle.load(f))
             continue
         if hasattr(dataset, 'prefetch_sequence'):
+            t_gen = time.perf_counter()
             dataset.prefetch_sequence()                 # synthetic data: generate the sequence before the clock starts (stands for disk IO)
+            gen_seconds += time.perf_counter() - t_gen
         t_seq = time.perf_counter()
         zsd = ZeroShotDetector(dataset, sequence_name, cfg=cfg, logger=logger, pipeline=pipeline)
-        zsd.process()
-        detection_results.extend(zsd.detection_3d_result_list)
-        indices.extend(dataset.sequence_indices)
-        if 'evaluate_sequence' in cfg.pipeline_active and (rank == 0 or by_sequence):
-            with open(result_file, 'wb') as f:
-                pickle.dump(zsd.detection_3d_result_list, f)
-            with open(indices_file, 'wb') as f:
-                pickle.dump(dataset.sequence_indices, f)
-            if cfg.get('export_pseudo_labels', False):
-                # OpenPCDet `infos`-style pickle + NPZ under paths.pseudo_label (an addition: upstream declares the path, never writes it)
-                from vilgod_amd import export
-                ids = [info.get('frame_id', f'{sequence_name}_{i:03d}') for i, info in enumerate(dataset.sequence_infos)]
-                export.write_sequence(cfg.paths.pseudo_label, sequence_name, zsd.detection_3d_result_list, ids,
-                                      dataset.sequence_indices, class_names=dataset.class_names)
+        seq_indices = list(dataset.sequence_indices)
+        seq_len = dataset.sequence_length
+        frame_ids = [info.get('frame_id', f'{sequence_name}_{i:03d}') for i, info in enumerate(dataset.sequence_infos)]
+        front, back = zsd.split_stages()
+        zsd.process(part='front' if back else 'all')
         torch.cuda.synchronize()
-        LAST_RUN['sequences'].append({'name': sequence_name, 'frames': dataset.sequence_length, 'world_size': world,
-                                      'seconds': time.perf_counter() - t_seq, 'stage_ms_per_frame': dict(zsd.stage_ms),
-                                      # the stages every rank repeats over ALL frames when the frames of one sequence are sharded (ms per frame of the
-                                      # sequence; with device.shard=sequences nothing is replicated)
-                                      'replicated_ms_per_frame': 0.0 if (world == 1 or by_sequence) else round(sum(
-                                          zsd.stage_ms.get(k, 0.0) * max(len(zsd.my_frames), 1) for k in ('track_clusters', 'propagate_labels', 'write_sequence_state')
-                                      ) / max(dataset.sequence_length, 1), 3),
-                                      'detail_ms': dict(zsd.detail_ms)})
-        if LAST_RUN['sequences'][-1]['replicated_ms_per_frame']:
-            logger.info(f"  sequence-level stages repeated on every rank: {LAST_RUN['sequences'][-1]['replicated_ms_per_frame']:.2f} ms per frame of the sequence "
-                        f"(of {1000.0 * LAST_RUN['sequences'][-1]['seconds'] / max(dataset.sequence_length, 1):.2f}); device.shard=sequences has none")
+        t_front = time.perf_counter() - t_seq
+        finish_pending()                                    # the previous sequence's tail ran under this sequence's GPU stages
+
+        def finish(zsd=zsd, seq_no=seq_no, sequence_name=sequence_name, seq_indices=seq_indices, seq_len=seq_len, frame_ids=frame_ids,
+                   result_file=result_file, indices_file=indices_file, t_front=t_front, clock=None):
+            starts.append((seq_no, len(detection_results), len(indices)))
+            detection_results.extend(zsd.detection_3d_result_list)
+            indices.extend(seq_indices)
+            seconds = t_front + (clock['back'] if clock else 0.0)
+            LAST_RUN['sequences'].append({'name': sequence_name, 'frames': seq_len, 'world_size': world,
+                                          'seconds': seconds, 'front_seconds': t_front, 'back_seconds': clock['back'] if clock else 0.0,
+                                          'stage_ms_per_frame': dict(zsd.stage_ms),
+                                          # the stages every rank repeats over ALL frames when the frames of one sequence are sharded (ms per frame of the
+                                          # sequence; with device.shard=sequences nothing is replicated)
+                                          'replicated_ms_per_frame': 0.0 if (world == 1 or by_sequence) else round(sum(
+                                              zsd.stage_ms.get(k, 0.0) * max(len(zsd.my_frames), 1) for k in ('track_clusters', 'propagate_labels', 'write_sequence_state')
+                                          ) / max(seq_len, 1), 3),
+                                          'detail_ms': dict(zsd.detail_ms)})
+            if LAST_RUN['sequences'][-1]['replicated_ms_per_frame']:
+                logger.info(f"  sequence-level stages repeated on every rank: {LAST_RUN['sequences'][-1]['replicated_ms_per_frame']:.2f} ms per frame of the sequence "
+                            f"(of {1000.0 * seconds / max(seq_len, 1):.2f}); device.shard=sequences has none")
+
+        def tail(zsd=zsd, sequence_name=sequence_name, seq_indices=seq_indices, frame_ids=frame_ids, result_file=result_file,
+                 indices_file=indices_file, with_back=bool(back)):
+            if with_back:
+                zsd.process(part='back')
+            if 'evaluate_sequence' in cfg.pipeline_active and (rank == 0 or by_sequence):
+                with open(result_file, 'wb') as f:
+                    pickle.dump(zsd.detection_3d_result_list, f)
+                with open(indices_file, 'wb') as f:
+                    pickle.dump(seq_indices, f)
+                if cfg.get('export_pseudo_labels', False):
+                    # OpenPCDet `infos`-style pickle + NPZ under paths.pseudo_label (an addition: upstream declares the path, never writes it)
+                    from vilgod_amd import export
+                    export.write_sequence(cfg.paths.pseudo_label, sequence_name, zsd.detection_3d_result_list, frame_ids,
+                                          seq_indices, class_names=dataset.class_names)
+
+        if back and zsd.back_is_host_only():
+            import threading
+            err, clock = [], {'back': 0.0}
+
+            def run(tail=tail, err=err, clock=clock):
+                t0 = time.perf_counter()
+                try:
+                    tail()
+                except BaseException as e:      # noqa: BLE001  (re-raised on the main thread by finish_pending)
+                    err.append(e)
+                clock['back'] = time.perf_counter() - t0
+            th = threading.Thread(target=run, name=f'vilgod-tail-{sequence_name}', daemon=True)
+            th.start()
+            pending.append((th, err, lambda finish=finish, clock=clock: finish(clock=clock)))
+        else:
+            t0 = time.perf_counter()
+            tail()
+            torch.cuda.synchronize()
+            finish(clock={'back': time.perf_counter() - t0})
         del zsd
         gc.collect()
-        torch.cuda.empty_cache()
+        if dev.get('empty_cache_between_sequences', False):
+            torch.cuda.empty_cache()                        # (off by default: the next sequence re-uses the allocator's blocks instead of
+                                                            # paying ~0.1 s of hipMalloc for them again; 288 GB of HBM hold both)
+    finish_pending()
 
     # the last sequence's state pickle may still be on its way to disk (background writer, vilgod_amd/zero_shot_detector.py): the
     # sequence loop -- and its clock -- ends when it has landed
@@ -168,7 +227,7 @@ def main(argv=None):
     t_wait = time.perf_counter()
     _zsd.wait_state_writes()
     LAST_RUN['state_write_wait_seconds'] = time.perf_counter() - t_wait
-    LAST_RUN['loop_seconds'] = time.perf_counter() - t_loop
+    LAST_RUN['loop_seconds'] = time.perf_counter() - t_loop - gen_seconds      # (without the synthetic generator, which stands for disk IO)
     if result_data is not None:
         detection_results = result_data
     elif by_sequence:

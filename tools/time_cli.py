@@ -11,15 +11,15 @@ nseq = int(os.environ.get('SEQUENCES', '1'))
 with tempfile.TemporaryDirectory() as root:
     logging.disable(logging.INFO)
     preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}', f'dataset.SYNTHETIC.frames_per_sequence={frames}',
-                          f'dataset.SYNTHETIC.points_per_frame={points}', f'dataset.SYNTHETIC.n_sequences={nseq}', f'end_sequence={nseq - 1}',
+                          f'dataset.SYNTHETIC.points_per_frame={points}', f'dataset.SYNTHETIC.n_sequences={nseq}', f'end_sequence={nseq - 1}', f"dataset.SYNTHETIC.seed_stride={os.environ.get('SEED_STRIDE', '0')}",
                           f'device.max_points={2 * points}', 'paths.clip_model=/nonexistent'] + sys.argv[3:])
 run = preprocess_data.LAST_RUN
 tot_f = sum(q['frames'] for q in run['sequences'])
-tot_s = sum(q['seconds'] for q in run['sequences']) + run.get('state_write_wait_seconds', 0.0)
+tot_s = run['loop_seconds']
 print(f"{len(run['sequences'])} sequence(s), {tot_f} frames: {1000 * tot_s / tot_f:.2f} ms per frame = {tot_f / tot_s:.2f} frames/s "
-      f"(sequence clocks + {run.get('state_write_wait_seconds', 0.0):.3f} s waiting for the last background state write)")
+      f"(wall time of the sequence loop without the synthetic generator; {run.get('state_write_wait_seconds', 0.0):.3f} s of it waiting for the last background state write)")
 for seq in run['sequences']:
-  print(f"frames {seq['frames']}  {1000 * seq['seconds'] / seq['frames']:.2f} ms per frame  ({seq['frames'] / seq['seconds']:.2f} frames/s)  " +
+  print(f"frames {seq['frames']}  front {1000 * seq['front_seconds'] / seq['frames']:.2f} + back {1000 * seq['back_seconds'] / seq['frames']:.2f} ms per frame  " +
       '  '.join(f'{k} {v:.2f}' for k, v in seq['stage_ms_per_frame'].items()))
   if seq.get('detail_ms'):
     print('parts (ms per frame): ' + '  '.join(f"{k} {v / seq['frames']:.3f}" for k, v in seq['detail_ms'].items()))

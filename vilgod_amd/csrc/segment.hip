@@ -419,16 +419,36 @@ __global__ void k_subsample_keys(unsigned long long seed, unsigned long long tag
 // Detection.cluster_mass_center = np.median(cluster_points, axis=0) (objects.py:121-123) for every packed cluster
 // and the first n_cols columns of the point rows: exact order statistics by a 4-pass byte radix select per (cluster, column);
 // an even count gives the float32 mean of the two middle values, like np.median on a float32 array.
-__device__ float vg_select_gather(const float* __restrict__ pts, int stride, int col, const int* __restrict__ idx, int n, int k,
-                                  uint32_t* hist, uint32_t* sh) {
+// Round 4 (the kernel took 3 ms per frame in the entry point's trace: one workgroup per cluster walked its five columns one after the
+// other, every pass gathered the column again from global memory, and the coordinates of one cluster share their leading bytes, so
+// 256 threads added to ONE histogram bin with one LDS atomic each): a workgroup per (cluster, column); the column's keys are staged
+// in LDS once (<= MED_CAP points; larger clusters keep gathering); a wave adds a bin's count once per DISTINCT bin among its 64 keys.
+#define MED_CAP 12288
+__device__ __forceinline__ void vg_hist_add_wave(uint32_t* hist, uint32_t bin, bool active) {
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == lb) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+template <bool STAGED>
+__device__ float vg_select_keys(const float* __restrict__ pts, int stride, int col, const int* __restrict__ idx, const uint32_t* keys,
+                                int n, int k, uint32_t* hist, uint32_t* sh) {
     uint32_t prefix = 0;
+    const int n64 = (n + 63) & ~63;                    // whole waves run the aggregation (ballots need every lane of the wave)
     for (int pass = 3; pass >= 0; --pass) {
         for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
         __syncthreads();
         const int shift = pass * 8;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t key = vg_fkey(pts[(size_t)idx[i] * stride + col]);
-            if (pass == 3 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        for (int i = threadIdx.x; i < n64; i += blockDim.x) {
+            uint32_t key = 0;
+            if (i < n) key = STAGED ? keys[i] : vg_fkey(pts[(size_t)idx[i] * stride + col]);
+            const bool in = i < n && (pass == 3 || (key >> (shift + 8)) == prefix);
+            vg_hist_add_wave(hist, (key >> shift) & 255u, in);
         }
         __syncthreads();
         {   // the bin that holds rank k: exclusive prefix of the 256 counts by wave scans; exactly one thread finds it
@@ -460,17 +480,23 @@ __global__ __launch_bounds__(256) void k_cluster_medians(const float* __restrict
                                                          float* __restrict__ out) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh[6];
-    const int c = blockIdx.x;
+    __shared__ uint32_t keys[MED_CAP];
+    const int c = blockIdx.x, col = blockIdx.y;
     const int p0 = seg_off[c], n = seg_off[c + 1] - p0;
-    for (int col = 0; col < n_cols; ++col) {
-        float m = 0.f;
-        if (n > 0) {
-            const float hi = vg_select_gather(pts, stride, col, index + p0, n, n / 2, hist, sh);
-            if (n & 1) m = hi;
-            else m = (vg_select_gather(pts, stride, col, index + p0, n, n / 2 - 1, hist, sh) + hi) / 2.0f;
+    float m = 0.f;
+    if (n > 0) {
+        const int* idx = index + p0;
+        if (n <= MED_CAP) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = vg_fkey(pts[(size_t)idx[i] * stride + col]);
+            __syncthreads();
+            const float hi = vg_select_keys<true>(pts, stride, col, idx, keys, n, n / 2, hist, sh);
+            m = (n & 1) ? hi : (vg_select_keys<true>(pts, stride, col, idx, keys, n, n / 2 - 1, hist, sh) + hi) / 2.0f;
+        } else {
+            const float hi = vg_select_keys<false>(pts, stride, col, idx, keys, n, n / 2, hist, sh);
+            m = (n & 1) ? hi : (vg_select_keys<false>(pts, stride, col, idx, keys, n, n / 2 - 1, hist, sh) + hi) / 2.0f;
         }
-        if (threadIdx.x == 0) out[(size_t)c * n_cols + col] = m;
     }
+    if (threadIdx.x == 0) out[(size_t)c * n_cols + col] = m;
 }
 
 extern "C" {
@@ -479,7 +505,7 @@ int vg_cluster_medians(const float* d_points, int stride, int n_cols, const int3
                        float* d_median, void* stream) {
     if (n_clusters <= 0) return VG_OK;
     if (!d_points || !d_index || !d_seg_off || !d_median || n_cols <= 0 || n_cols > stride) return VG_ERR_ARG;
-    hipLaunchKernelGGL(k_cluster_medians, dim3(n_clusters), dim3(256), 0, (hipStream_t)stream, d_points, stride, n_cols, d_index, d_seg_off,
+    hipLaunchKernelGGL(k_cluster_medians, dim3(n_clusters, n_cols), dim3(256), 0, (hipStream_t)stream, d_points, stride, n_cols, d_index, d_seg_off,
                        d_median);
     VG_LAUNCH_CHECK();
     return VG_OK;

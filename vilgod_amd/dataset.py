@@ -26,6 +26,10 @@ class SyntheticDataset:
         self.objects_per_frame = int(_get(syn, 'objects_per_frame', 60))
         self.step = float(_get(syn, 'step', 0.5))
         self.seed = int(_get(syn, 'seed', 0))
+        # seed of sequence sid = seed + sid * seed_stride; 0 = every sequence is the SAME world under its own name (bench.py's cli_mode:
+        # several sequences of the benchmark workload; generated once)
+        self.seed_stride = int(_get(syn, 'seed_stride', 1))
+        self._gen_cache = {}
         # coherent: one world per sequence (static scene + moving objects + ego motion) -- what the entropy scores and
         # the two-frame clustering need; False: independent frames (`synthetic.make_frame`)
         self.coherent = bool(_get(syn, 'coherent', True))
@@ -57,7 +61,7 @@ class SyntheticDataset:
         for sid in range(self.start_sequence, min(self.end_sequence + 1, self.n_sequences)):
             self._seq_id = sid
             self.sequence_name = f'synthetic_{self.split}_{sid:04d}'
-            poses = synthetic.make_poses(self.frames_per_sequence, step=self.step, seed=self.seed + sid)
+            poses = synthetic.make_poses(self.frames_per_sequence, step=self.step, seed=self.seed + sid * self.seed_stride)
             self.sequence_infos = [{'pose': p, 'frame_id': f'{self.sequence_name}_{i:03d}'} for i, p in enumerate(poses)]
             base = sid * self.frames_per_sequence
             self.sequence_indices = list(range(base, base + self.frames_per_sequence))
@@ -67,7 +71,7 @@ class SyntheticDataset:
     def get_lidar_points(self, fnr):
         """(N,5) float32 [x,y,z,intensity,elongation] in the vehicle frame."""
         if not self.coherent:
-            return synthetic.make_frame(self.seed + self._seq_id * 100_003 + fnr, self.points_per_frame,
+            return synthetic.make_frame(self.seed + self._seq_id * self.seed_stride * 100_003 + fnr, self.points_per_frame,
                                         n_objects=self.objects_per_frame)
         self._generate()
         return self._frames[fnr]
@@ -82,8 +86,13 @@ class SyntheticDataset:
         if self._frames is not None:
             return
         from .fixture_data import WAYMO_NAME
-        self._frames, _, truth = synthetic.make_sequence(self.seed + self._seq_id, self.frames_per_sequence, self.points_per_frame,
-                                                         n_objects=self.objects_per_frame, step=self.step, return_objects=True)
+        gseed = self.seed + self._seq_id * self.seed_stride
+        if gseed not in self._gen_cache:
+            if self.seed_stride != 0:
+                self._gen_cache.clear()                  # (one sequence's clouds at a time: 0.6 GB per 199 x 150k-point sequence)
+            self._gen_cache[gseed] = synthetic.make_sequence(gseed, self.frames_per_sequence, self.points_per_frame,
+                                                             n_objects=self.objects_per_frame, step=self.step, return_objects=True)
+        self._frames, _, truth = self._gen_cache[gseed]
         for info, idx, t in zip(self.sequence_infos, self.sequence_indices, truth):
             n = len(t['kind'])
             info['annos'] = {'name': np.array([WAYMO_NAME.get(k, 'unknown') for k in t['kind']]), 'gt_boxes_lidar': t['box'].astype(np.float32),

@@ -37,34 +37,101 @@ from .frame_state import FrameState, pack_clusters, vote
 from .pipeline import PseudoLabelPipeline
 
 
-# The sequence-state pickle (zero_shot_detector.py:105-114 of the reference) of a 199-frame Waymo-shape sequence is ~200 MB of numpy
-# arrays: ~0.4 s of pickle.dump, nearly all of it in write() calls that release the interpreter lock.  It is handed to ONE background
-# thread (device.async_state_write, default on) so that the next sequence's GPU pass starts meanwhile; the data are the detached
-# per-detection dicts of FrameState.serialize (later stages never touch them).  At most one write is outstanding; tools/preprocess_data.py
-# waits for the last one before it returns, and a detector that is about to LOAD a file waits for any write of that file first.
-_STATE_WRITER = {'pool': None, 'pending': None}
+# The sequence-state pickle (zero_shot_detector.py:105-114 of the reference) of a 199-frame Waymo-shape sequence is ~300 MB in ~18 000
+# per-detection dicts of numpy objects: ~0.45 s of pickle.dump that holds the interpreter lock, plus ~0.08 s to build the dicts.  With
+# device.async_state_write (default on) the frames go, as FrameState.compact() arrays, to ONE helper process
+# (python -m vilgod_amd.state_writer: numpy only) that builds the dicts and writes the file, fed by one background thread, so that the
+# next sequence's GPU pass -- whose worker threads need the interpreter lock to launch kernels -- is not held up.  At most one write is
+# outstanding; tools/preprocess_data.py waits for the last one before it returns, and a detector that is about to LOAD a file waits
+# for a write of that file first.  If the helper cannot be started or dies, the file is written in the background thread instead.
+_STATE_WRITER = {'pool': None, 'pending': None, 'path': None, 'proc': None}
 
 
-def _write_state_file(path, data):
+def _write_state_file(path, compacts):
+    from .frame_state import FrameState
+    data = [FrameState.from_compact(c).serialize for c in compacts]
     tmp = str(path) + '.tmp'
     with open(tmp, 'wb') as fp:
         pickle.dump(data, fp, protocol=pickle.HIGHEST_PROTOCOL)
     os.replace(tmp, path)                                # readers never see a half-written file
 
 
-def wait_state_writes():
-    """Blocks until the outstanding background state write (if any) is on disk; re-raises its error."""
+def start_state_writer():
+    """Starts the helper process (idempotent)."""
+    if _STATE_WRITER['proc'] is not None and _STATE_WRITER['proc'].poll() is None:
+        return _STATE_WRITER['proc']
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
+    try:
+        _STATE_WRITER['proc'] = subprocess.Popen([sys.executable, '-m', 'vilgod_amd.state_writer'], stdin=subprocess.PIPE,
+                                                 stdout=subprocess.PIPE, env=env, cwd=root)
+    except OSError:
+        _STATE_WRITER['proc'] = None
+    return _STATE_WRITER['proc']
+
+
+def _write_state_via_helper(path, compacts):
+    import struct
+    p = start_state_writer()
+    if p is not None:
+        try:
+            blob = pickle.dumps((str(path), compacts), protocol=pickle.HIGHEST_PROTOCOL)
+            p.stdin.write(struct.pack('<q', len(blob)))
+            p.stdin.write(blob)
+            p.stdin.flush()
+            del blob
+            head = p.stdout.read(8)
+            if len(head) == 8:
+                (n,) = struct.unpack('<q', head)
+                status, val = pickle.loads(p.stdout.read(n))
+                if status == 'ok':
+                    return
+                raise RuntimeError(f'state writer process: {val}')
+        except (BrokenPipeError, EOFError, OSError, ValueError):
+            pass
+        import logging
+        logging.getLogger('vilgod_amd.state_writer').warning('state writer process ended; writing %s in-process', path)
+        try:
+            p.kill()
+        except Exception:               # noqa: BLE001
+            pass
+        _STATE_WRITER['proc'] = None
+    _write_state_file(path, compacts)
+
+
+def wait_state_writes(path=None):
+    """Blocks until the outstanding background state write (if any; with `path`: only a write of that file) is on disk; re-raises
+    its error."""
+    if path is not None and _STATE_WRITER['path'] != str(path):
+        return
     fut, _STATE_WRITER['pending'] = _STATE_WRITER['pending'], None
     if fut is not None:
         fut.result()
 
 
-def _submit_state_write(path, data):
+def shutdown_state_writer():
+    wait_state_writes()
+    p, _STATE_WRITER['proc'] = _STATE_WRITER['proc'], None
+    if p is not None:
+        try:
+            p.stdin.close()
+            p.wait(timeout=5)
+        except Exception:               # noqa: BLE001
+            p.kill()
+
+
+def _submit_state_write(path, compacts):
     from concurrent.futures import ThreadPoolExecutor
     wait_state_writes()
     if _STATE_WRITER['pool'] is None:
+        import atexit
         _STATE_WRITER['pool'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vilgod-state-writer')
-    _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_file, path, data)
+        atexit.register(shutdown_state_writer)
+    _STATE_WRITER['path'] = str(path)
+    _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_via_helper, path, compacts)
 
 
 class ZeroShotDetector:
@@ -102,6 +169,8 @@ class ZeroShotDetector:
         self.n_workers = int(dev.get('frames_in_flight', 6))
         self.sync_every_stage = bool(dev.get('sync_every_stage', False))
         self.async_state_write = bool(dev.get('async_state_write', True)) and not self.sync_every_stage
+        if self.async_state_write and self.rank == 0:
+            start_state_writer()                         # (numpy import in the helper: ready long before the first write)
         self.stage_ms = {}                               # stage name -> ms per (own) frame of the last process()
         self.detail_ms = {}                              # VILGOD_STAGE_DETAIL=1: wall ms of the parts of the host-heavy stages (whole sequence)
         self._detail_on = os.environ.get('VILGOD_STAGE_DETAIL', '0') == '1'
@@ -280,7 +349,7 @@ class ZeroShotDetector:
                 self._dirty = False                      # propagate_labels handed exactly this snapshot to the background writer already
                 return
             with self._part('state.serialize'):
-                data = snapshot if snapshot is not None else [f.serialize for f in self.lidar_frame_list]
+                data = snapshot if snapshot is not None else [f.compact() for f in self.lidar_frame_list]
             with self._part('state.pickle'):
                 if final and self.async_state_write:
                     _submit_state_write(path, data)      # (the one write at the end of process(): in the background, see _STATE_WRITER)
@@ -289,7 +358,7 @@ class ZeroShotDetector:
                     _write_state_file(path, data)
             self._dirty = False
         elif mode == 'load':
-            wait_state_writes()                          # (a background write of this very file may still be running)
+            wait_state_writes(path)                      # (a background write of this very file may still be running)
             if path.exists():
                 with open(path, 'rb') as fp:
                     data = pickle.load(fp)
@@ -298,22 +367,57 @@ class ZeroShotDetector:
         else:
             raise NotImplementedError(f'Mode {mode} not implemented!')
 
-    def process(self):
-        self.logger.info(f'Processing sequence: {self.name}')
+    # stages that are host logic once the tracker has run (no collective, no shared GPU handle): the tail of the shipped stage list
+    HOST_TAIL = ('fit_bounding_boxes_simple', 'propagate_labels', 'evaluate_sequence')
+
+    def split_stages(self):
+        """(front, back) of pipeline_active for tools/preprocess_data.py's sequence overlap: `back` = the trailing run of host-only
+        stages (HOST_TAIL) that may run on a background thread while the NEXT sequence's GPU stages run; empty when that is not safe
+        (several ranks: the stages hold collectives; per-stage files; device.overlap_sequences: false)."""
+        active = list(self.cfg.pipeline_active)
+        dev = self.cfg.get('device', {}) if hasattr(self.cfg, 'get') else {}
+        if self.world_size != 1 or self.sync_every_stage or not dev.get('overlap_sequences', True):
+            return active, []
+        k = len(active)
+        while k > 0 and active[k - 1] in self.HOST_TAIL:
+            k -= 1
+        return active[:k], active[k:]
+
+    def back_is_host_only(self):
+        """After process('front'): does the `back` part stay off the GPU?  The box stage does when the tracker has run (its track branch
+        reads the static boxes the helper processes prefetched during classification)."""
+        _, back = self.split_stages()
+        if not back:
+            return False
+        if 'fit_bounding_boxes_simple' in back and (self.tracker is None or len(self.tracker.tracks_valid) == 0):
+            return False
+        return True
+
+    def process(self, part='all'):
+        """part: 'all' (the reference's process(), zero_shot_detector.py:58-69), or 'front' / 'back' = the two halves of split_stages()
+        (tools/preprocess_data.py runs `back` of sequence s on a thread while `front` of sequence s + 1 runs)."""
+        active = list(self.cfg.pipeline_active)
+        front, back = self.split_stages() if part != 'all' else (active, [])
+        names = {'all': active, 'front': front, 'back': back}[part]
+        if part != 'back':
+            self.logger.info(f'Processing sequence: {self.name}')
+            self._fused = self._fusion_plan()
+            if self._fused:
+                self.logger.info(f"  per-frame work of {' + '.join(self._fused)} runs inside spatial_clustering's frame pass")
         available = [t['name'] for t in self.cfg.pipeline]
-        self._fused = self._fusion_plan()
-        if self._fused:
-            self.logger.info(f"  per-frame work of {' + '.join(self._fused)} runs inside spatial_clustering's frame pass")
-        for task_name in self.cfg.pipeline_active:
+        for task_name in names:
             if task_name in available and hasattr(self, task_name):
                 t0 = time.perf_counter()
                 getattr(self, task_name)(**self.cfg.pipeline[available.index(task_name)]['args'])
-                torch.cuda.synchronize()
+                if part != 'back':
+                    torch.cuda.synchronize()             # (the back half is host logic; a device-wide wait there would wait for the next sequence's kernels)
                 ms = 1000.0 * (time.perf_counter() - t0) / max(len(self.my_frames), 1)
                 self.stage_ms[task_name] = self.stage_ms.get(task_name, 0.0) + ms
                 self.logger.info(f'  stage {task_name}: {ms:.2f} ms per frame')
             else:
                 self.logger.warning(f'{task_name} NOT FOUND!!!')
+        if part == 'front':
+            return
         # the sequence-state pickle (zero_shot_detector.py:105-114): the reference rewrites it after every stage; here it is
         # written once per run unless device.sync_every_stage asks for the reference's per-stage files (same final content).
         # With several ranks it is written by rank 0 after the states were gathered, whatever stages ran.
@@ -858,7 +962,7 @@ class ZeroShotDetector:
             self._frozen = True                          # every rank holds every frame's state here (_exchange_states above)
             if self.rank == 0:
                 with self._part('propagate.snapshot'):
-                    self._snapshot = [f.serialize for f in self.lidar_frame_list]
+                    self._snapshot = [f.compact() for f in self.lidar_frame_list]     # (detached copies: see FrameState.compact)
                 if self.async_state_write:
                     # what the file will hold is final from here on (no later stage of the reference synchronises): the background
                     # writer starts now, under the label propagation and the evaluation, instead of at the end of process()
