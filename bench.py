@@ -9,11 +9,13 @@
 
 A "step" = one synthetic 150k-point frame through the whole per-frame path (ground removal -> ref transform -> HDBSCAN ->
 filters -> multi-view render -> CLIP ViT-B/16 fp16 encode -> scores -> vote -> boxes -> result dict).  Weak scaling: ONE
-sequence of N*K frames is sharded over the N ranks in contiguous blocks of K frames, exactly as the stage dispatcher shards a
-sequence (vilgod_amd/zero_shot_detector.py, vilgod_amd/dist.py).  Patchwork++'s adaptive state runs through the whole
-sequence: inside the timed region rank r receives the state after frame r*K - 1 from rank r - 1 (`--ground-handoff chain`,
-vg_ground_export_state / vg_ground_set_state) or replays the ground stage over the r*K frames before its block
-(`--ground-handoff replay`).  The only data-path collective is ONE all-gather of the per-crop score matrices after the K
+sequence of N*K frames is sharded over the N ranks.  Patchwork++'s adaptive state runs through the whole sequence (the sensor height
+estimated on frame i seeds frame i + 1): by default (`--ground-handoff replicate`) the frames are dealt ROUND-ROBIN (frame g -> rank
+g % N) and every rank runs the cheap stateful ground pass over all N*K frames itself, on its high-priority stream under its own
+frames' ViT work -- rank r's first frame waits for r ground passes (0.36 ms each) and nothing is exchanged; `chain` shards contiguous
+blocks of K frames like the stage dispatcher (vilgod_amd/zero_shot_detector.py, vilgod_amd/dist.py) and hands the state down the rank
+chain (vg_ground_export_state / vg_ground_set_state: rank r starts r*K passes late), `replay` re-runs the ground stage over the r*K
+frames before the block.  All inside the timed region.  The only data-path collective is ONE all-gather of the per-crop score matrices after the K
 frames (north_star).  The run is a real stream: every one of the W + K frames of a rank is a DISTINCT seeded synthetic cloud (no
 cycling -- a new crop count almost every frame), handed over as a pinned HOST buffer (SURVEY 8d's clock: "raw points resident in
 host pinned memory" to "result dict on the host"; the copy to HBM is queued inside the timed region; `--input resident` uploads
@@ -152,8 +154,10 @@ def main():
     ap.add_argument('--views', type=int, default=4)
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
     ap.add_argument('--box-mode', default='reference', choices=['reference', 'fast'])
-    ap.add_argument('--ground-handoff', default='chain', choices=['chain', 'replay'],
-                    help='N > 1: how rank r obtains the Patchwork++ state at the start of its frame block (both inside the timed region)')
+    ap.add_argument('--ground-handoff', default='replicate', choices=['replicate', 'chain', 'replay'],
+                    help='N > 1: how a rank obtains the Patchwork++ state its frames need (inside the timed region).  replicate (default): '
+                         'frames dealt round-robin, every rank runs the ground pass over the whole sequence itself, nothing is exchanged; '
+                         'chain / replay: contiguous blocks, state handed down the rank chain / ground passes of the earlier blocks replayed')
     ap.add_argument('--vit-graph', action='store_true', help='captured hipGraphs (one per crop-count bucket and worker, LRU-bounded) for the ViT instead of plain stream launches')
     ap.add_argument('--input', default='host', choices=['host', 'resident'],
                     help='host: every frame is handed over as a pinned host buffer, H2D inside the timed region (SURVEY 8d); resident: uploaded before the clock starts')
@@ -239,7 +243,25 @@ def main():
         t0 = time.perf_counter()
         p.new_sequence()
         out = []
-        if world > 1 and args.ground_handoff == 'replay':
+        if world > 1 and args.ground_handoff == 'replicate':
+            # frames dealt round-robin: frame g of the N * K frame sequence belongs to rank g % N.  Every rank queues the upload + ground
+            # pass of ALL frames, in order, on its high-priority ground stream (0.36 ms per scan: N * K passes against K * ~15 ms of own
+            # work) and processes its own frames in full; rank r's first frame waits for r ground passes, no state is exchanged.
+            # (The other ranks' clouds are not held here: this rank's own stand in, same upload and ground cost.)
+            seq = [frames[W + g // world] for g in range(world * K)]
+            seq_poses = [poses[W + g] for g in range(world * K)]
+            mine = [g for g in range(world * K) if g % world == rank]
+            if inflight == 1:
+                for g in range(world * K):
+                    d_pts = p.upload(seq[g])
+                    if g % world == rank:
+                        fs, res = p.process_frame(d_pts, seq_poses[g], poses[0], fnr=g, timing=args.stage_times)
+                        out.append((fs, res, p.last_probs))
+                    else:
+                        p.ground(d_pts)
+            else:
+                out = p.process_frames(seq, seq_poses, poses[0], n_workers=inflight, first_fnr=0, own=mine)
+        elif world > 1 and args.ground_handoff == 'replay':
             for i in range(rank * K):                    # the frames before this rank's block: ground stage only (the other ranks'
                 p.ground(p.upload(frames[W + i % K]))    # clouds are not held here: this rank's own stand in, same cost)
             out = run_steps(p, W + rank * K, K, rank * K, first_frame=W)
@@ -284,11 +306,12 @@ def main():
             return
         from vilgod_amd._lib import lib as _l
         cdev = 'cpu' if dist.get_backend() == 'gloo' else dev
-        buf = torch.zeros(int(_l.vg_ground_state_bytes()), dtype=torch.uint8, device=cdev)
-        if rank > 0:
-            dist.recv(buf, src=rank - 1)
-        if rank < world - 1:
-            dist.send(buf, dst=rank + 1)
+        if args.ground_handoff == 'chain':               # (the other modes exchange no state: no point-to-point communicator is built)
+            buf = torch.zeros(int(_l.vg_ground_state_bytes()), dtype=torch.uint8, device=cdev)
+            if rank > 0:
+                dist.recv(buf, src=rank - 1)
+            if rank < world - 1:
+                dist.send(buf, dst=rank + 1)
         one = torch.ones(1, dtype=torch.int64, device=cdev)
         dist.all_gather([torch.zeros_like(one) for _ in range(world)], one)
         if dist.get_backend() != 'gloo':
@@ -378,7 +401,8 @@ def main():
                 'workload': (f'full per-frame path (ground removal, HDBSCAN, filters, {args.views}-view render, CLIP ViT-B/16 '
                              f'{args.dtype} encode, scores, vote, boxes [{args.box_mode} mode]) on synthetic {args.points}-pt frames, '
                              f'{args.objects} objects (BASELINE config 3 shape, 4 views), ONE sequence of {frames_total} frames sharded '
-                             f'{world}-way in contiguous blocks' + (f', ground state by {args.ground_handoff}' if world > 1 else '') +
+                             f'{world}-way ' + (('round-robin, ground pass replicated on every rank (no state exchange)' if args.ground_handoff == 'replicate'
+                                                else f'in contiguous blocks, ground state by {args.ground_handoff}') if world > 1 else '(one rank)') +
                              ', one all-gather of the score matrices'),
                 'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,
                 'setup_frames': n_setup * setup_passes,

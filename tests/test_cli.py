@@ -8,6 +8,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import ROOT
 
@@ -214,13 +215,15 @@ def test_cli_sequence_sharding_equals_one_rank(cuda, tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu(cuda):
+@pytest.mark.parametrize('handoff', ['replicate', 'chain'])
+def test_bench_two_ranks_on_one_gpu(cuda, handoff):
     """bench.py's N > 1 path (barriers, padded all-gather of the score matrices, max-over-ranks timing, one JSON line from
-    rank 0) with two processes sharing the single GPU of the test box over gloo; the driver's multi-GPU runs use RCCL."""
+    rank 0) with two processes sharing the single GPU of the test box over gloo; the driver's multi-GPU runs use RCCL.
+    replicate (default): frames dealt round-robin, every rank runs all ground passes itself; chain: blocks + state hand-off."""
     import json
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2', VILGOD_DIST_BACKEND='gloo')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--points', '30000',
-           '--objects', '12', '--no-cpu-baseline', '--no-sequence-pass']
+           '--objects', '12', '--no-cpu-baseline', '--no-sequence-pass', '--no-extras', '--ground-handoff', handoff]
     import tempfile
     tmp = tempfile.mkdtemp()
     files = [(open(f'{tmp}/o{k}', 'w'), open(f'{tmp}/e{k}', 'w')) for k in range(2)]
@@ -238,6 +241,27 @@ def test_bench_two_ranks_on_one_gpu(cuda):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['value'] > 0 and d['unit'] == 'frames/s'
     assert d['value'] == pytest.approx(2 * 3 / (d['ms_per_step'] * 3 / 1000.0), rel=1e-3)       # whole-job frames / max-rank time
     assert 0 < d['roofline']['frac'] < 1 and 'cpu_baseline' not in d
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(cuda):
+    """The driver's multi-GPU command line with backend nccl (= RCCL) on two devices: init_process_group with device_id, the barriers,
+    all_gather + all_gather_into_tensor on device tensors, the all-reduce of the times -- so that the 8-GPU scaling run is not the first
+    execution of that code.  RCCL refuses two ranks on one device: skipped on the one-GPU test boxes."""
+    import json
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL refuses two ranks on one device); the gloo twin of this test runs on one')
+    env = dict(os.environ, MASTER_PORT=_free_port())
+    env.pop('VILGOD_DIST_BACKEND', None)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--points', '30000',
+                        '--objects', '12', '--no-cpu-baseline', '--no-sequence-pass', '--no-extras'], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak' and d['value'] > 0
 
 
 @pytest.mark.gpu

@@ -142,6 +142,37 @@ def test_dense_frames_six_views_in_flight_equal_sequential(cuda):
 
 
 @pytest.mark.gpu
+def test_round_robin_frames_with_replicated_ground_equal_one_rank(cuda):
+    """SURVEY 8e, bench.py --ground-handoff replicate: two "ranks" (two pipeline objects here) take the frames of one sequence
+    round-robin; each runs the stateful ground pass over ALL frames itself (process_frames(own=...)) and its own frames in full.
+    Merged, the results equal one pipeline processing the whole sequence: ground sets, clusters, validity, boxes, names, scores --
+    Patchwork++'s adaptive state reached every frame through the same passes in the same order on every rank."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    poses = synthetic.make_poses(9)
+    frames = [synthetic.make_frame(70 + f, 40_000, n_objects=16) for f in range(7)]
+    one = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=41_000, clip_model_path='/nonexistent')
+    one.new_sequence()
+    want = one.process_frames(frames, poses[1:8], poses[0], n_workers=3)
+    merged = {}
+    for r in range(2):
+        p = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=41_000, clip_model_path='/nonexistent')
+        p.new_sequence()
+        mine = [g for g in range(7) if g % 2 == r]
+        got = p.process_frames(frames, poses[1:8], poses[0], n_workers=3, own=mine)
+        assert len(got) == len(mine)
+        merged.update(dict(zip(mine, got)))
+    assert sorted(merged) == list(range(7))
+    for g in range(7):
+        (fa, ra, pa), (fb, rb, pb) = want[g], merged[g]
+        assert fa.fnr == fb.fnr == g
+        assert np.array_equal(np.sort(fa.ground_point_indices), np.sort(fb.ground_point_indices))
+        assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off) and np.array_equal(fa.valid, fb.valid)
+        assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+        assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
+    assert sum(len(r['name']) for _, r, _ in want) > 0
+
+
+@pytest.mark.gpu
 def test_f16_pipeline_agrees_with_f32_pipeline_on_150k_frames(cuda):
     """The benchmarked fp16 pipeline against the fp32 (oracle-pinned, test_pipeline_matches_oracle_20k) pipeline on three synthetic
     150k-point frames: everything before the ViT is the same code -> ground set, clusters, valid flags and boxes EQUAL; per-crop

@@ -164,12 +164,20 @@ class PseudoLabelPipeline:
         parts = [f.result() for f in futs]
         return [parts[i % n_workers][i // n_workers] for i in range(len(items))]
 
-    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0, after_ground=None):
+    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0, after_ground=None, own=None):
         """Throughput mode: frames (list of CUDA/numpy point arrays) are processed with `n_workers` frames in flight,
         each on its own HIP stream with its own handles.  Ground segmentation is stateful across frames and runs in
         frame order on the caller's stream; everything else of a frame runs on a worker stream after an event wait.
         `after_ground()` is called once all ground passes are queued, before the results are awaited.
-        Returns [(FrameState, result dict, probs tensor)] in frame order."""
+        own: indices into `frames` this caller processes in full (default: all).  The other frames only go through upload + ground
+        segmentation, in their place in the order: with several ranks every rank runs the cheap, stateful ground pass over the WHOLE
+        sequence itself (0.36 ms per 150k-point scan on a high-priority stream, under its own frames' ViT work) and the frames are
+        dealt round-robin, so rank r's first frame waits for r ground passes instead of r whole blocks and no state travels
+        (bench.py --ground-handoff replicate).
+        Returns [(FrameState, result dict, probs tensor)] of the own frames, in frame order."""
+        own_set = None if own is None else set(int(i) for i in own)
+        own_idx = list(range(len(frames))) if own_set is None else sorted(own_set)
+        slot = {i: k for k, i in enumerate(own_idx)}             # frame index -> position among the own frames
         workers = self._ensure_workers(n_workers)
         # the ground passes chain the frames (and, with several ranks, the ranks: the next rank waits for the state after this block):
         # they run on a HIGH-PRIORITY stream of their own so that their small kernels are dispatched ahead of the workers' heavy ones
@@ -184,13 +192,14 @@ class PseudoLabelPipeline:
         # else hides behind -- begins after ~25 ms instead of ~10; a ViT pass (~15 ms) is longer than a lone front stage, so the chain
         # never starves the encoder.  Frames after the first round are not gated.
         ramp = os.environ.get('VILGOD_FILL_RAMP', '1') != '0' and n_workers > 1
-        front_done = [threading.Event() for _ in range(min(n_workers, len(frames)))]
+        front_done = [threading.Event() for _ in range(min(n_workers, len(own_idx)))]
 
         frame_log = [] if os.environ.get('VILGOD_FRAME_LOG') else None      # development aid: per-frame host timeline of the block
         t_block = time.perf_counter()
 
         def run(worker, i, d_pts, mask, ev):
-            gate = front_done[i] if ramp and i < len(front_done) else None
+            k_ = slot[i]
+            gate = front_done[k_] if ramp and k_ < len(front_done) else None
             t_start = time.perf_counter()
             t_front = [None]
 
@@ -199,8 +208,8 @@ class PseudoLabelPipeline:
                 if gate is not None:
                     gate.set()
             try:
-                if gate is not None and i > 0:
-                    front_done[i - 1].wait()
+                if gate is not None and k_ > 0:
+                    front_done[k_ - 1].wait()
                 t_go = time.perf_counter()
                 with torch.cuda.stream(worker.stream):
                     worker.stream.wait_event(ev)
@@ -222,12 +231,12 @@ class PseudoLabelPipeline:
         # 52.1 -> 60.3 frames/s in 20-frame blocks, 96-frame blocks unchanged).
         from concurrent.futures import Future
         import queue
-        futures = [Future() for _ in frames]
+        futures = {i: Future() for i in own_idx}
         jobs = queue.Queue()
 
         # (the block's first n_workers frames still go one to each worker: a short warm-up block then exercises every worker's
         # stream, allocator pool and ViT workspace)
-        n_active = min(n_workers, len(frames))
+        n_active = min(n_workers, len(own_idx))
         first = [queue.Queue() for _ in range(n_active)]
 
         def drain(worker, k):
@@ -248,10 +257,12 @@ class PseudoLabelPipeline:
                 for i, pts in enumerate(frames):
                     d_pts = self.upload(pts)
                     mask = self.ground(d_pts)
+                    if own_set is not None and i not in own_set:
+                        continue                 # another rank's frame: only the ground state moves on
                     ev = torch.cuda.Event()
                     ev.record(main)
-                    (first[i] if i < n_active else jobs).put((i, d_pts, mask, ev))
-                    fed = i + 1
+                    (first[fed] if fed < n_active else jobs).put((i, d_pts, mask, ev))
+                    fed += 1
                 if after_ground is not None:
                     after_ground()         # every ground pass of the block is queued: e.g. hand the ground state to the next rank
         finally:
@@ -259,12 +270,12 @@ class PseudoLabelPipeline:
                 first[k].put(None)             # (only when an upload / ground pass failed before the first round was out)
             for _ in drains:
                 jobs.put(None)                 # one stop mark per draining worker, behind the last frame
-            if fed < len(frames):
+            if fed < len(own_idx):
                 for d in drains:               # ... let the frames already handed out finish before the error goes up
                     d.result()
         out, first_error = [], None
         try:
-            for f in futures:                  # drain every worker even when one frame failed: nothing keeps running behind the caller's back
+            for f in (futures[i] for i in own_idx):     # drain every worker even when one frame failed: nothing keeps running behind the caller's back
                 try:
                     out.append(f.result())
                 except BaseException as e:     # noqa: BLE001
