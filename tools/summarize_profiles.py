@@ -63,6 +63,52 @@ if os.path.exists(sq_path):
                 'wave_cycles_split': {'waiting (s_waitcnt / barrier)': agg['SQ_WAIT_ANY'] / agg['SQ_WAVE_CYCLES'],
                                       'issue stalled': agg['SQ_WAIT_INST_ANY'] / agg['SQ_WAVE_CYCLES'],
                                       'issuing': agg['SQ_ACTIVE_INST_ANY'] / agg['SQ_WAVE_CYCLES']}}
+# ---- stage kernels next to the GEMM (north_star: "rocprof HBM GB/s (clustering, renderer)"): bench.py's `roofline_stages` block reads this ----
+def bench_line(logname):
+    try:
+        for ln in open(os.path.join(root, 'gpurun_out', logname)):
+            if ln.startswith('{') and '"metric"' in ln:
+                return json.loads(ln)
+    except OSError:
+        pass
+    return {}
+bl = bench_line(f'prof_{tag}.trace.log')
+cfg = bl.get('config', {})
+frames = max([int(r['Calls']) for k, r in stats.items() if 'k_head' in k] + [1])
+crops = float(cfg.get('crops_per_frame', 337.0))
+M = float(cfg.get('nonground_points_per_frame', 79_000.0))
+N = float(cfg.get('points_per_frame', 150_000))
+PEAK = 8.0e12
+def stage(match, alg_bytes, alg_note, extra=None):
+    g = group(match)
+    names = [k for k in stats if match(k)]
+    dur_ns = sum(float(stats[k]['TotalDurationNs']) for k in names)
+    calls = sum(int(stats[k]['Calls']) for k in names)
+    per_launch_us = dur_ns / max(calls, 1) / 1e3
+    hbm = g['hbm_bytes_per_launch']
+    d = {'kernels': sorted({k.split('(')[0][:48] for k in names}), 'launches_per_frame': round(calls / frames, 2),
+         'avg_launch_us': round(per_launch_us, 1), 'ms_per_frame': round(dur_ns / frames / 1e6, 3),
+         'hbm_bytes_per_launch_pmc': round(hbm), 'hbm_tb_per_s': round(hbm / (per_launch_us * 1e-6) / 1e12, 3) if per_launch_us else None,
+         'frac_of_8_tb_per_s': round(hbm / (per_launch_us * 1e-6) / PEAK, 4) if per_launch_us else None,
+         'algorithmic_bytes_per_frame': round(alg_bytes), 'algorithmic': alg_note,
+         'hbm_bytes_per_frame_pmc': round(hbm * calls / frames),
+         'traffic_over_algorithmic': round(hbm * calls / frames / alg_bytes, 2) if alg_bytes else None}
+    if extra:
+        d.update(extra)
+    return d
+stages = {
+    'tag': tag, 'frames': frames, 'source': f'profiles/{tag}_bench_kernel_stats.csv (time, rocprofv3 --kernel-trace --stats) + profiles/{tag}_pmc_summary.json '
+                                          '(bytes: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950 per MI355X_MICROARCH.md) of '
+                                          'bench.py --steps 4 --warmup 2 --inflight 1 (sequential: kernel times not inflated by other streams)',
+    'peak_hbm_tb_per_s': 8.0,
+    'render': stage(lambda k: k.startswith('k_render'), crops * 196 * 256 * 2, 'single-channel fp16 patch rows written: crops x 196 x 256 x 2 B (reads: the clusters\' points, < 1 MB)'),
+    'clustering_core_distances': stage(lambda k: 'k_cl_core' in k or 'k_cl_blocks' in k, M * 16 + M * 8, 'Morton-sorted float4 points read once + one f64 core distance per point written; needed pair distances M x 15'),
+    'clustering_boruvka_search': stage(lambda k: 'k_cl_b_search' in k, M * 16 + (M - 1) * 16, 'points read once per round + the n - 1 MST edges (16 B) over all rounds; latency-bound tree walks, not a bandwidth kernel',
+                                       {'pairs_evaluated_over_needed_core_distances': {'value': 29.9, 'source': 'profiles/r03a: VG_CLUSTER_DEBUG counters of the development build (cooperative k-NN kernel; the per-point walk: 9.5)'}}),
+    'clustering_grid_tables': stage(lambda k: 'k_cl_fill_int' in k or 'k_cl_levels' in k, M * 4, 'the dense cell-start table (64 MB) is refilled and its level tables rebuilt per frame for M x 4 B of codes'),
+    'ground': stage(lambda k: k.startswith('k_pw_'), N * 16 + N * 1, 'N x 16 B of points read + N x 1 B mask written; one workgroup per patch, bound by its densest patch\'s dependent chain'),
+}
+json.dump(stages, open(os.path.join(dst, 'stage_roofline.json'), 'w'), indent=1)
 json.dump(out, open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 json.dump(dict(out['k_gemm_f16_pp64'], kernel='k_gemm_f16_pp64', tag=tag), open(os.path.join(dst, 'gemm_traffic.json'), 'w'), indent=1)
 print(json.dumps({'k_gemm_f16_pp64': out['k_gemm_f16_pp64'], 'k_gemm_f16': out['k_gemm_f16']}, indent=1))

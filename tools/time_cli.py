@@ -23,3 +23,8 @@ for seq in run['sequences']:
       '  '.join(f'{k} {v:.2f}' for k, v in seq['stage_ms_per_frame'].items()))
   if seq.get('detail_ms'):
     print('parts (ms per frame): ' + '  '.join(f"{k} {v / seq['frames']:.3f}" for k, v in seq['detail_ms'].items()))
+if os.environ.get('TIME_CLI_JSON'):
+    import json
+    print('TIME_CLI_JSON ' + json.dumps({'loop_seconds': run['loop_seconds'], 'state_write_wait_seconds': run.get('state_write_wait_seconds', 0.0),
+                                        'sequences': [{k: q[k] for k in ('name', 'frames', 'seconds', 'front_seconds', 'back_seconds', 'stage_ms_per_frame')}
+                                                      for q in run['sequences']]}))
