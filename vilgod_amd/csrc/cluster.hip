@@ -831,6 +831,9 @@ __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
 // (that workgroup needs all 160 KB of LDS and every vector register), and the dispatcher deals workgroups round-robin over the CUs:
 // 309 workgroups of 256 threads sit on all 256 CUs for the launch's ~300 us, 155 of 512 threads on 155 (two waves per SIMD either way:
 // 172 registers, 88 KB of stack per CU).  FAR: the far_list / far_flag entry paths of the cooperative search (development build).
+// Measured and dropped (round 4): rounds >= 2 over a compacted list of the points that still have to walk (a few thousand; one 6 us
+// launch builds it): bit-identical, and the rounds take as long as before (332 vs 316 us: a round lasts as long as its longest walks,
+// however few waves carry them) while the pipeline's frames/s do not move (65.1 vs 65.2) -- the walks do not keep GEMM tiles waiting.
 template <int DIM, int NT = 256, bool FAR = false>
 __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                      const ClGrid* __restrict__ gp, const int* __restrict__ cs,
