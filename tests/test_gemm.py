@@ -104,3 +104,32 @@ def test_gemm_fp16_residual_epilogue(cuda, shape):
     assert ((got - want).abs() <= 2.5 * ulp).all(), ((got - want).abs() / ulp).max().item()
     assert (got == want).float().mean().item() > 0.9, (got == want).float().mean().item()
     assert lib.vg_gemm(1, 4, ptr(Xd), ptr(Wd), ptr(bd), None, ptr(R), M, 128, K, stream_ptr()) == 1     # N % 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+@pytest.mark.parametrize('shape', [(256, 768, 768), (128, 2304, 768), (256, 768, 3072), (384, 128, 16), (128, 3072, 768)])
+def test_gemm_f32_on_the_matrix_cores_equals_the_vector_kernel(cuda, epi, shape, monkeypatch):
+    """The fp32 parity tower's GEMM on v_mfma_f32_32x32x2_f32 (M % 128 == 0 and N % 128 == 0; round 4) against the 4 x 4 micro-tile
+    vector-ALU kernel it replaces (VG_GEMM_F32_MFMA=0): the instruction performs, per output element, two exact fused multiply-adds in
+    k order -- the same fmaf chain over ascending k -- so the results are required to be BIT-IDENTICAL, every epilogue."""
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    X = (torch.randn(M, K, generator=g) * 0.5).to(cuda)
+    W = torch.randn(N, K, generator=g) * 0.05
+    W[:, 0] += torch.arange(N) * 1e-3
+    W = W.to(cuda)
+    bias = (torch.randn(N, generator=g) * 0.1).to(cuda)
+    resid = torch.randn(M, N, generator=g)
+    outs = []
+    for mode in ('1', '0'):
+        monkeypatch.setenv('VG_GEMM_F32_MFMA', mode)
+        C = torch.zeros(M, N, dtype=torch.float32, device=cuda)
+        R = resid.clone().to(cuda)
+        check(lib.vg_gemm(0, epi, ptr(X), ptr(W), ptr(bias), ptr(C), ptr(R), M, N, K, stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((R if epi == 2 else C).clone())
+    want = _ref(X.cpu(), W.cpu(), bias.cpu(), resid, epi)
+    assert (outs[0].cpu() - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item())
+    assert torch.equal(outs[0], outs[1])

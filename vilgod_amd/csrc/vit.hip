@@ -551,6 +551,96 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float* __restrict__ X, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32 parity-mode GEMM on the matrix cores (round 4): v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, each instruction two exact
+// fused multiply-adds per output element in k order, i.e. the same fmaf chain over ascending k as k_gemm_f32 above (the tower's
+// numbers do not change), at the vector-ALU peak rate but with 1/32 of the LDS reads per FLOP of the 4 x 4 micro-tile kernel.
+// 128 x 128 tile, 256 threads = 2 x 2 waves of 64 x 64 (2 x 2 blocks of 32 x 32: 64 accumulator registers), K-step 16.
+// LDS tiles are k-major ([16][128 + 4] floats per operand): lane l reads A[k0 + l / 32][row l % 32] -- 32 consecutive floats per
+// half-wave, conflict-free.  The next K-step's global loads (a float4 along k per thread and operand half) are in registers while the
+// current one is multiplied.  D layout of the 32 x 32 instruction: register j of lane l = token 8 (j / 4) + 4 (l / 32) + j % 4,
+// feature l % 32 -> a store instruction writes two 128-byte row segments.
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+#define GF_LD 132
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32_mfma(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, float* __restrict__ Cout,
+                                                       float* __restrict__ resid, int M, int N, int K) {
+    __shared__ float As[16 * GF_LD];
+    __shared__ float Bs[16 * GF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = N / 128;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int l32 = lane & 31, lk = lane >> 5;
+    // staging: thread t moves rows (t >> 2) and (t >> 2) + 64 of each operand, k quad t & 3
+    const int srow = tid >> 2, skq = (tid & 3) * 4;
+    float4 xa, xb, wa, wb;
+    auto fetch = [&](int k0) {
+        xa = *(const float4*)(X + (size_t)(m0 + srow) * K + k0 + skq);
+        xb = *(const float4*)(X + (size_t)(m0 + srow + 64) * K + k0 + skq);
+        wa = *(const float4*)(Wt + (size_t)(n0 + srow) * K + k0 + skq);
+        wb = *(const float4*)(Wt + (size_t)(n0 + srow + 64) * K + k0 + skq);
+    };
+    auto stage = [&]() {
+        const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xb.x, xb.y, xb.z, xb.w}};
+        const float ws[2][4] = {{wa.x, wa.y, wa.z, wa.w}, {wb.x, wb.y, wb.z, wb.w}};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                As[(skq + e) * GF_LD + srow + 64 * h] = xs[h][e];
+                Bs[(skq + e) * GF_LD + srow + 64 * h] = ws[h][e];
+            }
+    };
+    f32x16m acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        stage();
+        __syncthreads();
+        if (k0 + 16 < K) fetch(k0 + 16);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[(kk + lk) * GF_LD + wm + 32 * i + l32];
+                b[i] = Bs[(kk + lk) * GF_LD + wn + 32 * i + l32];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + l32;
+            const float bn = EPI != EPI_NONE_F32 ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * lk + (r & 3);
+                float v = acc[i][j][r];
+                if (EPI != EPI_NONE_F32) v += bn;
+                if (EPI == EPI_BIAS_GELU) v = v / (1.0f + expf(-1.702f * v));
+                if (EPI == EPI_BIAS_RESID)
+                    resid[(size_t)m * N + n] += v;
+                else
+                    Cout[(size_t)m * N + n] = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // im2col of CHW crops into patch rows: P[(crop*G*G + py*G + px)][c*ps*ps + i*ps + j]
 template <typename TI, typename TO>
 __global__ void k_im2col(const TI* __restrict__ crops, TO* __restrict__ P, int n, int res, int ps) {
@@ -1000,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_attention_f32(const float* __restrict__
     extern __shared__ float sm[];
     float* Ks = sm;                 // [T][65]
     float* Vs = sm + (size_t)T * 65;  // [T][64]
-    float* Ps = Vs + (size_t)T * 64;  // [4 waves][T]
+    float* Ps = Vs + (size_t)T * 64;  // [4 waves][4 rows][T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int crop = blockIdx.x / heads, head = blockIdx.x - crop * heads;
     const size_t row0 = (size_t)crop * T;
@@ -1012,34 +1102,76 @@ __global__ __launch_bounds__(256) void k_attention_f32(const float* __restrict__
         Vs[key * 64 + d] = qbase[(size_t)key * ld + 2 * W + d];
     }
     __syncthreads();
-    float* P = Ps + wave * T;
-    for (int q = wave; q < T; q += 4) {
-        float qd = qbase[(size_t)q * ld + lane] * 0.125f;   // q scaled before QK^T like nn.MultiheadAttention
-        float mx = -INFINITY;
+    // Four query rows per wave at a time (round 4; one row at a time spent an LDS read on every multiply-add: 2.2 ms per layer for 64
+    // crops, half of the fp32 tower): a K / V element read from LDS serves four rows, the query and probability values come out of
+    // registers as wave-uniform scalars (v_readlane).  Per (row, key) the same fmaf chain over d, per (row, feature) the same chain over
+    // the keys as before: the numbers do not change.
+    constexpr int QB = 4;
+    float* P = Ps + wave * QB * T;
+    for (int q0 = wave * QB; q0 < T; q0 += 4 * QB) {
+        float qd[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) qd[j] = q0 + j < T ? qbase[(size_t)(q0 + j) * ld + lane] * 0.125f : 0.f;   // q scaled before QK^T like nn.MultiheadAttention
+        float mx[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) mx[j] = -INFINITY;
         for (int k0 = 0; k0 < T; k0 += 64) {
-            int key = k0 + lane;
-            float s = 0.f;
+            const int key = k0 + lane;
+            const float* kr = Ks + (key < T ? key : T - 1) * 65;
+            float sacc[QB] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
             for (int d = 0; d < 64; ++d) {
-                float qv = __shfl(qd, d);
-                if (key < T) s = fmaf(qv, Ks[key * 65 + d], s);
+                const float kv = kr[d];
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    sacc[j] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qd[j]), d)), kv, sacc[j]);
             }
             if (key < T) {
-                P[key] = s;
-                mx = fmaxf(mx, s);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    P[j * T + key] = sacc[j];
+                    mx[j] = fmaxf(mx[j], sacc[j]);
+                }
             }
         }
-        mx = vg_wave_max(mx);
-        float sum = 0.f;
-        for (int key = lane; key < T; key += 64) {
-            float p = expf(P[key] - mx);
-            P[key] = p;
-            sum += p;
+        float sum[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            mx[j] = vg_wave_max(mx[j]);
+            float sj = 0.f;
+            for (int key = lane; key < T; key += 64) {
+                const float p = expf(P[j * T + key] - mx[j]);
+                P[j * T + key] = p;
+                sj += p;
+            }
+            sum[j] = vg_wave_sum(sj);
         }
-        sum = vg_wave_sum(sum);
         __builtin_amdgcn_s_waitcnt(0);
-        float o = 0.f;
-        for (int key = 0; key < T; ++key) o = fmaf(P[key], Vs[key * 64 + lane], o);
-        out[(row0 + q) * (size_t)W + head * 64 + lane] = o / sum;
+        float o[QB] = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < T; k0 += 64) {
+            float pv[QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) pv[j] = k0 + lane < T ? P[j * T + k0 + lane] : 0.f;
+            const int nk = T - k0 < 64 ? T - k0 : 64;
+            if (nk == 64) {
+#pragma unroll
+                for (int kk = 0; kk < 64; ++kk) {
+                    const float vv = Vs[(k0 + kk) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < QB; ++j)
+                        o[j] = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pv[j]), kk)), vv, o[j]);
+                }
+            } else {
+                for (int kk = 0; kk < nk; ++kk) {
+                    const float vv = Vs[(k0 + kk) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < QB; ++j) o[j] = fmaf(__shfl(pv[j], kk), vv, o[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+            if (q0 + j < T) out[(row0 + q0 + j) * (size_t)W + head * 64 + lane] = o[j] / sum[j];
     }
 }
 
@@ -2098,9 +2230,15 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                            resid, M, N, K, ldc, gemm_chunk_tiles(N, K));
     } else {
         if (M % 64 || N % 64 || K % 16) return VG_ERR_ARG;
-        int nwg = (M / 64) * (N / 64);
-        hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nwg), dim3(256), 0, st, (const float*)X, (const float*)Wt, bias,
-                           (float*)C, resid, M, N, K);
+        const char* mf = getenv("VG_GEMM_F32_MFMA");           // A/B aid: 0 = the vector-ALU kernel for every shape
+        if (M % 128 == 0 && N % 128 == 0 && !(mf && atoi(mf) == 0)) {
+            hipLaunchKernelGGL((k_gemm_f32_mfma<EPI>), dim3((M / 128) * (N / 128)), dim3(256), 0, st, (const float*)X, (const float*)Wt, bias,
+                               (float*)C, resid, M, N, K);
+        } else {
+            int nwg = (M / 64) * (N / 64);
+            hipLaunchKernelGGL((k_gemm_f32<EPI>), dim3(nwg), dim3(256), 0, st, (const float*)X, (const float*)Wt, bias,
+                               (float*)C, resid, M, N, K);
+        }
     }
     VG_LAUNCH_CHECK();
     return VG_OK;
@@ -2512,7 +2650,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
                 if (rc) return rc;
             }
         } else {
-            size_t lds = ((size_t)T * 65 + (size_t)T * 64 + 4 * (size_t)T) * sizeof(float);
+            size_t lds = ((size_t)T * 65 + (size_t)T * 64 + 16 * (size_t)T) * sizeof(float);
             static bool attr = false;
             if (!attr) {
                 VG_CHECK(hipFuncSetAttribute((const void*)k_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
