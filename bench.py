@@ -395,6 +395,42 @@ def main():
         all_launches, all_ms, all_flops = pipe.clip.encoder.profile_read(kind=-1)
         pipe.clip.encoder.profile(False)
 
+    # The tower the way the pipeline runs it: TWO encodes in flight (pipeline._vit_in_turn), every kernel of the tower counted.  The
+    # sequential pass above times one launch at a time and so pays, per launch, for the partial last round of 256 x 256 tiles (333 crops
+    # are 257 row tiles x 3 column tiles = 3.01 rounds of 256 CUs for out_proj / c_proj); two encodes in flight fill each other's tails,
+    # which is what the timed region sees (tools/exp_tile_tail.py: 40.4 us per crop whatever the crop count, against 42-46 with one).
+    tower2 = None
+    if not args.no_roofline_pass and not args.stage_times and args.dtype == 'f16':
+        import threading
+        n_cr = int(round(sum(p_.shape[0] for _, _, p_ in outs) / max(len(outs), 1))) or 337
+        rows2 = (n_cr * 196 + 255) // 256 * 256
+        views2 = [pipe.clip.encoder.view(), pipe.clip.encoder.view()]
+        streams2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        pat2 = [(torch.randint(0, 256, (rows2, 256), device=dev).float() / 256).half() for _ in range(2)]
+        reps2 = 8
+
+        def loop2(k, reps):
+            with torch.cuda.stream(streams2[k]):
+                for _ in range(reps):
+                    views2[k].encode_patches(pat2[k], n_cr)
+                streams2[k].synchronize()
+        for k in range(2):
+            loop2(k, 2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        th2 = [threading.Thread(target=loop2, args=(k, reps2)) for k in range(2)]
+        [t.start() for t in th2]
+        [t.join() for t in th2]
+        torch.cuda.synchronize()
+        t2 = (time.perf_counter() - t2) / (2 * reps2)
+        tower2 = {'crops': n_cr, 'ms_per_encode': round(1000.0 * t2, 3), 'us_per_crop': round(1e6 * t2 / n_cr, 2),
+                  'achieved': round(VIT_FLOP_PER_CROP * n_cr / t2 / 1e12, 1), 'unit': 'TFLOP/s',
+                  'frac': round(VIT_FLOP_PER_CROP * n_cr / t2 / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                  'note': 'the whole ViT-B/16 tower (projection GEMMs, attention, embedding, head: 35.1 GFLOP per crop, SURVEY 8d) on random '
+                          'single-channel patch rows of the stream\'s mean crop count, two encodes in flight on two streams as in the pipeline; wall '
+                          'time per encode.  Not the kernel roofline (that is `frac` above, one launch at a time): what the timed region gets'}
+        del views2, pat2
+
     if rank == 0:
         frames_total = world * K
         value = frames_total / elapsed
@@ -445,6 +481,7 @@ def main():
                 'launches': launches, 'avg_launch_us': round(1000.0 * gemm_ms / max(launches, 1), 2),
                 'algorithmic_flops_per_launch': round(gemm_flops / max(launches, 1)),
                 'gemm_ms_per_frame': round(gemm_ms / max(n_pass, 1), 3),
+                'tower_two_in_flight': tower2,
                 'all_projection_gemms': {'launches': all_launches,
                                          'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
                                          'ms_per_frame': round(all_ms / max(n_pass, 1), 3)},

@@ -1084,6 +1084,14 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
 #undef AT_STAMP
 }
 
+// Measured and dropped (round 4): k_attention_f16_dma -- K and V double-buffered in LDS and filled by LDS-DMA (8-row x 128-byte pieces,
+// chunk swizzle by the reversed bits of row >> 1: conflict-free for the K fragment reads and the transposing V reads), the next item
+// requested under this item's MFMAs and softmax, no staging phase, one barrier per item, 207 instead of 249 VGPRs.  Two things the
+// compiler needed: the transposing reads as inline asm (through the builtin it waits vmcnt(0) in front of the first one: it cannot see
+// that the DMA in flight fills the other buffers) and a raw s_barrier (__syncthreads adds vmcnt(0) for the output stores).
+// Bit-identical to this kernel; 111.5 vs 114 us per launch alone (337 crops, two interleaved pairs), 65.2 vs 65.2 frames/s in the
+// pipeline.  With the whole staging phase gone the item is as long as before: it is bound by the two waves that share a SIMD (seven
+// waves on four SIMDs: 2 : 2 : 2 : 1) issuing their softmax and MFMA streams one after the other, not by getting K and V into LDS.
 // fp32 parity-mode attention: one workgroup per (crop, head); K,V in LDS; one wave per query row at a time.
 __global__ __launch_bounds__(256) void k_attention_f32(const float* __restrict__ qkv, float* __restrict__ out, int T,
                                                        int W, int heads) {
