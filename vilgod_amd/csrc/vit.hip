@@ -1580,6 +1580,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     const int xo0 = (grp * 128 + r15) * 128 + ((q4 ^ swz) << 4), xo1 = (grp * 128 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int wo0 = (wn * 64 + r15) * 128 + ((q4 ^ swz) << 4), wo1 = (wn * 64 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int np = K / 64;                         // host guarantees K % 64 == 0 and np >= 2
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the rings (inline-asm reads)
     // folded LayerNorm, consumer side: thread t < 256 merges the K / 256 partials of tile row t into (mean, rstd) here, where the
     // loads' latency hides behind the prologue's DMA (in the epilogue it cost ~7 us per tile), and carries two registers
     float2 ln_row = make_float2(0.f, 0.f);
@@ -1628,28 +1629,51 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
         PP_BAR()
         if (TRACE) c2 = clock64();
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) fa2[ni] = *(const f16x8*)(wb + wo1 + ni * 2048);
-        // the second k32 sub-step's x fragments go into the registers the first sub-step has consumed, TWO MFMA groups
-        // later (a ds_read into a register that in-flight MFMAs still read stalls the issue: 1370 instead of 1024 cycles)
-        __builtin_amdgcn_sched_barrier(0);      // pin the issue order: left alone, hipcc sinks every reload next to its consumer
-                                                // and waits lgkmcnt(0) there (4 exposed LDS latencies per segment)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0);
-            if (mi >= 2) fb[mi - 2] = *(const f16x8*)(xb + xo1 + (mi - 2) * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa2[ni], fb[mi], acc[ni][mi], 0, 0, 0);
-            if (mi < 2) fb[TM - 2 + mi] = *(const f16x8*)(xb + xo1 + (TM - 2 + mi) * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // The second k32 sub-step's fragments are read DURING the first sub-step's MFMAs, by inline-asm ds_read_b128 with counted waits
+        // (round 4).  Written as plain loads hipcc put `s_waitcnt lgkmcnt(0)` in front of the segment's first MFMA (right behind the four
+        // W reads it had just issued: their whole LDS latency exposed) and again in front of the second sub-step (behind the x reload it
+        // had issued three MFMAs earlier): MMA segment 1 180 cycles for 1 024 cycles of MFMAs.  Now: MFMA group 0 starts at once (its
+        // operands were read in the LOAD segment), the four W reads follow it, the x fragment mi is re-read two groups after its last use
+        // (a read into a register an in-flight MFMA still reads stalls the issue), and every group of the second sub-step waits only for
+        // the reads it consumes -- LDS returns in order, so `lgkmcnt(n)` with n = the reads issued after them.  The wait names its
+        // registers as operands: the MFMAs that consume them cannot be scheduled in front of it (guide 5.4 rule 18).  Same MFMAs on
+        // the same operands in the same order: the same numbers.  Interleaved with the compiler-placed form on one box (M = 66 560): in_proj 247.8 vs
+        // 258.3 us, c_fc + QuickGELU 327.9 vs 337.0, out_proj 136.3 vs 138.1, c_proj 340.7 vs 348.3; 13.01 vs 13.33 ms of GEMMs per frame.
+        const unsigned xa1 = lds0 + (unsigned)((j & 1) * XBUF + xo1), wa1 = lds0 + (unsigned)(WBASE + (j % 3) * WBUF + wo1);
+#define PP_DS128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define PP_GROUP(FA, MI)                                                                                              \
+        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                                             \
+            acc[ni][MI] = __builtin_amdgcn_mfma_f32_16x16x32_f16(FA[ni], fb[MI], acc[ni][MI], 0, 0, 0);
+        PP_GROUP(fa, 0)
+        PP_DS128(fa2[0], wa1, 0); PP_DS128(fa2[1], wa1, 2048); PP_DS128(fa2[2], wa1, 4096); PP_DS128(fa2[3], wa1, 6144);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 2) PP_DS128(fb[0], xa1, 0);          __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 3) PP_DS128(fb[1], xa1, 2048);       __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 4) PP_DS128(fb[2], xa1, 2 * 2048);   __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 5) PP_DS128(fb[3], xa1, 3 * 2048);   __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 6) PP_DS128(fb[4], xa1, 4 * 2048);   __builtin_amdgcn_sched_barrier(0);
+        PP_GROUP(fa, 7) PP_DS128(fb[5], xa1, 5 * 2048);   __builtin_amdgcn_sched_barrier(0);
+        // reads in flight, oldest first: fa2[0..3], fb[0..5]; fb[6], fb[7] follow groups 0 and 1 of the second sub-step
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa2[0]), "+v"(fa2[1]), "+v"(fa2[2]), "+v"(fa2[3]), "+v"(fb[0]));
+        PP_GROUP(fa2, 0) PP_DS128(fb[6], xa1, 6 * 2048);  __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fb[1]));
+        PP_GROUP(fa2, 1) PP_DS128(fb[7], xa1, 7 * 2048);  __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fb[2]));
+        PP_GROUP(fa2, 2) __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fb[3]));
+        PP_GROUP(fa2, 3) __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fb[4]));
+        PP_GROUP(fa2, 4) __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[5]));
+        PP_GROUP(fa2, 5) __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fb[6]));
+        PP_GROUP(fa2, 6) __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[7]));
+        PP_GROUP(fa2, 7) __builtin_amdgcn_sched_barrier(0);
+#undef PP_GROUP
+#undef PP_DS128
         __builtin_amdgcn_s_setprio(0);
         if (TRACE) c3 = clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my pieces issued in this phase have landed
