@@ -215,6 +215,19 @@ def test_cli_sequence_sharding_equals_one_rank(cuda, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_two_processes_per_gpu(cuda, tmp_path):
+    """device.processes_per_gpu=2 under torch.distributed.run (tools/time_cli.py PROCS=2 starts it the way a user would): two ranks
+    share cuda:0, rank r walks sequences r, r + 2, ...; gloo process group chosen by the entry point itself."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'time_cli.py'), '6', '20000', 'dataset.SYNTHETIC.objects_per_frame=10'],
+                       env=dict(os.environ, PROCS='2', SEQUENCES='2', SEED_STRIDE='1', TIME_CLI_JSON='1'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    run = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('TIME_CLI_JSON ')][-1][len('TIME_CLI_JSON '):])
+    assert run['processes'] == 2 and [q['frames'] for q in run['sequences']] == [6, 6]
+    assert [q['name'] for q in run['sequences']] == ['synthetic_train_0000', 'synthetic_train_0001'] and run['loop_seconds'] > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('handoff', ['replicate', 'chain'])
 def test_bench_two_ranks_on_one_gpu(cuda, handoff):
     """bench.py's N > 1 path (barriers, padded all-gather of the score matrices, max-over-ranks timing, one JSON line from

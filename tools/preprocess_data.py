@@ -52,9 +52,13 @@ def main(argv=None):
     if cfg.get('random_seed', False):
         set_random_seed(cfg.random_seed)
 
-    rank, world = vdist.init_from_env(os.environ.get('VILGOD_DIST_BACKEND'))
+    # device.processes_per_gpu = P > 1 (whole sequences per rank only): P ranks share one GPU, rank r works on cuda:(LOCAL_RANK // P).  A
+    # sequence's host-only stages (track boxes, label propagation, result dicts: ~2.5 of ~18 ms per frame, under one interpreter lock)
+    # then run while the OTHER process's frame pass keeps the GPU busy.  Such ranks never exchange device memory: the process group is gloo.
+    ppg = max(1, int(cfg.get('device', {}).get('processes_per_gpu', 1)))
+    rank, world = vdist.init_from_env(os.environ.get('VILGOD_DIST_BACKEND') or ('gloo' if ppg > 1 else None))
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) // ppg)
 
     dataset = vconfig.instantiate(cfg.dataset_class, logger=logger, training=True,
                                   start_sequence=cfg.start_sequence, end_sequence=cfg.end_sequence)
@@ -108,11 +112,15 @@ def main(argv=None):
     except Exception:           # noqa: BLE001  (a read-only config object)
         pass
     by_sequence = world > 1 and shard == 'sequences'
+    if ppg > 1 and world > 1 and not by_sequence:
+        raise ValueError(f'device.processes_per_gpu={ppg} shares a GPU between ranks that work on DIFFERENT sequences; it needs device.shard=sequences '
+                         f'(resolved: {shard}) and at least as many sequences as ranks')
     logger.info(f'ranks: {world}; sharding: {shard}')
     if by_sequence:
         result_path.mkdir(parents=True, exist_ok=True)      # every rank writes the pickles of its own sequences
     starts = []                                             # (sequence number, offsets into detection_results / indices) of this rank's sequences
     t_loop = time.perf_counter()
+    LAST_RUN['loop_started_at'] = time.time()
     gen_seconds = 0.0
     if os.environ.get('VILGOD_SWITCH_INTERVAL'):
         sys.setswitchinterval(float(os.environ['VILGOD_SWITCH_INTERVAL']))
@@ -228,6 +236,8 @@ def main(argv=None):
     _zsd.wait_state_writes()
     LAST_RUN['state_write_wait_seconds'] = time.perf_counter() - t_wait
     LAST_RUN['loop_seconds'] = time.perf_counter() - t_loop - gen_seconds      # (without the synthetic generator, which stands for disk IO)
+    LAST_RUN['loop_ended_at'] = time.time()
+    LAST_RUN['generator_seconds'] = gen_seconds
     if result_data is not None:
         detection_results = result_data
     elif by_sequence:
