@@ -119,6 +119,16 @@ int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h
 int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, float* d_resid,
             int M, int N, int K, void* stream);
 
+/* vg_gemm(dtype 1, epi 2) the way the tower launches its residual GEMMs (out_proj / c_proj, model.py:190-191): with scratch for a
+ * split-K tail.  A 256 x 256 tile owns a CU, so a launch runs in rounds of n_cu tiles; the row tiles that do not fill complete rounds
+ * (when they are at most half a round) are computed by several workgroups per tile, each over a slice of K, their fp32 partial tiles
+ * summed in fixed order before the residual epilogue -- deterministic, within fp32 rounding of the unsplit result.  d_scratch: device
+ * memory, 256 KB per (tail tile, part).  OPT-IN through the environment, read per launch: VG_GEMM_SPLITK=n allows up to n parts per tile
+ * (8 is the measured optimum); unset, 0, K < 1536 or too little scratch = the unsplit launch.  One encode at a time gains 2.8 % at
+ * 333-338 crops; with two encodes in flight (the throughput pipeline) the other encode already fills the last round: off by default. */
+int vg_gemm_resid_splitk(const void* d_X, const void* d_Wt, const float* d_bias, float* d_resid, int M, int N, int K,
+                         void* d_scratch, int64_t scratch_bytes, void* stream);
+
 /* The fp16 attention kernel of the tower alone (model.py:175-187 via nn.MultiheadAttention): d_qkv fp16 [n_crops*T, ld] with
  * q | k | v at column offsets 0 | W | 2W (what in_proj writes), d_out fp16 [n_crops*T, W] = softmax(q k^T / 8) v per (crop, head).
  * Exposed so that the kernel can be unit-tested against a plain fp32 attention. */

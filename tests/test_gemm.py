@@ -133,3 +133,48 @@ def test_gemm_f32_on_the_matrix_cores_equals_the_vector_kernel(cuda, epi, shape,
     want = _ref(X.cpu(), W.cpu(), bias.cpu(), resid, epi)
     assert (outs[0].cpu() - want).abs().max().item() < 2e-4 * max(1.0, want.abs().max().item())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K', [768, 3072])
+@pytest.mark.parametrize('rows', [257, 260, 300])
+def test_gemm_resid_splitk_tail(cuda, K, rows, monkeypatch):
+    """The residual GEMMs' split-K tail (vg_gemm_resid_splitk, opt-in through VG_GEMM_SPLITK=8; round 4): with N = 768 a launch of `rows` row tiles is rows x 3 tiles on
+    n_cu CUs; the row tiles beyond the last complete round run K-split through scratch.  Against the unsplit launch (VG_GEMM_SPLITK=0):
+    the rows of the complete rounds are the SAME numbers, the tail rows agree to fp32 rounding of the partial sums; both against a
+    float32 matmul of the same fp16 operands.  300 row tiles leave a last round that is more than half full: not split at all."""
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    n_cu = torch.cuda.get_device_properties(cuda).multi_processor_count
+    M, N = rows * 256, 768
+    g = torch.Generator().manual_seed(rows + K)
+    X = (torch.randn(M, K, generator=g) * 0.5).half().to(cuda)
+    W = torch.randn(N, K, generator=g) * 0.05
+    W[:, 0] += torch.arange(N) * 1e-3
+    W = W.half().to(cuda)
+    bias = (torch.randn(N, generator=g) * 0.1).to(cuda)
+    resid = torch.randn(M, N, generator=g).to(cuda)
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
+    outs = {}
+    for mode in ('1', '0', 'small'):
+        monkeypatch.setenv('VG_GEMM_SPLITK', '0' if mode == '0' else '8')
+        R = resid.clone()
+        nbytes = 4096 if mode == 'small' else scratch.numel()
+        check(lib.vg_gemm_resid_splitk(ptr(X), ptr(W), ptr(bias), ptr(R), M, N, K, ptr(scratch), nbytes, stream_ptr()))
+        torch.cuda.synchronize()
+        outs[mode] = R
+    want = resid + X.float() @ W.float().t() + bias
+    scale = max(1.0, want.abs().max().item())
+    for mode in outs:
+        assert (outs[mode] - want).abs().max().item() < 3e-3 * scale
+    assert torch.equal(outs['0'], outs['small'])                    # no room for the partial tiles: the unsplit launch
+    total, full = rows * 3, rows * 3 // n_cu
+    r_main = full * n_cu // 3
+    tail = (rows - r_main) * 3
+    split = full >= 1 and 0 < tail <= n_cu // 2 and K >= 1536          # (short K loops are never split: the two extra launches cost as much)
+    if not split:
+        assert torch.equal(outs['1'], outs['0'])
+        return
+    assert torch.equal(outs['1'][:r_main * 256], outs['0'][:r_main * 256])
+    d = (outs['1'][r_main * 256:] - outs['0'][r_main * 256:]).abs().max().item()
+    print(f'{rows} row tiles, K {K}: {tail} tail tiles split; max |split - unsplit| = {d:.2e} (values up to {scale:.1f})')
+    assert 0 < d < 2e-5 * scale

@@ -336,7 +336,33 @@ def test_hip_last_block_on_class_token_rows_only(cuda, n, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_hip_folded_layernorm_follows_a_replaced_weight(cuda):
+@pytest.mark.parametrize('n', [334, 340])
+def test_hip_tower_with_split_k_tails(cuda, n, monkeypatch):
+    """334 / 340 crops are 258 / 262 row tiles: the residual GEMMs' fourth round of tiles would hold 6 / 18 tiles on 256 CUs; the tower
+    runs c_proj's share of those row tiles K-split when VG_GEMM_SPLITK=8 (opt-in: launch_gemm / splitk_plan).  The features stay within the fp16 tower's bound against the fp32 tower and
+    within fp16 rounding of the unsplit run (VG_GEMM_SPLITK=0); crops whose rows lie in complete rounds only change through nothing at all
+    in the first block and through attention-free row-wise work afterwards: rows never mix, so THEIR features are the same numbers."""
+    from vilgod_amd.clip_wrapper import VitEncoder
+    wd = cw.synthetic_vit_weights(3, **cw.VIT_B16)
+    x = torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(n)).to(cuda)
+    f32 = VitEncoder(wd, dtype='f32', device=cuda).encode(x).cpu()
+    monkeypatch.setenv('VG_GEMM_SPLITK', '8')
+    f_split = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    monkeypatch.setenv('VG_GEMM_SPLITK', '0')
+    f_plain = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    e_split = ((f_split - f32).norm() / f32.norm()).item()
+    e_plain = ((f_plain - f32).norm() / f32.norm()).item()
+    n_cu = torch.cuda.get_device_properties(cuda).multi_processor_count
+    rows = (n * 197 + 255) // 256
+    r_main = (rows * 3 // n_cu) * n_cu // 3
+    first_tail_crop = r_main * 256 // 197              # crops below it have every token row in the complete rounds
+    changed = (f_split != f_plain).any(dim=1)
+    print(f'{n} crops: split {e_split:.2e}, unsplit {e_plain:.2e} (relative L2 vs fp32); {int(changed.sum())} crops differ, first {int(changed.nonzero()[0]) if changed.any() else -1}, '
+          f'first crop with a tail row {first_tail_crop}; max |split - unsplit| {float((f_split - f_plain).abs().max()):.2e}')
+    assert e_split < 1e-3 and e_split <= 1.2 * e_plain + 1e-5
+    assert changed.any() and not changed[:first_tail_crop].any()
+    assert ((f_split - f_plain).norm() / f_plain.norm()).item() < 5e-4
+
     """The gamma-scaled weights / c1 / c2 of the folded LayerNorms are derived once per handle; vg_vit_set_weight on any tensor of a
     block invalidates them, the next encode rebuilds them: a handle whose ln_2 gain and c_fc bias were replaced after its first
     encode returns bit for bit what a fresh handle with the final weights returns."""

@@ -56,6 +56,20 @@ def main(argv=None):
     # sequence's host-only stages (track boxes, label propagation, result dicts: ~2.5 of ~18 ms per frame, under one interpreter lock)
     # then run while the OTHER process's frame pass keeps the GPU busy.  Such ranks never exchange device memory: the process group is gloo.
     ppg = max(1, int(cfg.get('device', {}).get('processes_per_gpu', 1)))
+    if ppg > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # started without a launcher: this process (which has not touched the GPU) starts the P x n_gpus ranks as children and waits
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        n_ranks = ppg * max(1, torch.cuda.device_count())
+        logger.info(f'device.processes_per_gpu={ppg}: starting {n_ranks} ranks through torch.distributed.run')
+        rc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_ranks}', '--master-addr', '127.0.0.1',
+                             '--master-port', str(port), os.path.abspath(__file__)] + list(argv)).returncode
+        if rc != 0:
+            raise SystemExit(rc)
+        return None
     rank, world = vdist.init_from_env(os.environ.get('VILGOD_DIST_BACKEND') or ('gloo' if ppg > 1 else None))
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) // ppg)

@@ -1516,13 +1516,18 @@ __device__ __forceinline__ float row256_sum(float v) {          // sum over the 
 // M = 66560: out_proj 188 vs 177 us and c_proj 382 vs 366 us with the residual stream out of the memory-side cache (as in the
 // pipeline), 157 vs 156 / 362 vs 360 with it cached; whole pipeline 65.1 vs 65.0 frames/s.  The residual epilogue is bound by the bytes
 // all CUs move at the same time (510 MB per launch), not by the latency of its load -> add -> store rounds.
-template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
+//
+// SPLITK (round 4; EPI_NONE_F32 only): the workgroup computes K-tiles [part np / P, (part + 1) np / P) of tile blockIdx.x / P (row-major
+// over the M / 256 x N / 256 tiles of THIS launch) and stores the raw fp32 accumulators as a dense 256 x 256 image at
+// Cout + blockIdx.x * 65536 -- the partial sums of a split-K tail (launch_gemm_resid_tail below; k_splitk_resid adds them up).
+template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0, bool SPLITK = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict__ X, const f16* __restrict__ Wt,
                                                           const float* __restrict__ bias, void* __restrict__ Cout,
                                                           float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
                                                           long long* __restrict__ trace = nullptr,
                                                           const float* __restrict__ ln_c1 = nullptr, LnPartial* __restrict__ ln_stats = nullptr,
-                                                          f16* __restrict__ ln_x16 = nullptr) {
+                                                          f16* __restrict__ ln_x16 = nullptr, int sk_parts = 1) {
+    static_assert(!SPLITK || (EPI == EPI_NONE_F32 && !PERSIST && LN == 0), "split-K partials are raw fp32 tiles");
     constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;
     constexpr int XBUF = 32768, WBASE = 2 * XBUF, WBUF = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1543,7 +1548,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     const int t = PERSIST ? xbase + ti : xcd_remap(blockIdx.x, gridDim.x);
     const int per_chunk = ntm * cw;
     const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    int kt0 = 0, np = K / 64;                      // host guarantees K % 64 == 0 and np >= 2 (per part when SPLITK)
+    if (SPLITK) {
+        const int st_ = (int)blockIdx.x / sk_parts, part = (int)blockIdx.x - st_ * sk_parts, ntn_ = N / BN;
+        tm = st_ / ntn_; tn = st_ - tm * ntn_;
+        kt0 = part * np / sk_parts;
+        np = (part + 1) * np / sk_parts - kt0;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // DMA pieces: 8 rows x 128 B; lane -> row l >> 3, chunk slot l & 7 (source chunk = slot ^ ((row >> 1) & 7))
@@ -1554,7 +1566,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = xr + 8 * i;
-            const f16* sp = X + (size_t)(m0 + r) * K + (size_t)kt * 64 + (pslot ^ ((r >> 1) & 7)) * 8;
+            const f16* sp = X + (size_t)(m0 + r) * K + (size_t)(kt0 + kt) * 64 + (pslot ^ ((r >> 1) & 7)) * 8;
             __builtin_amdgcn_global_load_lds((glb_void*)sp, (lds_void*)(d + i * 1024), 16, 0, 0);
         }
     };
@@ -1566,7 +1578,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = h * 128 + wn * 32 + prow + 8 * i;
-            const f16* sp = Wt + (size_t)(n0 + r) * K + (size_t)kt * 64 + (pslot ^ ((r >> 1) & 7)) * 8;
+            const f16* sp = Wt + (size_t)(n0 + r) * K + (size_t)(kt0 + kt) * 64 + (pslot ^ ((r >> 1) & 7)) * 8;
             __builtin_amdgcn_global_load_lds((glb_void*)sp, (lds_void*)(d + i * 1024), 16, 0, 0);
         }
     };
@@ -1579,7 +1591,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
     const int swz = (r15 >> 1) & 7;
     const int xo0 = (grp * 128 + r15) * 128 + ((q4 ^ swz) << 4), xo1 = (grp * 128 + r15) * 128 + (((4 + q4) ^ swz) << 4);
     const int wo0 = (wn * 64 + r15) * 128 + ((q4 ^ swz) << 4), wo1 = (wn * 64 + r15) * 128 + (((4 + q4) ^ swz) << 4);
-    const int np = K / 64;                         // host guarantees K % 64 == 0 and np >= 2
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;     // LDS byte address of the rings (inline-asm reads)
     // folded LayerNorm, consumer side: thread t < 256 merges the K / 256 partials of tile row t into (mean, rstd) here, where the
     // loads' latency hides behind the prologue's DMA (in the epilogue it cost ~7 us per tile), and carries two registers
@@ -1793,7 +1804,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
                 for (int q = 0; q < 8; ++q) {
                     const int m = (p8 * 8 + q) * 8 + rr;
                     float4 v = *(const float4*)(smem + m * 1024 + j * 16);
-                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+                    const size_t off = SPLITK ? (size_t)blockIdx.x * 65536 + (size_t)(half * 128 + m) * 256 + ((j ^ (m & 31)) << 2)
+                                              : (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
                     if (EPI == EPI_BIAS_RESID) {
                         v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
                         *(float4*)(resid + off) = v;
@@ -2151,6 +2163,85 @@ static int launch_gemm_x2(const void* X, const void* Wt, const float* bias, void
     return VG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K tail of the residual GEMMs (out_proj, c_proj: N = width = three 256-wide column tiles for ViT-B).  One workgroup owns a CU, so a
+// launch runs in ROUNDS of n_cu tiles: 333 crops are 257 row tiles x 3 = 771 tiles = three full rounds and a fourth with 3 tiles on 256
+// CUs -- the launch takes 4 / 3 of the time for 0.4 % more work (tools/exp_tile_tail.py: +7.6 % tower time from 332 to 333 crops, one
+// encode at a time).  The row tiles that do not fill complete rounds are therefore computed K-split: P workgroups per tile, each a
+// slice of the K-tiles (k_gemm_f16_pp64<EPI_NONE_F32, ..., SPLITK>: raw fp32 partial tiles into scratch), and k_splitk_resid adds the P
+// partials IN FIXED ORDER and applies the residual epilogue -- bias, fp32 residual read-modify-write, and for LN = 2 the fp16 copy and
+// the row's partial statistics, the same expressions as the GEMM's own epilogue.  Deterministic; a row in the tail differs from the
+// unsplit result by the rounding of ((p0 + p1) + ...) against one fp32 accumulation chain (<= a few 1e-7 relative, tests/test_gemm.py).
+template <int LN>
+__global__ __launch_bounds__(256) void k_splitk_resid(const float* __restrict__ part, int P, const float* __restrict__ bias,
+                                                      float* __restrict__ resid, int N, int ldc, int row0, int ntn,
+                                                      LnPartial* __restrict__ ln_stats, f16* __restrict__ ln_x16) {
+    // grid: tail tiles x 16; a wave = one row of the tile's 256 columns at a time (lane j: columns 4 j .. 4 j + 3), four rows per wave
+    const int tile = blockIdx.x >> 4, rb = blockIdx.x & 15, w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int tm = tile / ntn, tn = tile - tm * ntn;
+    const float4 b4 = *(const float4*)(bias + tn * 256 + 4 * j);
+    const float* pb = part + (size_t)tile * P * 65536 + 4 * j;
+    float4 x4[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rb * 16 + w * 4 + i;
+        x4[i] = *(const float4*)(resid + (size_t)(row0 + tm * 256 + r) * ldc + tn * 256 + 4 * j);
+        v[i] = *(const float4*)(pb + (size_t)r * 256);
+    }
+    for (int p = 1; p < P; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rb * 16 + w * 4 + i;
+            const float4 a = *(const float4*)(pb + (size_t)p * 65536 + (size_t)r * 256);
+            v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = rb * 16 + w * 4 + i;
+        const size_t off = (size_t)(row0 + tm * 256 + r) * ldc + tn * 256 + 4 * j;
+        float4 o = make_float4(v[i].x + b4.x, v[i].y + b4.y, v[i].z + b4.z, v[i].w + b4.w);
+        o.x += x4[i].x; o.y += x4[i].y; o.z += x4[i].z; o.w += x4[i].w;
+        *(float4*)(resid + off) = o;
+        if (LN == 2) {
+            const f16x4 h4 = {(f16)o.x, (f16)o.y, (f16)o.z, (f16)o.w};
+            *(f16x4*)(ln_x16 + off) = h4;
+            const float mean = row256_sum((o.x + o.y) + (o.z + o.w)) * (1.0f / 256.0f);
+            const float a = o.x - mean, b = o.y - mean, c = o.z - mean, d = o.w - mean;
+            const float m2 = row256_sum((a * a + b * b) + (c * c + d * d));
+            if (j == 0) ln_stats[(size_t)(row0 + tm * 256 + r) * (N >> 8) + tn] = LnPartial{mean, m2};
+        }
+    }
+}
+
+// how a residual GEMM of ntm x ntn tiles is divided: row tiles [0, r_main) in complete rounds, the rest K-split `parts` ways (0 = no split)
+struct SplitPlan { int r_main, parts; };
+static SplitPlan splitk_plan(int ntm, int ntn, int np, size_t scratch_bytes) {
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 8) n_cu = 256; }
+    // OPT-IN (VG_GEMM_SPLITK=n, read per launch: at most n parts per tile, 8 is the measured optimum; unset / 0 = never split).
+    // Measured (tools/bench_gemm_splitk.py, N = 768, one launch at a time): K = 3072 (c_proj) 356 -> 305 us for 3-15 tail tiles, -12 % at 48,
+    // -8 % at 72, -2 % at 126; K = 768 (out_proj: the fourth round costs 16 us, two more launches cost as much) -3 % at 6 tiles, +2 % at 30,
+    // +9 % at 48: only long K loops are split.  Whole tower (tools/exp_tile_tail.py): one encode at a time 14.12 -> 13.73 ms at 333 crops,
+    // 14.35 -> 13.94 at 338; TWO encodes in flight (what the pipeline runs) 12.94 -> 13.01 / 13.27 -> 13.29: the other encode's tiles
+    // already fill the last round, and the partial tiles are 60 MB of extra traffic per launch; pipeline 65.5 vs 65.7 frames/s.  So the
+    // split is for one-frame-at-a-time (latency) use and stays off in the throughput configuration.
+    const char* e = getenv("VG_GEMM_SPLITK");
+    const int max_parts = e ? atoi(e) : 0;                 // more parts = more partial-sum traffic than K-loop saved (256 KB per part and tile)
+    if (max_parts < 2) return {ntm, 0};
+    if (np < 24) return {ntm, 0};
+    const int total = ntm * ntn, full = total / n_cu;
+    if (full < 1) return {ntm, 0};
+    const int r_main = full * n_cu / ntn, tail = (ntm - r_main) * ntn;
+    if (tail <= 0 || 2 * tail > n_cu) return {ntm, 0};     // a last round that is more than half full is left alone
+    int parts = n_cu / tail;
+    if (parts > np / 2) parts = np / 2;                    // the kernel's ring needs two K-tiles per workgroup
+    if (parts > max_parts) parts = max_parts;
+    while (parts >= 2 && (size_t)tail * parts * 262144 > scratch_bytes) --parts;
+    if (parts < 2) return {ntm, 0};
+    return {r_main, parts};
+}
+
 template <int EPI, bool TRACE = false, bool PERSIST = false, int LN = 0>
 static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                             hipStream_t st, long long* trace = nullptr, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
@@ -2172,7 +2263,26 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
         grid = (grid + 7) / 8 * 8;                 // slot s of XCD x = block 8 s + x
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, cwt, trace, ln_c1, ln_stats, ln_x16);
+                       ldc, cwt, trace, ln_c1, ln_stats, ln_x16, 1);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+// rows [row0, row0 + Mt) of a residual GEMM, K-split `parts` ways through `scratch` (see k_splitk_resid)
+template <int LN>
+static int launch_gemm_resid_tail(const void* X, const void* Wt, const float* bias, float* resid, int row0, int Mt, int N, int K, int ldc,
+                                  int parts, float* scratch, hipStream_t st, LnPartial* ln_stats, f16* ln_x16) {
+    if (Mt % 256 || N % 256 || K % 64 || parts < 2 || K / 64 / parts < 2 || !scratch) return VG_ERR_ARG;
+    auto kern = k_gemm_f16_pp64<EPI_NONE_F32, false, false, 0, true>;
+    const int lds = 5 * 32768;
+    VG_MAX_DYNAMIC_LDS(kern, lds);
+    const int ntn = N / 256, tiles = (Mt / 256) * ntn;
+    hipLaunchKernelGGL(kern, dim3(tiles * parts), dim3(512), lds, st, (const f16*)X + (size_t)row0 * K, (const f16*)Wt, (const float*)nullptr,
+                       (void*)scratch, (float*)nullptr, Mt, N, K, 256, ntn, (long long*)nullptr, (const float*)nullptr, (LnPartial*)nullptr,
+                       (f16*)nullptr, parts);
+    VG_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_splitk_resid<LN>), dim3(tiles * 16), dim3(256), 0, st, (const float*)scratch, parts, bias, resid, N, ldc, row0, ntn,
+                       ln_stats, ln_x16);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
@@ -2214,7 +2324,7 @@ static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void
 template <int EPI, int LN = 0>
 static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const float* bias, void* C, float* resid, int M,
                        int N, int K, hipStream_t st, int ldc = 0, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr,
-                       f16* ln_x16 = nullptr) {
+                       f16* ln_x16 = nullptr, float* sk_scratch = nullptr, size_t sk_bytes = 0) {
     if (ldc == 0) ldc = N;
     vg_vit* v = const_cast<vg_vit*>(cv);
     // f16 ViT shapes (N % 256 == 0, K >= 128) take the ping-pong kernel; k_gemm_f16 serves the remaining legal shapes.
@@ -2252,6 +2362,18 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                 if (v->gemm_x2 && K % 256 == 0 && (LN != 1 || K / 64 <= X2_LN_MAXP))
                     return launch_gemm_x2<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
                 if (v->gemm_x2 && LN != 0) return VG_ERR_ARG;       // (the two kernels keep different partial statistics)
+                if constexpr (EPI == EPI_BIAS_RESID && LN != 1) {
+                    // residual GEMMs with scratch at hand: the row tiles beyond the last complete round of tiles run K-split
+                    if (sk_scratch && M % 256 == 0) {
+                        const SplitPlan sp = splitk_plan(M / 256, N / 256, K / 64, sk_bytes);
+                        if (sp.parts) {
+                            const int rc = launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, sp.r_main * 256, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
+                            if (rc) return rc;
+                            return launch_gemm_resid_tail<LN>(X, Wt, bias, resid, sp.r_main * 256, M - sp.r_main * 256, N, K, ldc, sp.parts, sk_scratch, st,
+                                                              ln_stats, ln_x16);
+                        }
+                    }
+                }
                 return launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
             }
         }
@@ -2572,6 +2694,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     void* mlp = ws;                   ws += Mp * 4 * W * es;
     void* patches = ws;               ws += Pp * Kp * es;
     float* pe = (float*)ws;           ws += Pp * W * 4;
+    const size_t pe_bytes = (size_t)(Pp * W * 4);      // dead once the embedding kernel has run: scratch of the residual GEMMs' split-K tails
     const bool fold = v->ln_fold;
     f16* x16 = (f16*)ws;              if (fold) ws += Mp * W * 2;
     LnPartial* lnst = (LnPartial*)ws;
@@ -2715,8 +2838,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             return VG_OK;
         }
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
-           : fold ? launch_gemm<EPI_BIAS_RESID, 2>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, lnst, x16)
-                  : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st);
+           : fold ? launch_gemm<EPI_BIAS_RESID, 2>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, lnst, x16, pe, pe_bytes)
+                  : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, nullptr, nullptr, pe, pe_bytes);
         if (rc) return rc;
         if (fold) {
             // ln_2 rides in c_fc
@@ -2732,8 +2855,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         if (rc) return rc;
         // the last block's c_proj has no LayerNorm consumer in a GEMM (ln_post reads the class token's fp32 row in k_head)
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
-           : (fold && l + 1 < L) ? launch_gemm<EPI_BIAS_RESID, 2>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st, 0, nullptr, lnst, x16)
-                  : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st);
+           : (fold && l + 1 < L) ? launch_gemm<EPI_BIAS_RESID, 2>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st, 0, nullptr, lnst, x16, pe, pe_bytes)
+                  : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st, 0, nullptr, nullptr, nullptr, pe, pe_bytes);
         if (rc) return rc;
     }
     if (rh)
@@ -2838,6 +2961,18 @@ int vg_gemm(int dtype, int epi, const void* d_X, const void* d_Wt, const float* 
         case 4: return dtype == 1 ? launch_gemm<EPI_BIAS_RESID_H>(&v, d_X, d_Wt, d_bias, d_C, d_resid, M, N, K, st) : VG_ERR_ARG;
     }
     return VG_ERR_ARG;
+}
+
+/* vg_gemm epi 2 (dtype 1) with scratch for the split-K tail (launch_gemm / splitk_plan): what the tower's residual GEMMs run.  Row tiles
+ * beyond the last complete round of n_cu tiles are computed K-split through d_scratch (>= 2 MB per tail tile; without enough the
+ * launch is not split).  Opt-in: VG_GEMM_SPLITK=n (at most n parts per tile; 8) in the environment, read per launch. */
+int vg_gemm_resid_splitk(const void* d_X, const void* d_Wt, const float* d_bias, float* d_resid, int M, int N, int K,
+                         void* d_scratch, int64_t scratch_bytes, void* stream) {
+    if (!d_X || !d_Wt || !d_bias || !d_resid || scratch_bytes < 0) return VG_ERR_ARG;
+    vg_vit v;
+    v.dtype = 1;
+    return launch_gemm<EPI_BIAS_RESID>(&v, d_X, d_Wt, d_bias, nullptr, d_resid, M, N, K, (hipStream_t)stream, 0, nullptr, nullptr, nullptr,
+                                       (float*)d_scratch, (size_t)scratch_bytes);
 }
 
 /* on != 0: record a HIP event pair around every projection-GEMM launch of vg_vit_encode (on the launch stream);
