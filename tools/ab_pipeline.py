@@ -4,7 +4,7 @@
 
 Every variant is a PseudoLabelPipeline built while its environment settings are in force (the switches this tool is for are read when
 the handles are created: VG_GEMM_RI, VILGOD_PATCH_1CH, VG_VIT_RESID16, VG_VIT_CLS_LAST, ... -- per-launch switches such as VG_ATT_TR are
-set around the variant's blocks as well).  The same K distinct 150k-point frames (resident) go through every variant, ROUNDS times,
+set around the variant's blocks as well; AB_WORKERS=n = frames in flight of the variant, default 6).  The same K distinct 150k-point frames (resident) go through every variant, ROUNDS times,
 variants interleaved; prints frames/s per block and the median per variant, plus the per-launch time of the projection GEMMs of one
 sequential pass (event pairs, vg_vit_profile)."""
 import os
@@ -62,7 +62,7 @@ def block(name, env, n=K):
         p.new_sequence()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        p.process_frames(frames[:n], [poses[1 + i] for i in range(n)], poses[0], n_workers=6)
+        p.process_frames(frames[:n], [poses[1 + i] for i in range(n)], poses[0], n_workers=int(os.environ.get('AB_WORKERS', '6')))
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
