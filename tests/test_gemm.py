@@ -46,32 +46,6 @@ def test_gemm_epilogues(cuda, dtype, epi, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('epi', [0, 1, 2, 3])
-@pytest.mark.parametrize('shape', [(256, 256, 256), (512, 768, 768), (256, 2304, 768), (256, 768, 3072), (768, 3072, 768), (256, 512, 512)])
-def test_gemm_two_workgroups_per_cu(cuda, epi, shape, monkeypatch):
-    """k_gemm_f16_x2 (VG_GEMM_X2=1: 128 x 256 tiles, W fragments straight from global memory, two workgroups per CU) against the
-    same torch fp32 reference, every epilogue; K = 256 is its shortest loop (the four peeled K-tiles alone)."""
-    from vilgod_amd._lib import lib, ptr, stream_ptr, check
-    monkeypatch.setenv('VG_GEMM_X2', '1')
-    M, N, K = shape
-    g = torch.Generator().manual_seed(M + N + K + epi)
-    X = torch.randn(M, K, generator=g) * 0.5
-    W = torch.randn(N, K, generator=g) * 0.05
-    W[:, 0] += torch.arange(N) * 1e-3
-    bias = torch.randn(N, generator=g) * 0.1
-    resid = torch.randn(M, N, generator=g)
-    Xd, Wd = X.half().to(cuda), W.half().to(cuda)
-    C = torch.zeros(M, N, dtype=torch.float32 if epi == 3 else torch.float16, device=cuda)
-    R = resid.clone().to(cuda)
-    bd = bias.to(cuda)
-    check(lib.vg_gemm(1, epi, ptr(Xd), ptr(Wd), ptr(bd), ptr(C), ptr(R), M, N, K, stream_ptr()))
-    got = (R if epi == 2 else C).float().cpu()
-    want = _ref(Xd.cpu(), Wd.cpu(), bias, resid, epi)
-    err = (got - want).abs().max().item()
-    assert err < 3e-3 * max(1.0, want.abs().max().item()), err
-
-
-@pytest.mark.gpu
 def test_gemm_rejects_bad_shapes(cuda):
     from vilgod_amd._lib import lib, ptr, stream_ptr
     x = torch.zeros(100, 64, dtype=torch.float16, device=cuda)

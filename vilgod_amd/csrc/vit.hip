@@ -1261,7 +1261,9 @@ __global__ __launch_bounds__(64) void k_clip_scores(const float* __restrict__ fe
 #define VG_PROF_MAX 4096
 struct vg_vit {
     int width, layers, heads, patch, res, out_dim, dtype, T;
+#ifdef VG_DEV
     bool gemm_x2 = getenv("VG_GEMM_X2") ? atoi(getenv("VG_GEMM_X2")) != 0 : false;   // projection GEMMs by k_gemm_f16_x2 (two workgroups per CU)
+#endif
     bool cls_last = !(getenv("VG_VIT_CLS_LAST") && atoi(getenv("VG_VIT_CLS_LAST")) == 0);   // last block: class-token rows only (see vg_vit_encode)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
@@ -1853,6 +1855,7 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
+#ifdef VG_DEV      // measured slower than k_gemm_f16_pp64 on every projection shape: development build only (VG_GEMM_X2=1)
 // ---------------------------------------------------------------------------------------------
 // k_gemm_f16_x2: TWO independent 4-wave workgroups per CU, each a 128 x 256 tile (one "group" of k_gemm_f16_pp64).
 // Why: in k_gemm_f16_pp64 the one workgroup that owns a CU reaches its epilogue with all eight waves at once, and the matrix pipe
@@ -2162,6 +2165,7 @@ static int launch_gemm_x2(const void* X, const void* Wt, const float* bias, void
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
+#endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
 // Split-K tail of the residual GEMMs (out_proj, c_proj: N = width = three 256-wide column tiles for ViT-B).  One workgroup owns a CU, so a
@@ -2359,9 +2363,11 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                     if ((persist_mask >> EPI) & 1) return launch_gemm_pp64<EPI, false, true>(X, Wt, bias, C, resid, M, N, K, ldc, st);
                 }
 #endif
+#ifdef VG_DEV
                 if (v->gemm_x2 && K % 256 == 0 && (LN != 1 || K / 64 <= X2_LN_MAXP))
                     return launch_gemm_x2<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
                 if (v->gemm_x2 && LN != 0) return VG_ERR_ARG;       // (the two kernels keep different partial statistics)
+#endif
                 if constexpr (EPI == EPI_BIAS_RESID && LN != 1) {
                     // residual GEMMs with scratch at hand: the row tiles beyond the last complete round of tiles run K-split
                     if (sk_scratch && M % 256 == 0) {
@@ -2581,9 +2587,11 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
     const char* fold = getenv("VG_VIT_LN_FOLD");
     v->ln_fold = dtype == 1 && width % 256 == 0 && !v->resid_h && !getenv("VG_GEMM_V4") && !(fold && atoi(fold) == 0);
+#ifdef VG_DEV
     // k_gemm_f16_x2 serves K % 256 == 0 and merges at most X2_LN_MAXP partial statistics per row: a tower uses it for all of its
     // projection GEMMs or for none (the two kernels keep the folded LayerNorm's partials at different granularity)
     if (v->gemm_x2 && !(dtype == 1 && width % 256 == 0 && width / 64 <= X2_LN_MAXP && !v->resid_h && !getenv("VG_GEMM_V4"))) v->gemm_x2 = false;
+#endif
     *out = v;
     return VG_OK;
 }
