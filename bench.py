@@ -810,18 +810,19 @@ def main():
                                         env=dict(os.environ, SEQUENCES=str(2 * nseq), SEED_STRIDE='0', TIME_CLI_JSON='1', PROCS='2'),
                                         capture_output=True, text=True, timeout=900)
                     l2 = [ln for ln in r2.stdout.splitlines() if ln.startswith('TIME_CLI_JSON ')]
-                    if r2.returncode != 0 or not l2:
-                        raise RuntimeError(f'tools/time_cli.py PROCS=2 failed (rc {r2.returncode}): {r2.stderr[-600:]}')
-                    q2 = json.loads(l2[-1][len('TIME_CLI_JSON '):])
-                    f2 = sum(q['frames'] for q in q2['sequences'])
-                    two = {'value': round(f2 / q2['loop_seconds'], 3), 'unit': 'frames/s', 'frames': f2, 'sequences': len(q2['sequences']), 'processes': 2,
-                           'frames_in_flight_per_process': 4, 'ms_per_frame': round(1000.0 * q2['loop_seconds'] / f2, 2),
-                           'window_seconds': round(q2['window_seconds'], 2), 'generator_seconds_excluded': round(q2['generator_seconds'], 2),
-                           'loop_seconds_per_rank': [round(x, 2) for x in q2['loop_seconds_per_rank']],
-                           'note': ('tools/preprocess_data.py device.processes_per_gpu=2 (started through torch.distributed.run, gloo group): rank r walks '
-                                    'sequences r, r + 2, ...; value = all frames / (first rank\'s loop start to last rank\'s loop end, minus the synthetic '
-                                    'generator every rank runs at the start of its loop); both pickle families equal the one-process run\'s '
-                                    '(tests/test_cli.py::test_cli_sequence_sharding_equals_one_rank)')}
+                    if r2.returncode != 0 or not l2:             # (must not cost the one-process figure)
+                        two = {'error': f'tools/time_cli.py PROCS=2 failed (rc {r2.returncode}): {(r2.stderr or r2.stdout)[-600:]}'}
+                    else:
+                        q2 = json.loads(l2[-1][len('TIME_CLI_JSON '):])
+                        f2 = sum(q['frames'] for q in q2['sequences'])
+                        two = {'value': round(f2 / q2['loop_seconds'], 3), 'unit': 'frames/s', 'frames': f2, 'sequences': len(q2['sequences']), 'processes': 2,
+                                'frames_in_flight_per_process': 4, 'ms_per_frame': round(1000.0 * q2['loop_seconds'] / f2, 2),
+                                'window_seconds': round(q2['window_seconds'], 2), 'generator_seconds_excluded': round(q2['generator_seconds'], 2),
+                                'loop_seconds_per_rank': [round(x, 2) for x in q2['loop_seconds_per_rank']],
+                                'note': ('tools/preprocess_data.py device.processes_per_gpu=2 (started through torch.distributed.run, gloo group): rank r walks '
+                                         'sequences r, r + 2, ...; value = all frames / (first rank\'s loop start to last rank\'s loop end, minus the synthetic '
+                                         'generator every rank runs at the start of its loop); both pickle families equal the one-process run\'s '
+                                         '(tests/test_cli.py::test_cli_sequence_sharding_equals_one_rank)')}
                 return {'two_processes_per_gpu': two, 'value': round(frames / run['loop_seconds'], 3), 'unit': 'frames/s', 'frames': frames, 'sequences': len(seqs),
                         'ms_per_frame': round(1000.0 * run['loop_seconds'] / frames, 2),
                         'state_write_wait_seconds': round(run.get('state_write_wait_seconds', 0.0), 3),
