@@ -98,8 +98,9 @@ def test_ball_count_and_nearest_gpu(cuda):
     m = HDBSCAN(min_cluster_size=15, cluster_selection_epsilon=0.15, max_points=50000)
     d = [torch.from_numpy(x).to(cuda) for x in X]
     m.grid(d[1])
+    # (r2 = 0.5 and 1.5: 5^3 and 9^3 cells per query)
     for r2, cap in ((np.float32(0.3) * np.float32(0.3), 1000), (np.float32(0.2) * np.float32(0.2), 100), (np.float32(0.1), 4),
-                    (np.float32(0.3) * np.float32(0.3), 5)):
+                    (np.float32(0.3) * np.float32(0.3), 5), (np.float32(0.5), 1000), (np.float32(1.5), 50)):
         for qi in (0, 1):
             got = m.ball_count(d[qi], r2, cap).cpu().numpy()
             assert np.array_equal(got, no.ball_count(X[qi], X[1], r2, cap)), (r2, cap, qi)
