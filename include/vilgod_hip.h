@@ -305,6 +305,17 @@ int vg_cluster_boxes(const float* d_points, int stride, const int32_t* d_index, 
 int vg_cluster_medians(const float* d_points, int stride, int n_cols, const int32_t* d_index, const int32_t* d_seg_off, int n_clusters,
                        float* d_median, void* stream);
 
+/* ---- execution resources (no reference counterpart: the reference has one implicit CUDA stream) -------------
+ * A HIP stream whose kernels may only be dispatched to the compute units set in h_cu_mask (hipExtStreamCreateWithCUMask):
+ * n_words 32-bit words, bit i of the mask = CU slot i.  On gfx950 in SPX mode the driver deals the mask bits round-robin over the
+ * 8 XCDs and, inside an XCD, over its shader engines (bit i -> XCD i % 8), so the low 8 r bits are r CUs of every XCD.
+ * Used to keep the small latency-bound kernels of a frame's front stage (ground, clustering, render) off the CUs the projection
+ * GEMMs of other frames' ViT passes need whole; numerics cannot depend on it.
+ * vg_device_cu_count: compute units of the current device. */
+int vg_stream_create_cu_mask(void** out_stream, const uint32_t* h_cu_mask, int n_words);
+int vg_stream_destroy(void* stream);
+int vg_device_cu_count(int32_t* h_count);
+
 #ifdef __cplusplus
 }
 #endif

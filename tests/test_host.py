@@ -261,3 +261,21 @@ def test_state_writer_process_writes_the_reference_layout(tmp_path):
             assert not (tmp_path / (name + '.tmp')).exists()
     finally:
         zsd.shutdown_state_writer()
+
+
+def test_cu_mask_words_partition_the_device():
+    """vilgod_amd/streams.py: the front mask is the low 8 r bits (r CUs of every XCD under amdkfd's round-robin deal), the tower mask
+    everything else of the device's CUs; together they cover every CU exactly once."""
+    from vilgod_amd.streams import cu_mask_words
+    for n_cu, r in ((256, 1), (256, 2), (256, 5), (304, 3), (64, 7)):
+        f, t = cu_mask_words(n_cu, r, 'front'), cu_mask_words(n_cu, r, 'tower')
+        assert f.dtype == np.uint32 and len(f) == len(t) == (n_cu + 31) // 32
+        bits_f = np.unpackbits(f.view(np.uint8), bitorder='little')[:n_cu]
+        bits_t = np.unpackbits(t.view(np.uint8), bitorder='little')[:n_cu]
+        assert bits_f.sum() == 8 * r and bits_f[:8 * r].all()
+        assert np.array_equal(bits_f + bits_t, np.ones(n_cu, np.uint8))
+        assert not np.unpackbits(t.view(np.uint8), bitorder='little')[n_cu:].any()
+    with pytest.raises(ValueError):
+        cu_mask_words(256, 32, 'front')
+    with pytest.raises(ValueError):
+        cu_mask_words(256, 0, 'tower')

@@ -142,6 +142,35 @@ def test_dense_frames_six_views_in_flight_equal_sequential(cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('tower', ['complement', 'all'])
+def test_cu_masked_streams_change_no_output(cuda, tower):
+    """device.cu_reserve (vilgod_amd/streams.py): the frames' front stages on streams restricted to 2 CUs of every XCD, the ViT passes on a
+    second stream per worker (the other CUs / all CUs).  Where a workgroup runs cannot change a number: states, scores and boxes are
+    bit-identical to the unrestricted run, and the masks reach the runtime (the stream objects carry them)."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    from vilgod_amd.streams import MaskedStream
+    poses = synthetic.make_poses(6)
+    frames = [synthetic.make_frame(70 + f, 60_000, n_objects=30) for f in range(4)]
+    ref = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=61_000, clip_model_path='/nonexistent')
+    msk = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=61_000, clip_model_path='/nonexistent', clip=ref.clip,
+                              cu_reserve=2, cu_tower=tower)
+    ref.new_sequence(); msk.new_sequence()
+    a = ref.process_frames([ref.upload(f) for f in frames], poses[1:5], poses[0], n_workers=3)
+    b = msk.process_frames([msk.upload(f) for f in frames], poses[1:5], poses[0], n_workers=3)
+    w = msk._workers[0]
+    assert isinstance(w.stream, MaskedStream) and int(w.stream.cu_mask_words[0]) == 0xFFFF
+    assert isinstance(w.vit_stream, MaskedStream) == (tower == 'complement')
+    n_valid = 0
+    for (fa, ra, pa), (fb, rb, pb) in zip(a, b):
+        assert np.array_equal(np.sort(fa.ground_point_indices), np.sort(fb.ground_point_indices))
+        assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off) and np.array_equal(fa.valid, fb.valid)
+        assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+        assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
+        n_valid += int(fa.valid.sum())
+    assert n_valid > 20
+
+
+@pytest.mark.gpu
 def test_round_robin_frames_with_replicated_ground_equal_one_rank(cuda):
     """SURVEY 8e, bench.py --ground-handoff replicate: two "ranks" (two pipeline objects here) take the frames of one sequence
     round-robin; each runs the stateful ground pass over ALL frames itself (process_frames(own=...)) and its own frames in full.

@@ -1,7 +1,8 @@
 """What does one clustering pass cost a projection GEMM that runs beside it?  Stream A: back-to-back c_fc-shaped launches (M = 66 560,
 N = 3072, K = 768, QuickGELU epilogue); stream B (another thread): the MST of one 150k-point frame's non-ground points, again and
 again.  Prints the time of 300 GEMM launches alone and with B running, the MSTs B finished meanwhile, and the GEMM time lost per MST --
-for the walk in 256- and 512-thread workgroups (VG_CLUSTER_SEARCH_NT, read per launch)."""
+with both streams unrestricted, and with B restricted to r CUs of every XCD (vilgod_amd/streams.py) while A runs on the other CUs
+('complement') or on all of them ('all'):    python tools/exp_interference.py [r ...]      (default sweep 1 2 3 4)"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,8 +19,15 @@ A = (torch.randn(M, K, device=dev) * 0.5).half()
 W = (torch.randn(N, K, device=dev) * 0.05).half()
 b = torch.randn(N, device=dev)
 C = torch.empty(M, N, dtype=torch.float16, device=dev)
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 NG = 300
+from vilgod_amd.streams import make_streams
+reserves = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+configs = [('unrestricted', torch.cuda.Stream(), torch.cuda.Stream())]
+for r in reserves:
+    for tower in ('complement', 'all'):
+        front, tow = make_streams(dev, r, tower)
+        configs.append((f'reserve {r}/XCD, GEMMs on {tower}', tow(), front()))
+sa = sb = None
 
 
 def gemms():
@@ -53,10 +61,15 @@ def timed(with_b):
     return dt, n1 - n0
 
 
-gemms()
-for nt in ('512', '256', '512', '256'):
-    os.environ['VG_CLUSTER_SEARCH_NT'] = nt
+for rep in range(2):
+  for name, sa, sb in configs:
+    gemms()
     t_alone, _ = timed(False)
     t_with, n = timed(True)
-    print(f'NT {nt}: {NG} GEMMs alone {1e3 * t_alone:.1f} ms ({1e6 * t_alone / NG:.1f} us each), beside the MST loop {1e3 * t_with:.1f} ms; '
+    with torch.cuda.stream(sb):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            pipe.cluster_model.mst(X)
+        torch.cuda.synchronize(); t_mst = (time.perf_counter() - t0) / 5
+    print(f'{name}: MST alone {1e3 * t_mst:.2f} ms; {NG} GEMMs alone {1e3 * t_alone:.1f} ms ({1e6 * t_alone / NG:.1f} us each), beside the MST loop {1e3 * t_with:.1f} ms; '
           f'{n} MSTs finished meanwhile ({1e3 * t_with / max(n, 1):.2f} ms each): {1e3 * (t_with - t_alone) / max(n, 1):.3f} ms of GEMM time lost per MST', flush=True)

@@ -63,6 +63,94 @@ if os.path.exists(sq_path):
                 'wave_cycles_split': {'waiting (s_waitcnt / barrier)': agg['SQ_WAIT_ANY'] / agg['SQ_WAVE_CYCLES'],
                                       'issue stalled': agg['SQ_WAIT_INST_ANY'] / agg['SQ_WAVE_CYCLES'],
                                       'issuing': agg['SQ_ACTIVE_INST_ANY'] / agg['SQ_WAVE_CYCLES']}}
+# ---- the projection GEMM per KIND (VERDICT r4 task 2): in_proj / out_proj / c_fc / c_proj of the full-size blocks, split by template
+# instantiation and -- out_proj and c_proj share one (EPI_BIAS_RESID, LN = 2) -- by their alternation in dispatch order of the sequential
+# run (per block: in_proj, attention, out_proj, c_fc, c_proj).  Time from the kernel-trace pass, bytes and SQ counters from the PMC passes.
+def dispatch_rows(path, counters=None):
+    """-> {dispatch_id: {'name', 'grid', 'dur_ns', counter: value ...}} of one pass."""
+    rows = {}
+    if not os.path.exists(path):
+        return rows
+    for r in csv.DictReader(open(path)):
+        name = r.get('Kernel_Name', '')
+        if 'k_gemm_f16_pp64' not in name:
+            continue
+        d = rows.setdefault(int(r['Dispatch_Id']), {'name': name, 'grid': int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)})
+        if 'Counter_Name' in r:
+            d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+        if r.get('Start_Timestamp') and r.get('End_Timestamp'):
+            d['dur_ns'] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    return rows
+def template_args(name):
+    import re
+    m = re.search(r'k_gemm_f16_pp64ILi(\d)ELb\dELb\dELi(\d)ELb(\d)E', name) or re.search(r'k_gemm_f16_pp64<(\d), \w+, \w+, (\d), (\w+)>', name)
+    return (int(m.group(1)), int(m.group(2))) if m else (None, None)
+def kinds_of(rows):
+    """dispatch id -> kind for the full-size launches (grid = the frame's largest for that instantiation)."""
+    out = {}
+    by_inst = {}
+    for did in sorted(rows):
+        by_inst.setdefault(template_args(rows[did]['name']), []).append(did)
+    for (epi, ln), dids in by_inst.items():
+        gmax = max(rows[d]['grid'] for d in dids)
+        full = [d for d in dids if rows[d]['grid'] * 2 > gmax]
+        if (epi, ln) == (0, 1):
+            out.update({d: 'in_proj' for d in full})
+        elif (epi, ln) == (1, 1):
+            out.update({d: 'c_fc' for d in full})
+        elif (epi, ln) == (2, 2):
+            # grids differ between frames (crop counts) but a frame's out_proj and c_proj have the same grid and alternate
+            for i, d in enumerate(full):
+                out[d] = 'out_proj' if i % 2 == 0 else 'c_proj'
+    return out
+SHAPES = {'in_proj': (2304, 768), 'out_proj': (768, 768), 'c_fc': (3072, 768), 'c_proj': (768, 3072)}
+def algorithmic_bytes(kind, M):
+    N, K = SHAPES[kind]
+    ldc = 2368 if kind == 'in_proj' else N
+    rd = M * K * 2 + N * K * 2
+    if kind in ('in_proj', 'c_fc'):
+        return rd + M * 8 * (K // 256), M * N * 2                      # + the row statistics; fp16 output
+    return rd + M * N * 4, M * N * 4 + M * N * 2 + M * 8                # fp32 residual read; residual + fp16 copy + statistics written
+trace_rows = dispatch_rows(os.path.join(src, 'trace', 'bench_kernel_trace.csv'))
+fetch_rows = dispatch_rows(os.path.join(src, 'fetch', 'bench_counter_collection.csv'))
+write_rows = dispatch_rows(os.path.join(src, 'write', 'bench_counter_collection.csv'))
+sq_rows = dispatch_rows(sq_path)
+kinds = {}
+for label, rows in (('trace', trace_rows), ('fetch', fetch_rows), ('write', write_rows), ('sq', sq_rows)):
+    km = kinds_of(rows)
+    for did, kind in km.items():
+        g = kinds.setdefault(kind, {})
+        a = g.setdefault(label, {'n': 0})
+        a['n'] += 1
+        for key, val in rows[did].items():
+            if key not in ('name',):
+                a[key] = a.get(key, 0.0) + float(val)
+gemm_kinds = {}
+for kind, g in kinds.items():
+    N, K = SHAPES[kind]
+    t, f, w, q = g.get('trace', {'n': 0}), g.get('fetch', {'n': 0}), g.get('write', {'n': 0}), g.get('sq', {'n': 0})
+    if not t['n']:
+        continue
+    M = t['grid'] / t['n'] / 512 / (N // 256) * 256                    # average rows per launch (Grid_Size = work-items)
+    us = t['dur_ns'] / t['n'] / 1e3
+    alg_r, alg_w = algorithmic_bytes(kind, M)
+    d = {'launches': t['n'], 'avg_rows': round(M), 'avg_launch_us': round(us, 1), 'tflops': round(2 * M * N * K / (us * 1e-6) / 1e12, 1),
+         'algorithmic_read_bytes': round(alg_r), 'algorithmic_write_bytes': round(alg_w)}
+    if f['n']:
+        d['fetch_bytes_corrected_x2'] = round(2048 * f['FETCH_SIZE'] / f['n'])
+        d['fetch_over_algorithmic'] = round(d['fetch_bytes_corrected_x2'] / alg_r, 2)
+    if w['n']:
+        d['write_bytes'] = round(1024 * w['WRITE_SIZE'] / w['n'])
+        d['write_over_algorithmic'] = round(d['write_bytes'] / alg_w, 2)
+    if f['n'] and w['n']:
+        d['hbm_tb_per_s'] = round((d['fetch_bytes_corrected_x2'] + d['write_bytes']) / (us * 1e-6) / 1e12, 2)
+    if q['n'] and q.get('GRBM_GUI_ACTIVE'):
+        d['mfma_utilisation'] = round(q['SQ_VALU_MFMA_BUSY_CYCLES'] / (q['GRBM_GUI_ACTIVE'] / 8 * 1024), 3)
+        d['wave_cycles_waiting'] = round(q['SQ_WAIT_ANY'] / q['SQ_WAVE_CYCLES'], 3)
+        d['wave_cycles_issue_stalled'] = round(q['SQ_WAIT_INST_ANY'] / q['SQ_WAVE_CYCLES'], 3)
+        d['sustained_ghz'] = round(q['GRBM_GUI_ACTIVE'] / 8 / q['n'] / (q['dur_ns'] / q['n']), 3) if q.get('dur_ns') else None
+    gemm_kinds[kind] = d
+out['k_gemm_f16_pp64_by_kind'] = gemm_kinds
 # ---- stage kernels next to the GEMM (north_star: "rocprof HBM GB/s (clustering, renderer)"): bench.py's `roofline_stages` block reads this ----
 def bench_line(logname):
     try:

@@ -64,7 +64,7 @@ def _get(cfg, key, default=None):
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
                  clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
-                 box_mode='reference', box_workers=4, vit_graph=False, angle_mode='reference'):
+                 box_mode='reference', box_workers=4, vit_graph=False, angle_mode='reference', cu_reserve=None, cu_tower=None):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -115,6 +115,15 @@ class PseudoLabelPipeline:
         self._xy_pinned = None
         self._ransac_work = torch.zeros(100 * 36 + 64, dtype=torch.uint8, device=self.device)
         self.timings = {}
+        # CU-masked streams for the frames in flight (vilgod_amd/streams.py): the worker streams that carry a frame's front stage
+        # (clustering, filters, render) may use `cu_reserve` CUs of every XCD, its ViT pass runs on a second stream restricted to the
+        # other CUs ('complement') or unrestricted ('all').  0 = one unrestricted stream per worker (the default; sweep in LAB_NOTES.md).
+        self.cu_reserve = int(os.environ.get('VILGOD_CU_RESERVE', '0') if cu_reserve is None else cu_reserve)
+        self.cu_tower = str(os.environ.get('VILGOD_CU_TOWER', 'complement') if cu_tower is None else cu_tower)
+        if self.cu_tower not in ('complement', 'all'):
+            raise ValueError("cu_tower: 'complement' or 'all'")
+        self._stream_factories = None
+        self.vit_stream = None
         self._clip_cfg, self._clip_model_path, self._mcfg, self._n_views = clip_cfg, clip_model_path, mcfg, n_views
         self._workers = None
 
@@ -133,7 +142,13 @@ class PseudoLabelPipeline:
         w._graph_cls = None
         w._ground_stream = None
         w.timings = {}
-        w.stream = torch.cuda.Stream(device=self.device)
+        if self.cu_reserve > 0:
+            if self._stream_factories is None:
+                from .streams import make_streams
+                self._stream_factories = make_streams(self.device, self.cu_reserve, self.cu_tower)
+            w.stream, w.vit_stream = self._stream_factories[0](), self._stream_factories[1]()
+        else:
+            w.stream, w.vit_stream = torch.cuda.Stream(device=self.device), None
         from concurrent.futures import ThreadPoolExecutor
         w.thread = ThreadPoolExecutor(max_workers=1)       # a worker's frames run one after the other on ITS thread
         return w
@@ -183,7 +198,10 @@ class PseudoLabelPipeline:
         # they run on a HIGH-PRIORITY stream of their own so that their small kernels are dispatched ahead of the workers' heavy ones
         # instead of queueing behind every GEMM tile
         if getattr(self, '_ground_stream', None) is None:
-            self._ground_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            if self.cu_reserve > 0 and os.environ.get('VILGOD_CU_GROUND', 'masked') == 'masked':
+                self._ground_stream = self._stream_factories[0]()        # (a CU-masked stream cannot also carry a priority)
+            else:
+                self._ground_stream = torch.cuda.Stream(device=self.device, priority=-1)
         main = self._ground_stream
         main.wait_stream(torch.cuda.current_stream(self.device))
 
@@ -320,6 +338,17 @@ class PseudoLabelPipeline:
         return f
 
     # ---------------------------------------------------------------------------------------------
+    def _mark(self, name):
+        """Latency accounting of ONE frame (process_frame(timing=True) only): device-synchronise and book the time since the previous
+        mark under `name` (bench.py `frame_latency_ms`).  A no-op in the throughput paths."""
+        lat = getattr(self, '_lat', None)
+        if lat is None:
+            return
+        torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        lat[name] = lat.get(name, 0.0) + (now - lat['_t'])
+        lat['_t'] = now
+
     def new_sequence(self):
         """A fresh Patchwork++ state per sequence (zero_shot_detector.py:137-140)."""
         self.ground_model.reset()
@@ -350,7 +379,11 @@ class PseudoLabelPipeline:
         if n < 2:
             return np.full(n, -1, np.int64), np.zeros(n)
         lo, hi, w2 = self.cluster_model.mst(d_X)
-        labels, probs, _ = self.cluster_model.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), n)
+        self._mark('mst_kernels')
+        h_lo, h_hi, h_w2 = lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy()
+        self._mark('mst_d2h')
+        labels, probs, _ = self.cluster_model.tree(h_lo, h_hi, h_w2, n)
+        self._mark('hierarchy_host')
         return labels, probs
 
     # [C2]
@@ -412,8 +445,23 @@ class PseudoLabelPipeline:
                     probs, top1, score = g.classify(n, self.clip.text_features)
                 return probs.clone(), top1.clone(), score.clone()
             patches = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out=pmode)
-            with self._vit_in_turn():
-                return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
+            self._mark('render')
+            vs = self.vit_stream
+            if vs is None or n == 0:
+                with self._vit_in_turn():
+                    return clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
+            # CU-masked streams: the tower runs on this worker's ViT stream (its own CU set), ordered after the render and in front of
+            # whatever this frame's stream does next
+            cur = torch.cuda.current_stream(self.device)
+            vs.wait_stream(cur)
+            patches.record_stream(vs)
+            with torch.cuda.stream(vs):
+                with self._vit_in_turn():
+                    out = clip_scores(enc.encode_patches(patches, n), self.clip.text_features)
+            cur.wait_stream(vs)
+            for t_ in out:
+                t_.record_stream(cur)
+            return out
         crops = self.projection.render_frame(d_X, d_index, d_seg, transform_to_ego, out='f16' if self.vit_dtype == 'f16' else 'f32')
         return self.clip.predict_probs(crops)
 
@@ -549,18 +597,28 @@ class PseudoLabelPipeline:
             return time.perf_counter()
 
         t0 = time.perf_counter()
-        if mask is None:
-            d_pts = self.upload(points)
-            mask = self.ground(d_pts)
-            t0 = tick('ground', t0)
-            points = d_pts
-        else:
-            t['ground'] = 0.0
-        fs, d_ref, d_X, gidx = self.prepare(points, pose, ref_pose, fnr=fnr, state=state, mask=mask)
-        t0 = tick('to_ref', t0)
-        labels, probs = self.cluster(d_X)
-        t0 = tick('cluster', t0)
-        return self.label(fs, d_ref, d_X, gidx, labels, probs, t=t, t0=t0, tick=tick, before_classify=before_classify)
+        self._lat = {'_t': t0} if timing else None
+        try:
+            if mask is None:
+                d_pts = self.upload(points)
+                self._mark('upload')
+                mask = self.ground(d_pts)
+                self._mark('ground')
+                t0 = tick('ground', t0)
+                points = d_pts
+            else:
+                t['ground'] = 0.0
+            fs, d_ref, d_X, gidx = self.prepare(points, pose, ref_pose, fnr=fnr, state=state, mask=mask)
+            self._mark('to_ref+gather')
+            t0 = tick('to_ref', t0)
+            labels, probs = self.cluster(d_X)
+            t0 = tick('cluster', t0)
+            out = self.label(fs, d_ref, d_X, gidx, labels, probs, t=t, t0=t0, tick=tick, before_classify=before_classify)
+            if timing:
+                self.latency = {k: v for k, v in self._lat.items() if k != '_t'}
+            return out
+        finally:
+            self._lat = None
 
     def process_sequence(self, frames, poses, ref_pose, entropy_args=None, n_frames=2, seed=0, first_fnr=0, n_workers=1):
         """The reference's DEFAULT stage order over a whole sequence (preprocessing.yaml:50-68):
@@ -633,6 +691,7 @@ class PseudoLabelPipeline:
             return fs, result
         d_index = torch.from_numpy(index).to(self.device)
         d_seg = torch.from_numpy(seg).to(self.device)
+        self._mark('pack_clusters+h2d')
         xy_host = xy_ev = None
         if self.box_mode == 'reference':
             xy_host, xy_ev = self.xy_to_host_async(d_X)            # lands while the plane fit / filters / classification run
@@ -641,6 +700,7 @@ class PseudoLabelPipeline:
         valid, stats = self.filter(d_X, d_index, d_seg, plane)
         fs.valid = valid.cpu().numpy().astype(bool)
         fs.filtered = True
+        self._mark('plane+filter')
         t0 = tick('filter', t0)
         vrows = np.flatnonzero(fs.valid)
         if len(vrows) == 0:
@@ -661,13 +721,16 @@ class PseudoLabelPipeline:
             box_fut = self.fit_boxes_async(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
         if before_classify is not None:
             before_classify()                    # the frame's clustering / filtering is done, its crops are about to be queued
+        self._mark('valid_lists+box_request')
         probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
+        self._mark('encode+scores')
         if box_fut is None:
             box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg)
         top1 = top1.cpu().numpy()
         score = score.cpu().numpy()
         if box_fut is not None:
             box = box_fut.result()
+        self._mark('scores_d2h+box_wait')
         t0 = tick('classify+boxes', t0)
         V = self.projection.num_views
         nv = len(vrows)
@@ -686,6 +749,7 @@ class PseudoLabelPipeline:
                   'name': np.array([str(names[w]) for w in win[keep]]),
                   'score': np.array(final[keep]),
                   'moving': np.zeros(int(keep.sum()), dtype=bool)}
+        self._mark('vote+results')
         t0 = tick('vote+results', t0)
         self.timings = t
         self.last_probs = probs_d
