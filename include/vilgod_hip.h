@@ -223,6 +223,13 @@ int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, const double*
                          int min_cluster_size, double eps, int32_t* h_labels, double* h_probs,
                          int32_t* h_n_clusters);
 
+/* LidarFrame.generate_detections' grouping (src/vilgod/lidar_frame.py:163-167, 230-237; Detection objects :42-58 of
+ * src/dataclass/objects.py) on the host: points whose membership probability is < threshold become noise (h_probs may be NULL),
+ * clusters in ascending label order, each cluster's point indices ascending.  h_ids [capacity n]: the labels that own a point;
+ * h_index [capacity n]: packed point indices; h_seg [capacity n + 1]: cluster offsets into h_index; *h_n_clusters: clusters written. */
+int vg_pack_clusters_host(const int32_t* h_labels, const double* h_probs, int n, double threshold, int64_t* h_ids,
+                          int32_t* h_index, int32_t* h_seg, int32_t* h_n_clusters);
+
 /* GPU half of the clustering: exact k-NN core distances and THE minimum spanning tree of the mutual
  * reachability graph under the strict edge order (w2, pair d2, min id, max id) (unique -> identical to the CPU oracle's). */
 typedef struct vg_cluster vg_cluster;

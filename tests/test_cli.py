@@ -145,6 +145,52 @@ def test_cli_fused_stage_pass_equals_stage_after_stage(cuda, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_sequence_tail_leaves_the_thread_when_it_would_touch_the_gpu(cuda, tmp_path):
+    """device.overlap_sequences runs a sequence's host-only tail (track boxes, label propagation, pickles) on a thread under the next
+    sequence's GPU stages -- only when it really is host-only (ZeroShotDetector.back_is_host_only): with the default box
+    mode the static boxes were requested during classification and the tail runs on the thread; with device.box_mode=fast, or on a
+    resumed run whose classification is skipped (nothing prefetched), the box stage launches kernels, so the tail stays on the main
+    thread.  Either way both pickle families equal the run without overlap."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import preprocess_data
+    two = [o for o in OVR if 'n_sequences' not in o and 'end_sequence' not in o] + ['dataset.SYNTHETIC.n_sequences=2', 'end_sequence=1']
+    seqs = ('synthetic_train_0000', 'synthetic_train_0001')
+
+    def run(name, *extra):
+        root = str(tmp_path / name)
+        preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}'] + two + list(extra))
+        return root, [q['tail_on_thread'] for q in preprocess_data.LAST_RUN['sequences']]
+    base, on_thread = run('overlap')
+    assert on_thread == [True, True]
+    plain, on_thread = run('no_overlap', 'device.overlap_sequences=False')
+    assert on_thread == [False, False]
+    for q in seqs:
+        a, _, sa = _load(base, q)
+        b, _, sb = _load(plain, q)
+        assert sum(len(fr['name']) for fr in a) > 0
+        _same_outputs(a, sa, b, sb)
+    # fast box mode: the tracked rows' rectangles come from vg_cluster_boxes inside the box stage -> main thread
+    fast, on_thread = run('fast', 'device.box_mode=fast')
+    assert on_thread == [False, False]
+    fast2, _ = run('fast_no_overlap', 'device.box_mode=fast', 'device.overlap_sequences=False')
+    for q in seqs:
+        a, _, sa = _load(fast, q)
+        b, _, sb = _load(fast2, q)
+        _same_outputs(a, sa, b, sb)
+    # resumed run: the first run stops after classification (state pickle on disk), the second finds every frame classified and
+    # skips the stage -- no static-box requests were sent, the box stage fetches the points and asks itself -> main thread
+    head = DEFAULT_STAGES[:6]
+    root = str(tmp_path / 'resume')
+    preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}', 'pipeline_active=[' + ','.join(head) + ']'] + two)
+    preprocess_data.main(['preprocessor=waymo', f'dataset.DATA_PATH={root}'] + two)
+    assert [q['tail_on_thread'] for q in preprocess_data.LAST_RUN['sequences']] == [False, False]
+    for q in seqs:
+        a, _, sa = _load(root, q)
+        b, _, sb = _load(plain, q)
+        _same_outputs(a, sa, b, sb)
+
+
+@pytest.mark.gpu
 def test_cli_two_ranks_equal_one_rank(cuda, tmp_path):
     root1, root2 = str(tmp_path / 'one'), str(tmp_path / 'two')
     cli = os.path.join(ROOT, 'tools', 'preprocess_data.py')

@@ -279,3 +279,20 @@ def test_cu_mask_words_partition_the_device():
         cu_mask_words(256, 32, 'front')
     with pytest.raises(ValueError):
         cu_mask_words(256, 0, 'tower')
+
+
+def test_pack_clusters_host_equals_numpy_form():
+    """frame_state.pack_clusters (vg_pack_clusters_host: one counting sort in C++) against the numpy grouping it replaced
+    (lidar_frame.py:163-167, 230-237): ids, packed indices and offsets equal, dtypes too -- random labels incl. empty input, all noise,
+    gaps in the label range and thresholded probabilities."""
+    from vilgod_amd.frame_state import pack_clusters, pack_clusters_numpy
+    rng = np.random.default_rng(5)
+    cases = [(np.zeros(0, np.int64), None), (np.full(7, -1), rng.random(7)), (np.array([3, 3, -1, 9, 3, 9]), None)]
+    for n in (1, 17, 1000, 50_000):
+        lab = rng.integers(-1, 40, n)
+        lab[lab == 5] = 7                                  # a label nobody owns
+        cases += [(lab, rng.random(n)), (lab.astype(np.int32), None)]
+    for lab, pr in cases:
+        got, want = pack_clusters(lab, pr, 0.3), pack_clusters_numpy(lab, pr, 0.3)
+        for g, w in zip(got, want):
+            assert g.dtype == w.dtype and np.array_equal(g, w)

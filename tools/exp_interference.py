@@ -26,7 +26,7 @@ configs = [('unrestricted', torch.cuda.Stream(), torch.cuda.Stream())]
 for r in reserves:
     for tower in ('complement', 'all'):
         front, tow = make_streams(dev, r, tower)
-        configs.append((f'reserve {r}/XCD, GEMMs on {tower}', tow(), front()))
+        configs.append((f'reserve {r}/XCD, GEMMs on {tower}', tow(0), front(0)))
 sa = sb = None
 
 

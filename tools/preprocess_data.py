@@ -45,6 +45,7 @@ def set_random_seed(seed):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     LAST_RUN['sequences'] = []
+    LAST_RUN['tail_seconds_under_generator'] = 0.0
     logging.basicConfig(level=logging.INFO, format='[%(asctime)s][%(levelname)s] - %(message)s', stream=sys.stdout)
     logger = logging.getLogger('preprocess_data')
     cfg = vconfig.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'configs'), 'preprocessing', argv)
@@ -145,7 +146,7 @@ def main(argv=None):
 
     def finish_pending():
         while pending:
-            th, err, fin = pending.pop(0)
+            th, err, fin, _ = pending.pop(0)
             th.join()
             if err:
                 raise err[0]
@@ -171,7 +172,14 @@ def main(argv=None):
         if hasattr(dataset, 'prefetch_sequence'):
             t_gen = time.perf_counter()
             dataset.prefetch_sequence()                 # synthetic data: generate the sequence before the clock starts (stands for disk IO)
-            gen_seconds += time.perf_counter() - t_gen
+            t_gen_end = time.perf_counter()
+            # only generator time during which no tail thread was working comes off the clock: the previous sequence's tail (boxes, label
+            # propagation, pickles) may be running under it, and that work belongs to the loop
+            hidden = 0.0
+            for th, _, _, clock in pending:
+                hidden = max(hidden, min(t_gen_end, clock.get('ended_at', t_gen_end) if not th.is_alive() else t_gen_end) - t_gen)
+            gen_seconds += (t_gen_end - t_gen) - max(hidden, 0.0)
+            LAST_RUN['tail_seconds_under_generator'] = LAST_RUN.get('tail_seconds_under_generator', 0.0) + max(hidden, 0.0)
         t_seq = time.perf_counter()
         zsd = ZeroShotDetector(dataset, sequence_name, cfg=cfg, logger=logger, pipeline=pipeline)
         seq_indices = list(dataset.sequence_indices)
@@ -191,7 +199,7 @@ def main(argv=None):
             seconds = t_front + (clock['back'] if clock else 0.0)
             LAST_RUN['sequences'].append({'name': sequence_name, 'frames': seq_len, 'world_size': world,
                                           'seconds': seconds, 'front_seconds': t_front, 'back_seconds': clock['back'] if clock else 0.0,
-                                          'stage_ms_per_frame': dict(zsd.stage_ms),
+                                          'stage_ms_per_frame': dict(zsd.stage_ms), 'tail_on_thread': bool(clock and clock.get('thread', False)),
                                           # the stages every rank repeats over ALL frames when the frames of one sequence are sharded (ms per frame of the
                                           # sequence; with device.shard=sequences nothing is replicated)
                                           'replicated_ms_per_frame': 0.0 if (world == 1 or by_sequence) else round(sum(
@@ -219,18 +227,20 @@ def main(argv=None):
 
         if back and zsd.back_is_host_only():
             import threading
-            err, clock = [], {'back': 0.0}
+            err, clock = [], {'back': 0.0, 'thread': True}
 
-            def run(tail=tail, err=err, clock=clock):
+            def run(tail=tail, err=err, clock=clock, device=zsd.pipe.device):
                 t0 = time.perf_counter()
                 try:
+                    torch.cuda.set_device(device)   # a new thread starts on device 0: a safety net should the tail ever touch the GPU
                     tail()
                 except BaseException as e:      # noqa: BLE001  (re-raised on the main thread by finish_pending)
                     err.append(e)
-                clock['back'] = time.perf_counter() - t0
+                clock['ended_at'] = time.perf_counter()
+                clock['back'] = clock['ended_at'] - t0
             th = threading.Thread(target=run, name=f'vilgod-tail-{sequence_name}', daemon=True)
             th.start()
-            pending.append((th, err, lambda finish=finish, clock=clock: finish(clock=clock)))
+            pending.append((th, err, lambda finish=finish, clock=clock: finish(clock=clock), clock))
         else:
             t0 = time.perf_counter()
             tail()

@@ -28,16 +28,16 @@ struct Tree {
     std::vector<double> dist;
 };
 
-inline int uf_find(std::vector<int>& p, int x) {
-    int r = x;
-    while (p[r] != r) r = p[r];
-    while (p[x] != r) {
-        int nx = p[x];
-        p[x] = r;
-        x = nx;
-    }
-    return r;
-}
+// The stage's arrays, kept per calling thread between frames (a worker thread of the pipeline runs one frame after the other): a
+// 79k-point frame needs ~5 MB of them, and fresh std::vectors of that size are mmap'ed and page-faulted anew on every call.
+struct Work {
+    std::vector<int32_t> lo, hi;
+    std::vector<std::pair<int32_t, int32_t>> run;
+    Tree t;
+    std::vector<int> parent, top, sz, r_parent, r_child, r_size, relabel, queue, next_q, dfs;
+    std::vector<double> r_lambda;
+    std::vector<char> ignore;
+};
 
 }  // namespace
 
@@ -53,9 +53,12 @@ extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, co
     if (n <= min_cluster_size) return 0;
     const int m = n - 1;
     // ---- strict total order (w2, lo, hi): the GPU sorts by weight only, fix up runs of equal weight ----
-    std::vector<int32_t> lo_v(h_lo, h_lo + m), hi_v(h_hi, h_hi + m);
+    static thread_local Work ws;
+    std::vector<int32_t>&lo_v = ws.lo, &hi_v = ws.hi;
+    lo_v.assign(h_lo, h_lo + m);
+    hi_v.assign(h_hi, h_hi + m);
     {
-        std::vector<std::pair<int32_t, int32_t>> run;
+        std::vector<std::pair<int32_t, int32_t>>& run = ws.run;
         for (int i = 0; i < m;) {
             int j = i + 1;
             while (j < m && h_w2[j] == h_w2[i]) ++j;
@@ -71,47 +74,70 @@ extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, co
     h_lo = lo_v.data();
     h_hi = hi_v.data();
     // ---- single linkage ------------------------------------------------------------------------
-    Tree t;
+    // Union-find over the n POINTS (union by size, path halving) with the dendrogram node that currently stands for each set kept
+    // beside the root: the library's form -- every merge makes the new node n + i the parent of both sets, sets found by walking the
+    // 2n - 1 node forest -- builds chains that path compression has to flatten again and again (5.4 of the stage's 8.7 ms on 79k points).
+    Tree& t = ws.t;
     t.n = n;
     t.left.resize(m); t.right.resize(m); t.size.resize(m); t.dist.resize(m);
     {
-        std::vector<int> parent(2 * n - 1), sz(2 * n - 1, 1);
-        for (int i = 0; i < 2 * n - 1; ++i) parent[i] = i;
+        std::vector<int>&parent = ws.parent, &top = ws.top, &sz = ws.sz;
+        parent.resize(n); top.resize(n); sz.assign(n, 1);
+        for (int i = 0; i < n; ++i) parent[i] = top[i] = i;
+        auto find = [&](int x) {
+            while (parent[x] != x) {
+                parent[x] = parent[parent[x]];
+                x = parent[x];
+            }
+            return x;
+        };
         for (int i = 0; i < m; ++i) {
-            int a = uf_find(parent, h_lo[i]), b = uf_find(parent, h_hi[i]);
-            if (a == b) return 1;   // not a tree
-            t.left[i] = a;
-            t.right[i] = b;
+            const int ra = find(h_lo[i]), rb = find(h_hi[i]);
+            if (ra == rb) return 1;   // not a tree
+            t.left[i] = top[ra];
+            t.right[i] = top[rb];
             t.dist[i] = sqrt(h_w2[i]);
-            parent[a] = parent[b] = n + i;
-            sz[n + i] = sz[a] + sz[b];
-            t.size[i] = sz[n + i];
+            const int big = sz[ra] >= sz[rb] ? ra : rb, small = big == ra ? rb : ra;
+            parent[small] = big;
+            sz[big] += sz[small];
+            top[big] = n + i;
+            t.size[i] = sz[big];
         }
     }
     // ---- condense (BFS, ids in visiting order like the library) ----------------------------------
     // rows: parent cluster (0-based, 0 = root), child (point id, or cluster index if csize > 1), lambda, csize
-    std::vector<int> r_parent, r_child, r_size;
-    std::vector<double> r_lambda;
-    r_parent.reserve(n + 64); r_child.reserve(n + 64); r_size.reserve(n + 64); r_lambda.reserve(n + 64);
-    std::vector<int> relabel(2 * n - 1, -1);
-    std::vector<char> ignore(2 * n - 1, 0);
+    // (every point is one row; a cluster row pair needs two sides of >= min_cluster_size points: the row count is bounded, the arrays are
+    // written by index -- four push_backs per row and a std::vector stack were 3.6 ms of this stage on 79k points)
+    const size_t row_cap = (size_t)n + 2 * ((size_t)n / (size_t)min_cluster_size + 2);
+    std::vector<int>&r_parent = ws.r_parent, &r_child = ws.r_child, &r_size = ws.r_size, &relabel = ws.relabel;
+    std::vector<double>& r_lambda = ws.r_lambda;
+    std::vector<char>& ignore = ws.ignore;
+    r_parent.resize(row_cap); r_child.resize(row_cap); r_size.resize(row_cap); r_lambda.resize(row_cap);
+    size_t nr = 0;
+    relabel.assign(2 * n - 1, -1);
+    ignore.assign(2 * n - 1, 0);
     int next_label = 1;
     const int root = 2 * n - 2;
     relabel[root] = 0;
-    std::vector<int> queue, next_q, stack;
+    std::vector<int>&queue = ws.queue, &next_q = ws.next_q, &dfs = ws.dfs;
+    std::vector<int> stack;
+    queue.clear(); next_q.clear();
+    dfs.resize(n + 1);                                   // a subtree's pending nodes: never more than its leaves
     queue.push_back(root);
+    const int* tl = t.left.data();
+    const int* tr = t.right.data();
     auto emit_leaves = [&](int node, int p, double lam) {
-        stack.clear();
-        stack.push_back(node);
-        while (!stack.empty()) {
-            int x = stack.back();
-            stack.pop_back();
+        int sp = 0;
+        dfs[sp++] = node;
+        while (sp > 0) {
+            const int x = dfs[--sp];
             if (x < n) {
-                r_parent.push_back(p); r_child.push_back(x); r_lambda.push_back(lam); r_size.push_back(1);
+                r_parent[nr] = p; r_child[nr] = x; r_lambda[nr] = lam; r_size[nr] = 1;
+                ++nr;
             } else {
                 ignore[x] = 1;
-                stack.push_back(t.right[x - n]);
-                stack.push_back(t.left[x - n]);
+                dfs[sp++] = tr[x - n];
+                dfs[sp++] = tl[x - n];
             }
         }
     };
@@ -120,16 +146,16 @@ extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, co
         next_q.clear();
         for (int node : queue) {
             if (node < n || ignore[node]) continue;
-            const int l = t.left[node - n], r = t.right[node - n];
+            const int l = tl[node - n], r = tr[node - n];
             const double d = t.dist[node - n];
             const double lam = d > 0.0 ? 1.0 / d : INF;
             const int lc = l >= n ? t.size[l - n] : 1, rc = r >= n ? t.size[r - n] : 1;
             const int p = relabel[node];
             if (lc >= min_cluster_size && rc >= min_cluster_size) {
                 relabel[l] = next_label;
-                r_parent.push_back(p); r_child.push_back(next_label++); r_lambda.push_back(lam); r_size.push_back(lc);
+                r_parent[nr] = p; r_child[nr] = next_label++; r_lambda[nr] = lam; r_size[nr] = lc; ++nr;
                 relabel[r] = next_label;
-                r_parent.push_back(p); r_child.push_back(next_label++); r_lambda.push_back(lam); r_size.push_back(rc);
+                r_parent[nr] = p; r_child[nr] = next_label++; r_lambda[nr] = lam; r_size[nr] = rc; ++nr;
             } else if (lc < min_cluster_size && rc < min_cluster_size) {
                 emit_leaves(l, p, lam);
                 emit_leaves(r, p, lam);
@@ -140,13 +166,13 @@ extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, co
                 relabel[l] = p;
                 emit_leaves(r, p, lam);
             }
-            next_q.push_back(l);
-            next_q.push_back(r);
+            if (l >= n && !ignore[l]) next_q.push_back(l);
+            if (r >= n && !ignore[r]) next_q.push_back(r);
         }
         queue.swap(next_q);
     }
     const int nc = next_label;          // clusters 0..nc-1, 0 = root
-    const size_t nrows = r_parent.size();
+    const size_t nrows = nr;
     // ---- stability, cluster tree ------------------------------------------------------------------
     std::vector<double> birth(nc, 0.0), stab(nc, 0.0), death(nc, 0.0);
     std::vector<int> cpar(nc, -1);
@@ -230,5 +256,38 @@ extern "C" int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, co
         h_probs[pt] = (mx == 0.0 || std::isinf(lam)) ? 1.0 : std::min(lam, mx) / mx;
     }
     if (h_n_clusters) *h_n_clusters = nl;
+    return 0;
+}
+
+// LidarFrame.generate_detections' grouping (src/vilgod/lidar_frame.py:163-167, 230-237) as one counting sort: labels of points whose
+// membership probability is below the threshold become noise, the clusters come in ascending label order, each cluster's point indices
+// ascending.  h_ids: [<= n] labels that own at least one point; h_index: [<= n] packed point indices; h_seg: [n_clusters + 1] offsets.
+extern "C" int vg_pack_clusters_host(const int32_t* h_labels, const double* h_probs, int n, double threshold, int64_t* h_ids,
+                                     int32_t* h_index, int32_t* h_seg, int32_t* h_n_clusters) {
+    if (n < 0 || (n > 0 && !h_labels) || !h_ids || !h_index || !h_seg || !h_n_clusters) return 1;
+    int max_label = -1;
+    for (int i = 0; i < n; ++i) max_label = std::max(max_label, (int)h_labels[i]);
+    static thread_local std::vector<int> count;
+    count.assign((size_t)max_label + 2, 0);
+    for (int i = 0; i < n; ++i) {
+        const int l = h_labels[i];
+        if (l >= 0 && !(h_probs && h_probs[i] < threshold)) count[l + 1]++;
+    }
+    int nc = 0, total = 0;
+    for (int l = 0; l <= max_label; ++l) {
+        const int c = count[l + 1];
+        count[l + 1] = total;                              // start of label l's segment (if it has one)
+        if (c > 0) {
+            h_ids[nc] = l;
+            h_seg[nc++] = total;
+            total += c;
+        }
+    }
+    h_seg[nc] = total;
+    for (int i = 0; i < n; ++i) {
+        const int l = h_labels[i];
+        if (l >= 0 && !(h_probs && h_probs[i] < threshold)) h_index[count[l + 1]++] = i;
+    }
+    *h_n_clusters = nc;
     return 0;
 }

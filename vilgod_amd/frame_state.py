@@ -18,7 +18,27 @@ DETECTION_FIELDS = ['cluster_id', '_bounding_box', 'valid', 'static', 'gt_assign
 
 def pack_clusters(labels, probs, threshold):
     """lidar_frame.py:163-167, 230-237 as arrays: labels of low-probability points -> -1; clusters in ascending
-    label order; each cluster's point indices ascending.  Returns (cluster_ids, packed index int32, seg_off int32)."""
+    label order; each cluster's point indices ascending.  Returns (cluster_ids, packed index int32, seg_off int32).
+    One counting sort on the host (csrc/hdbscan_tree.cpp vg_pack_clusters_host): the numpy form below -- a stable argsort of ~80k labels --
+    was 2 ms of a frame's 12.6 ms front-stage latency (round 5)."""
+    import ctypes
+    from ._lib import lib, check
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    n = len(labels)
+    pr = None if probs is None else np.ascontiguousarray(probs, dtype=np.float64)
+    ids = np.empty(n, np.int64)
+    index = np.empty(n, np.int32)
+    seg = np.empty(n + 1, np.int32)
+    nc = ctypes.c_int32(0)
+    p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+    check(lib.vg_pack_clusters_host(p(labels), p(pr), n, float(threshold), p(ids), p(index), p(seg), ctypes.byref(nc)),
+          'vg_pack_clusters_host')
+    c = nc.value
+    return ids[:c].copy(), index[:int(seg[c])].copy(), seg[:c + 1].copy()
+
+
+def pack_clusters_numpy(labels, probs, threshold):
+    """The same grouping in numpy (what `pack_clusters` computed before round 5; tests compare the two)."""
     labels = np.asarray(labels).copy()
     if probs is not None:
         labels[np.asarray(probs) < threshold] = -1

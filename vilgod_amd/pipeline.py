@@ -146,7 +146,8 @@ class PseudoLabelPipeline:
             if self._stream_factories is None:
                 from .streams import make_streams
                 self._stream_factories = make_streams(self.device, self.cu_reserve, self.cu_tower)
-            w.stream, w.vit_stream = self._stream_factories[0](), self._stream_factories[1]()
+            k = len(self._workers or [])                 # this worker's position: the pooled masked streams are handed out by it
+            w.stream, w.vit_stream = self._stream_factories[0](1 + k), self._stream_factories[1](k)
         else:
             w.stream, w.vit_stream = torch.cuda.Stream(device=self.device), None
         from concurrent.futures import ThreadPoolExecutor
@@ -155,7 +156,8 @@ class PseudoLabelPipeline:
 
     def _ensure_workers(self, n_workers):
         if self._workers is None or len(self._workers) < n_workers:
-            self._workers = (self._workers or []) + [self._clone_for_worker() for _ in range(n_workers - len(self._workers or []))]
+            for _ in range(n_workers - len(self._workers or [])):
+                self._workers = (self._workers or []) + [self._clone_for_worker()]
         return self._workers[:n_workers]
 
     def map_workers(self, items, fn, n_workers):
@@ -199,7 +201,7 @@ class PseudoLabelPipeline:
         # instead of queueing behind every GEMM tile
         if getattr(self, '_ground_stream', None) is None:
             if self.cu_reserve > 0 and os.environ.get('VILGOD_CU_GROUND', 'masked') == 'masked':
-                self._ground_stream = self._stream_factories[0]()        # (a CU-masked stream cannot also carry a priority)
+                self._ground_stream = self._stream_factories[0](0)       # (a CU-masked stream cannot also carry a priority)
             else:
                 self._ground_stream = torch.cuda.Stream(device=self.device, priority=-1)
         main = self._ground_stream
@@ -699,6 +701,7 @@ class PseudoLabelPipeline:
         fs.ground_plane_model_ref = plane
         valid, stats = self.filter(d_X, d_index, d_seg, plane)
         fs.valid = valid.cpu().numpy().astype(bool)
+        st = stats.cpu().numpy() if self.box_mode == 'reference' else None     # (the same kernel wrote it: no further wait)
         fs.filtered = True
         self._mark('plane+filter')
         t0 = tick('filter', t0)
@@ -712,18 +715,20 @@ class PseudoLabelPipeline:
         v_seg = np.r_[0, np.cumsum([len(p) for p in parts])].astype(np.int32)
         d_vindex = torch.from_numpy(v_index).to(self.device)
         d_vseg = torch.from_numpy(v_seg).to(self.device)
-        box_fut = None
-        if self.box_mode == 'reference':
-            # host part of the reference-exact box fit (vilgod_amd/boxes.py) in a helper process, started before the frame's crops
-            # are queued (the boxes do not depend on the classes)
-            st = stats.cpu().numpy()
-            xy_ev.synchronize()
-            box_fut = self.fit_boxes_async(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
         if before_classify is not None:
             before_classify()                    # the frame's clustering / filtering is done, its crops are about to be queued
-        self._mark('valid_lists+box_request')
+        self._mark('valid_lists')
         probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
         self._mark('encode+scores')
+        box_fut = None
+        if self.box_mode == 'reference':
+            # host part of the reference-exact box fit (vilgod_amd/boxes.py) in a helper process.  The boxes do not depend on the classes;
+            # the request (gathering and pickling the clusters' xy points: ~1 ms of this thread) goes out AFTER the frame's crops are
+            # queued -- the GPU renders and encodes meanwhile, the helpers have the ViT pass's ~13 ms for their ~2.5 ms (round 5: the
+            # request used to sit in front of the render, on the frame's critical path)
+            xy_ev.synchronize()
+            box_fut = self.fit_boxes_async(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
+            self._mark('box_request')
         if box_fut is None:
             box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg)
         top1 = top1.cpu().numpy()

@@ -10,6 +10,7 @@ Mask layout (amdkfd, gfx9.4.3+ in SPX mode): bit i of the mask is CU slot i // 8
 its shader engines -- the low 8 r bits are r CUs of every XCD spread over its engines (tools/micro/cu_mask_probe.hip prints the
 placement a mask really produces)."""
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -42,7 +43,9 @@ def cu_mask_words(n_cu, reserve_per_xcd, role):
 
 
 class MaskedStream(torch.cuda.ExternalStream):
-    """A torch view of a CU-masked HIP stream; the HIP stream lives as long as this object."""
+    """A torch view of a CU-masked HIP stream.  The HIP stream is created once and lives until the process ends: torch's caching
+    allocator keeps events on every stream a tensor was `record_stream`ed on and records them when the block is freed, so destroying
+    the stream under it crashes the process (seen: a segmentation fault when a test's pipeline went out of scope)."""
 
     def __new__(cls, words, device):
         device = torch.device(device)
@@ -52,31 +55,39 @@ class MaskedStream(torch.cuda.ExternalStream):
             check(lib.vg_stream_create_cu_mask(ctypes.byref(h), words.ctypes.data_as(ctypes.c_void_p), len(words)),
                   'vg_stream_create_cu_mask')
         self = super().__new__(cls, h.value, device=device)
-        self._vg_handle = h
         self.cu_mask_words = words.copy()
         return self
 
-    def __del__(self):
-        h = getattr(self, '_vg_handle', None)
-        if h is not None and lib is not None:
-            self._vg_handle = None
-            try:
-                lib.vg_stream_destroy(h)
-            except Exception:       # noqa: BLE001  (interpreter shutdown)
-                pass
+
+# Every masked stream is its own hardware queue, and queues beyond GPU_MAX_HW_QUEUES are time-sliced (seven pipeline objects with masked
+# streams in one process: everything ran 4x slower).  So the streams are pooled per (device, mask) and handed out by POSITION: worker k of
+# every pipeline object of a process gets the same k-th stream -- two pipeline objects used at the same time would serialise on it, which
+# the tools that build several avoid by running one variant per process.
+_POOL = {}
+_POOL_LOCK = threading.Lock()
+
+
+def pooled_stream(device, words, position):
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tuple(int(w) for w in words))
+    with _POOL_LOCK:
+        pool = _POOL.setdefault(key, [])
+        while len(pool) <= position:
+            pool.append(MaskedStream(words, device))
+        return pool[position]
 
 
 def make_streams(device, reserve_per_xcd, tower='complement'):
-    """-> (new_front_stream, new_tower_stream) factories for `device`; tower: 'complement' | 'all' (unmasked torch stream)."""
+    """-> (front_stream(k), tower_stream(k)) for worker position k of `device`; tower: 'complement' | 'all' (unmasked torch stream)."""
     n_cu = device_cu_count(device)
     front_words = cu_mask_words(n_cu, reserve_per_xcd, 'front')
     tower_words = cu_mask_words(n_cu, reserve_per_xcd, 'tower')
 
-    def front():
-        return MaskedStream(front_words, device)
+    def front(k):
+        return pooled_stream(device, front_words, k)
 
-    def tower_stream():
+    def tower_stream(k):
         if tower == 'all':
             return torch.cuda.Stream(device=device)
-        return MaskedStream(tower_words, device)
+        return pooled_stream(device, tower_words, k)
     return front, tower_stream

@@ -26,6 +26,7 @@ parity with the sequential reference), the other stages run on the 
 import contextlib
 import os
 import pickle
+import threading
 import time
 from pathlib import Path
 
@@ -45,6 +46,7 @@ from .pipeline import PseudoLabelPipeline
 # outstanding; tools/preprocess_data.py waits for the last one before it returns, and a detector that is about to LOAD a file waits
 # for a write of that file first.  If the helper cannot be started or dies, the file is written in the background thread instead.
 _STATE_WRITER = {'pool': None, 'pending': None, 'path': None, 'proc': None}
+_STATE_LOCK = threading.RLock()      # the main thread, a sequence's tail thread and the writer's pool thread all touch _STATE_WRITER
 
 
 def _write_state_file(path, compacts):
@@ -57,20 +59,21 @@ def _write_state_file(path, compacts):
 
 
 def start_state_writer():
-    """Starts the helper process (idempotent)."""
-    if _STATE_WRITER['proc'] is not None and _STATE_WRITER['proc'].poll() is None:
+    """Starts the helper process (idempotent; one at a time: the lock keeps two threads from each starting one)."""
+    with _STATE_LOCK:
+        if _STATE_WRITER['proc'] is not None and _STATE_WRITER['proc'].poll() is None:
+            return _STATE_WRITER['proc']
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
+        try:
+            _STATE_WRITER['proc'] = subprocess.Popen([sys.executable, '-m', 'vilgod_amd.state_writer'], stdin=subprocess.PIPE,
+                                                     stdout=subprocess.PIPE, env=env, cwd=root)
+        except OSError:
+            _STATE_WRITER['proc'] = None
         return _STATE_WRITER['proc']
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
-    env['PYTHONPATH'] = root + os.pathsep + env.get('PYTHONPATH', '')
-    try:
-        _STATE_WRITER['proc'] = subprocess.Popen([sys.executable, '-m', 'vilgod_amd.state_writer'], stdin=subprocess.PIPE,
-                                                 stdout=subprocess.PIPE, env=env, cwd=root)
-    except OSError:
-        _STATE_WRITER['proc'] = None
-    return _STATE_WRITER['proc']
 
 
 def _write_state_via_helper(path, compacts):
@@ -89,7 +92,7 @@ def _write_state_via_helper(path, compacts):
                 status, val = pickle.loads(p.stdout.read(n))
                 if status == 'ok':
                     return
-                raise RuntimeError(f'state writer process: {val}')
+                raise RuntimeError(f'state writer process, writing {path}: {val}')
         except (BrokenPipeError, EOFError, OSError, ValueError):
             pass
         import logging
@@ -98,23 +101,31 @@ def _write_state_via_helper(path, compacts):
             p.kill()
         except Exception:               # noqa: BLE001
             pass
-        _STATE_WRITER['proc'] = None
+        with _STATE_LOCK:
+            if _STATE_WRITER['proc'] is p:
+                _STATE_WRITER['proc'] = None
     _write_state_file(path, compacts)
 
 
 def wait_state_writes(path=None):
     """Blocks until the outstanding background state write (if any; with `path`: only a write of that file) is on disk; re-raises
     its error."""
-    if path is not None and _STATE_WRITER['path'] != str(path):
-        return
-    fut, _STATE_WRITER['pending'] = _STATE_WRITER['pending'], None
+    with _STATE_LOCK:
+        if path is not None and _STATE_WRITER['path'] != str(path):
+            return
+        fut, _STATE_WRITER['pending'] = _STATE_WRITER['pending'], None
+        written = _STATE_WRITER['path']
     if fut is not None:
-        fut.result()
+        try:
+            fut.result()
+        except BaseException as e:      # noqa: BLE001  (name the file: the error surfaces in whichever thread waits next)
+            raise RuntimeError(f'background write of the sequence state {written} failed: {e}') from e
 
 
 def shutdown_state_writer():
     wait_state_writes()
-    p, _STATE_WRITER['proc'] = _STATE_WRITER['proc'], None
+    with _STATE_LOCK:
+        p, _STATE_WRITER['proc'] = _STATE_WRITER['proc'], None
     if p is not None:
         try:
             p.stdin.close()
@@ -126,12 +137,13 @@ def shutdown_state_writer():
 def _submit_state_write(path, compacts):
     from concurrent.futures import ThreadPoolExecutor
     wait_state_writes()
-    if _STATE_WRITER['pool'] is None:
-        import atexit
-        _STATE_WRITER['pool'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vilgod-state-writer')
-        atexit.register(shutdown_state_writer)
-    _STATE_WRITER['path'] = str(path)
-    _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_via_helper, path, compacts)
+    with _STATE_LOCK:
+        if _STATE_WRITER['pool'] is None:
+            import atexit
+            _STATE_WRITER['pool'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vilgod-state-writer')
+            atexit.register(shutdown_state_writer)
+        _STATE_WRITER['path'] = str(path)
+        _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_via_helper, path, compacts)
 
 
 class ZeroShotDetector:
@@ -384,13 +396,29 @@ class ZeroShotDetector:
         return active[:k], active[k:]
 
     def back_is_host_only(self):
-        """After process('front'): does the `back` part stay off the GPU?  The box stage does when the tracker has run (its track branch
-        reads the static boxes the helper processes prefetched during classification)."""
+        """After process('front'): does the `back` part stay off the GPU?  The box stage does only when every precondition of its
+        host-only route holds -- checked here, not assumed: the tracker has valid tracks, the boxes come from the helper
+        processes (box_mode 'reference'), every tracked (frame, row) is covered by the static-box request `classification` sent ahead
+        (`_box_prefetch`; empty on a resumed run that skipped classification, or when the two stages' `valid_only` differ), and every
+        tracked frame's points are on the host (`_host_X`) and gathered on the device (`_dev[fnr]['X']`, only handed through).  Anything
+        else would launch kernels from the tail thread -- on the thread's default device, with the next sequence's stages running --
+        so the caller then runs the tail synchronously on the main thread."""
         _, back = self.split_stages()
         if not back:
             return False
-        if 'fit_bounding_boxes_simple' in back and (self.tracker is None or len(self.tracker.tracks_valid) == 0):
-            return False
+        if 'fit_bounding_boxes_simple' in back:
+            if self.tracker is None or len(self.tracker.tracks_valid) == 0 or self.pipe.box_mode != 'reference':
+                return False
+            tracked = {}
+            for t in self.tracker.tracks_valid:
+                for fnr, row in t.source:
+                    tracked.setdefault(fnr, set()).add(int(row))
+            for fnr, rows in tracked.items():
+                pre = self._box_prefetch.get(fnr)
+                if pre is None or not rows <= set(int(r) for r in pre[0]):
+                    return False
+                if fnr not in self._host_X or 'X' not in self._dev.get(fnr, {}):
+                    return False
         return True
 
     def process(self, part='all'):
