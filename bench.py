@@ -176,6 +176,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=96)
     ap.add_argument('--warmup', type=int, default=12)
+    ap.add_argument('--blocks', type=int, default=3, help='timed blocks of --steps frames each, on distinct clouds, every one bracketed by its own '
+                    'barrier + synchronize; value = the MEDIAN block (one 0.3 s window on a shared box reads +-4 %%); 1 = a single block')
     ap.add_argument('--points', type=int, default=150_000)
     ap.add_argument('--objects', type=int, default=60)
     ap.add_argument('--views', type=int, default=4)
@@ -227,11 +229,12 @@ def main():
     pipe = PseudoLabelPipeline(device=dev, vit_dtype=args.dtype, n_views=args.views, max_points=args.points + 1024,
                                clip_model_path='/nonexistent', box_mode=args.box_mode, vit_graph=args.vit_graph, angle_mode=args.angle_mode)
     K, W = args.steps, max(args.warmup, args.inflight if args.inflight > 1 else 0)       # warm-up covers the worker handles
+    B = max(1, args.blocks)                          # timed blocks (each exactly K steps, each on its own distinct clouds)
     # ONE sequence of world * K timed frames (+ a warm-up stretch in front), contiguous block of K frames per rank, smooth
     # trajectory; every frame of the stream is a distinct seeded cloud (pinned host memory; `--input resident`: in HBM)
     poses = synthetic.make_poses(W + world * K + 8, seed=0)
     host_frames = [torch.from_numpy(synthetic.make_frame(1 + rank * 100_000 + i, args.points, n_objects=args.objects)).pin_memory()
-                   for i in range(W + K)]
+                   for i in range(W + B * K)]
     frames = [f.to(dev) for f in host_frames] if args.input == 'resident' else host_frames
     if args.input == 'host':
         # a block's input copies are all queued up front, one device buffer per frame: bring torch's caching allocator to the
@@ -261,8 +264,10 @@ def main():
         return p.process_frames([src[first_frame + i] for i in idx], [poses[first_pose + i] for i in idx], poses[0],
                                 n_workers=inflight, first_fnr=first_fnr, after_ground=after_ground)
 
-    def timed_block(p):
-        """The timed region of one rank: ground-state hand-off + K frames + the one all-gather.  -> (elapsed, outputs)."""
+    def timed_block(p, b=0):
+        """The timed region of one rank: ground-state hand-off + K frames + the one all-gather.  -> (elapsed, outputs).
+        b: which block of K distinct clouds of the stream (frames[W + b K : W + (b + 1) K])."""
+        off = W + b * K
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -275,7 +280,7 @@ def main():
             # pass of ALL frames, in order, on its high-priority ground stream (0.36 ms per scan: N * K passes against K * ~15 ms of own
             # work) and processes its own frames in full; rank r's first frame waits for r ground passes, no state is exchanged.
             # (The other ranks' clouds are not held here: this rank's own stand in, same upload and ground cost.)
-            seq = [frames[W + g // world] for g in range(world * K)]
+            seq = [frames[off + g // world] for g in range(world * K)]
             seq_poses = [poses[W + g] for g in range(world * K)]
             mine = [g for g in range(world * K) if g % world == rank]
             if inflight == 1:
@@ -290,15 +295,15 @@ def main():
                 out = p.process_frames(seq, seq_poses, poses[0], n_workers=inflight, first_fnr=0, own=mine)
         elif world > 1 and args.ground_handoff == 'replay':
             for i in range(rank * K):                    # the frames before this rank's block: ground stage only (the other ranks'
-                p.ground(p.upload(frames[W + i % K]))    # clouds are not held here: this rank's own stand in, same cost)
-            out = run_steps(p, W + rank * K, K, rank * K, first_frame=W)
+                p.ground(p.upload(frames[off + i % K]))  # clouds are not held here: this rank's own stand in, same cost)
+            out = run_steps(p, W + rank * K, K, rank * K, first_frame=off)
         elif world > 1:
             # chain: the block's ground passes are queued first on the caller's stream (process_frames does that), the state after
             # them is exported and sent on while the workers are already busy with the block's frames
             vdist.recv_ground_state(p.ground_model, dev)
-            out = run_steps(p, W + rank * K, K, rank * K, after_ground=lambda: vdist.send_ground_state(p.ground_model, dev), first_frame=W)
+            out = run_steps(p, W + rank * K, K, rank * K, after_ground=lambda: vdist.send_ground_state(p.ground_model, dev), first_frame=off)
         else:
-            out = run_steps(p, W, K, 0, first_frame=W)
+            out = run_steps(p, W, K, 0, first_frame=off)
         score_mats = [probs for _, _, probs in out]
         # the one collective of the path: all-gather of the per-crop score matrices (padded to a common length)
         scores = torch.cat(score_mats) if score_mats else torch.zeros((0, 24), device=dev)
@@ -387,7 +392,13 @@ def main():
             {'graphs_captured': 0, 'graph_launches': 0, 'graphs_evicted': 0, 'graphs_live': 0}
 
     g_before = graph_stats(pipe)
-    elapsed, outs = timed_block(pipe)
+    # B blocks of EXACTLY K steps each, every block on its own K distinct clouds and bracketed by its own barrier + synchronize (timed_block);
+    # the reported block is the MEDIAN one (its elapsed time, its outputs): a single 0.3 s window decided round 4's number to +-4 %
+    blocks_run = [timed_block(pipe, b) for b in range(B)]
+    order = sorted(range(B), key=lambda b: blocks_run[b][0])
+    elapsed, outs = blocks_run[order[(B - 1) // 2]]
+    block_elapsed = [e for e, _ in blocks_run]
+    outs0 = blocks_run[0][1]                         # block 0 = frames[W : W + K]: the frames the information blocks below process again
     g_after = graph_stats(pipe)
     crops = sum(p.shape[0] for _, _, p in outs)
     clusters = sum(fs.n_detections for fs, _, _ in outs)
@@ -408,6 +419,26 @@ def main():
         launches, gemm_ms, gemm_flops = pipe.clip.encoder.profile_read(kind=1)        # the dominant kernel alone
         all_launches, all_ms, all_flops = pipe.clip.encoder.profile_read(kind=-1)
         pipe.clip.encoder.profile(False)
+
+    # Latency of ONE frame on the otherwise idle GPU, stage by stage (pipeline.process_frame(timing=True): a device synchronisation behind
+    # every stage; medians over six frames after two untimed ones).  Not a throughput figure: it is what an online user waits for, and what a
+    # timed block pays once while its pipeline fills (the first frame's front stage runs on an empty GPU before the first GEMM starts).
+    frame_latency = None
+    if not args.no_roofline_pass and not args.stage_times and world == 1:
+        rows_l = []
+        pipe.new_sequence()
+        for i in range(min(8, W + K)):
+            torch.cuda.synchronize()
+            pipe.process_frame(frames[i], poses[i + 1], poses[0], fnr=i, timing=True)
+            if i >= 2:
+                rows_l.append(dict(pipe.latency))
+        if rows_l:
+            med_l = {k: round(1e3 * float(np.median([r.get(k, 0.0) for r in rows_l])), 3) for k in rows_l[0]}
+            back_keys = ('encode+scores', 'scores_d2h+box_wait', 'vote+results')
+            frame_latency = dict(med_l, total=round(sum(med_l.values()), 3),
+                                 front_stage_until_the_crops_are_queued=round(sum(v for k, v in med_l.items() if k not in back_keys), 3),
+                                 note='one frame at a time on an idle GPU, a device synchronisation behind every stage (sum = the frame\'s latency; '
+                                      'inside the stream the stages of different frames overlap)')
 
     # The tower the way the pipeline runs it: TWO encodes in flight (pipeline._vit_in_turn), every kernel of the tower counted.  The
     # sequential pass above times one launch at a time and so pays, per launch, for the partial last round of 256 x 256 tiles (333 crops
@@ -458,6 +489,8 @@ def main():
         out = {
             'metric': 'pseudo-labeled LiDAR frames/sec (150k pts, ~60 clusters)',
             'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
+            'blocks': B, 'block_values': [round(frames_total / e, 3) for e in block_elapsed],
+            'block_spread': round((max(block_elapsed) - min(block_elapsed)) / elapsed, 4),
             'ms_per_step': round(1000.0 * elapsed / K, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f16' if args.dtype == 'f16' else 'f32', 'data': 'synthetic',
             'config': {
@@ -470,9 +503,10 @@ def main():
                              ', one all-gather of the score matrices'),
                 'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,
                 'setup_frames': n_setup * setup_passes,
-                'distinct_frames': len({id(f) for f in frames[W:W + K]}), 'distinct_crop_counts': len({int(p.shape[0]) for _, _, p in outs}),
+                'distinct_frames': len({id(f) for f in frames[W:W + B * K]}), 'distinct_crop_counts': len({int(p.shape[0]) for _, _, p in outs}),
                 'input': ('pinned host buffers, H2D copy inside the timed region' if args.input == 'host' else 'resident in HBM before the timed region'),
                 'vit_launch': 'captured hipGraphs per crop-count bucket' if args.vit_graph else 'plain stream launches',
+                'value_is': f'the median of {B} timed blocks of {K} steps each (block_values; every block exactly --steps frames on its own distinct clouds, own barrier + synchronize brackets)',
                 'graphs_captured': g_after['graphs_captured'] - g_before['graphs_captured'],
                 'graph_launches': g_after['graph_launches'] - g_before['graph_launches'],
                 'angle_mode': args.angle_mode,
@@ -501,6 +535,8 @@ def main():
                                          'ms_per_frame': round(all_ms / max(n_pass, 1), 3)},
             },
         }
+        if frame_latency is not None:
+            out['frame_latency_ms'] = frame_latency
         if args.stage_times:
             out['stage_ms_per_frame'] = {k: round(1000.0 * v / K, 3) for k, v in stage.items()}
         if world == 1 and not args.stage_times and not args.no_extras:
@@ -607,7 +643,7 @@ def main():
                 other = 'fast' if args.box_mode == 'reference' else 'reference'
                 dt, res = other_shape(args.points, args.objects, args.views, K, box_mode=other)
                 n = differ = 0
-                for (fa, _, _), (fb, _, _) in zip(outs, res):
+                for (fa, _, _), (fb, _, _) in zip(outs0, res):
                     if fa.boxes is None or fb.boxes is None:
                         continue
                     rows = np.flatnonzero(fa.valid)
@@ -624,7 +660,7 @@ def main():
             def hipgraph_loop():
                 on = args.vit_graph
                 dt, res = other_shape(args.points, args.objects, args.views, K, vit_graph=not on)
-                same = all(np.array_equal(a[1]['name'], b[1]['name']) and np.array_equal(a[2].cpu().numpy(), b[2].cpu().numpy()) for a, b in zip(outs, res))
+                same = all(np.array_equal(a[1]['name'], b[1]['name']) and np.array_equal(a[2].cpu().numpy(), b[2].cpu().numpy()) for a, b in zip(outs0, res))
                 gs = other_shape.graphs if not on else {k: g_after[k] - g_before[k] for k in g_after}
                 return {'captured': {'value': round(value if on else K / dt, 3), 'unit': 'frames/s'},
                         'plain_launches': {'value': round(K / dt if on else value, 3), 'unit': 'frames/s'},
@@ -646,7 +682,7 @@ def main():
                 return fn
             def resident_input():
                 dt, res = other_shape(args.points, args.objects, args.views, K, resident=(args.input == 'host'))
-                same = all(np.array_equal(a[1]['name'], b[1]['name']) for a, b in zip(outs, res))
+                same = all(np.array_equal(a[1]['name'], b[1]['name']) for a, b in zip(outs0, res))
                 return {'value': round(K / dt, 3), 'unit': 'frames/s', 'bytes_per_frame': int(host_frames[0].numel() * host_frames[0].element_size()),
                         'same_names_as_metric_run': bool(same),
                         'note': ('the same steps with every frame uploaded to HBM before the clock starts' if args.input == 'host' else
@@ -657,7 +693,7 @@ def main():
                 other = 'reference' if args.angle_mode == 'device' else 'device'
                 dt, res = other_shape(args.points, args.objects, args.views, K, angle_mode=other)
                 n = flips = 0
-                for a, b in zip(outs, res):
+                for a, b in zip(outs0, res):
                     if np.array_equal(a[0].valid, b[0].valid) and pipe.cls_key in a[0].cls and pipe.cls_key in b[0].cls:
                         rows = np.flatnonzero(a[0].valid)
                         n += len(rows)
@@ -697,7 +733,7 @@ def main():
                 torch.cuda.synchronize()
                 n = flips = 0
                 worst = 0.0
-                for a, b in zip(outs, res):
+                for a, b in zip(outs0, res):
                     if a[2].shape == b[2].shape and a[2].numel():
                         worst = max(worst, float((a[2] - b[2]).abs().max()))
                     if np.array_equal(a[0].valid, b[0].valid) and pipe.cls_key in a[0].cls and pipe.cls_key in b[0].cls:
@@ -736,7 +772,7 @@ def main():
                 gc.collect()
                 torch.cuda.synchronize()
                 worst, n, flips = 0.0, 0, 0
-                for a, b in zip(outs, res):
+                for a, b in zip(outs0, res):
                     if a[2].shape == b[2].shape and a[2].numel():
                         worst = max(worst, float((a[2] - b[2]).abs().max()))
                     if np.array_equal(a[0].valid, b[0].valid) and pipe.cls_key in a[0].cls and pipe.cls_key in b[0].cls:
@@ -745,7 +781,7 @@ def main():
                         flips += int(sum(str(a[0].cls[pipe.cls_key]['name'][r]) != str(b[0].cls[pipe.cls_key]['name'][r]) for r in rows))
                 return {'value': round(n32 / dt, 3), 'unit': 'frames/s', 'steps': n32, 'dtype': 'f32',
                         'max_abs_probability_difference_to_the_metric_run': round(worst, 5), 'clusters_compared': n, 'class_names_that_differ': flips,
-                        'note': 'vit_dtype=f32: the whole tower in fp32 (k_gemm_f32, k_attention_f32, k_layernorm), everything before it is the same '
+                        'note': 'vit_dtype=f32: the whole tower in fp32 (k_gemm_f32_mfma = v_mfma_f32_32x32x2_f32 on the matrix cores, k_attention_f32, k_layernorm), everything before it is the same '
                                 'code as the metric\'s run; the first frames of the metric\'s stream'}
             block('f32_parity_mode', f32_parity_mode)
 

@@ -324,6 +324,7 @@ __global__ void k_cl_e_up(int n, int l, const unsigned int* __restrict__ code_s,
     cell_e[cl_pur_off_fwd(l) + key] = cl_pack_e(mn, mx);
 }
 
+#ifdef VG_DEV      // the per-point tree walk of rounds 1-2 (superseded by the cooperative kernels below in round 3): A/B aid, development build only
 template <int DIM>
 __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                  const ClGrid* __restrict__ gp, const int* __restrict__ cs,
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(256) void k_cl_core(const float4* __restrict__ spts
     core2[i] = h[k];
     if (dbg_scan) dbg_scan[i] = scanned;
 }
+#endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
 // Cooperative exact k-NN core distances (north_star: "LDS-staged radius-neighbour / HDBSCAN core-distance kernel over
@@ -1526,19 +1528,29 @@ static int cl_build_grid(vg_cluster* h, const float* d_points, int n, int stride
 
 template <int DIM>
 static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
-    static const int walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;   // 1: the per-point tree walk (A/B aid)
+#ifdef VG_DEV
+    static const int walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;   // 1: the per-point tree walk (A/B aid, development build)
+    const bool no_far = getenv("VG_CLUSTER_CORE_NOFAR") != nullptr;
+    const int far_level = getenv("VG_CLUSTER_FAR_LEVEL") ? atoi(getenv("VG_CLUSTER_FAR_LEVEL")) : 0;
+#else
+    constexpr int walk = 0, far_level = 0;
+    constexpr bool no_far = false;
+#endif
+#ifdef VG_DEV
     if (walk) {
         hipLaunchKernelGGL((k_cl_core<DIM>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_e, k, h->d_core2, h->d_dbg);
-    } else {
+    } else
+#endif
+    {
         // counters[2] = work-list entries of phase A (kept for the Boruvka rounds), counters[3] = queries left for phase B
         (void)hipMemsetAsync(h->d_counter + 2, 0, 8, st);
         hipLaunchKernelGGL(k_cl_blocks, dim3(vg_div_up(n, 256)), dim3(256), 0, st, n, h->d_code_s, h->d_cell_start, h->d_entries, h->d_counter);
         hipLaunchKernelGGL((k_cl_core_blk<DIM>), dim3(std::min(n, 16384)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
                            h->d_code_s, h->d_entries, h->d_counter, k, h->d_core2, h->d_far, h->d_dbg);
-        if (!getenv("VG_CLUSTER_CORE_NOFAR"))
-        hipLaunchKernelGGL((k_cl_core_far<DIM>), dim3(std::min(n, 8192)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
-                           h->d_far, h->d_counter, k, h->d_core2, h->d_dbg, getenv("VG_CLUSTER_FAR_LEVEL") ? atoi(getenv("VG_CLUSTER_FAR_LEVEL")) : 0);
+        if (!no_far)
+            hipLaunchKernelGGL((k_cl_core_far<DIM>), dim3(std::min(n, 8192)), dim3(64), 0, st, h->d_spts, h->d_st, n, h->d_grid, h->d_cell_start,
+                               h->d_far, h->d_counter, k, h->d_core2, h->d_dbg, far_level);
     }
     if (h->d_dbg) {
         // VG_CLUSTER_DEBUG=1: pairs evaluated / pairs needed: the exact answer needs n * k distances
@@ -1557,9 +1569,13 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
 }
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
-    // VG_CLUSTER_SEARCH_NT (A/B aid): threads per workgroup of the walk, 256 or 512 (default: see k_cl_b_search)
+#ifdef VG_DEV
+    // VG_CLUSTER_SEARCH_NT (A/B aid, development build): threads per workgroup of the walk, 256 or 512 (see k_cl_b_search)
     const char* nt_env = getenv("VG_CLUSTER_SEARCH_NT");          // (read per launch: the A/B tool switches it inside one process)
     const int nt = nt_env ? atoi(nt_env) : 512;
+#else
+    constexpr int nt = 512;
+#endif
 #ifdef VG_DEV
     // VG_CLUSTER_SEARCH_MODE (A/B aid, development build): 0 = the tree walk alone, 1 = cooperative search, leftovers walk as a compacted
     // list, 2 = cooperative search, leftovers walk in place.  Measured on 150k-point frames the cooperative search + the leftover walks

@@ -8,11 +8,13 @@
 //   dtype 1 (f16): GEMM operands and activations fp16, fp32 accumulate, fp32 LayerNorm -- what the
 //                  reference runs on a GPU (model.py:375-396 convert_weights) -- except that the
 //                  residual stream is kept in fp32 (strictly more accurate than the reference's fp16
-//                  stream).  GEMMs: v_mfma_f32_32x32x16_f16, 256x128x64 tiles, 8 waves, 3-stage LDS-DMA pipeline.
-//                  Attention: one workgroup per (crop, head), K and V^T resident in LDS, S^T = K Q^T
-//                  and O^T = V^T P^T both on MFMA with the softmax row living on one lane.
-//   dtype 0 (f32): parity mode against the fp32 CPU reference (tolerance 1e-3 on probabilities):
-//                  plain fp32 VALU kernels, no MFMA, same epilogues.
+//                  stream).  Projection GEMMs: k_gemm_f16_pp64 (v_mfma_f32_16x16x32_f16, 256 x 256 x 64 tiles, 8 waves as two
+//                  groups one barrier apart, LDS-DMA rings, LayerNorm folded into the epilogues); shapes with N % 256 != 0:
+//                  k_gemm_f16 (256 x 128 x 32).  Attention: persistent workgroups, item = (crop, head), K and V row-major in
+//                  LDS, S^T = K Q^T and O^T = V^T P^T both on MFMA with the softmax row living on one lane.
+//   dtype 0 (f32): parity mode against the fp32 CPU reference (tolerance 1e-3 on probabilities): the same tower in fp32 --
+//                  k_gemm_f32_mfma (v_mfma_f32_32x32x2_f32, 128 x 128 tiles; bit-identical to the vector-ALU k_gemm_f32 that
+//                  serves the other shapes), k_attention_f32, k_layernorm -- same epilogues.
 //
 // Layout (all row-major, K contiguous):
 //   tokens M = n_crops * T (T = 1 + (res/patch)^2), rows padded to a multiple of 256 (the padding rows of the
@@ -1265,6 +1267,14 @@ struct vg_vit {
     bool gemm_x2 = getenv("VG_GEMM_X2") ? atoi(getenv("VG_GEMM_X2")) != 0 : false;   // projection GEMMs by k_gemm_f16_x2 (two workgroups per CU)
 #endif
     bool cls_last = !(getenv("VG_VIT_CLS_LAST") && atoi(getenv("VG_VIT_CLS_LAST")) == 0);   // last block: class-token rows only (see vg_vit_encode)
+    // A/B switches every test exercises (tests/test_vit.py, test_gemm.py), read ONCE when the handle is made -- never per launch: getenv
+    // is not safe against a concurrent setenv, the worker threads launch concurrently, and a captured graph must replay what the plain
+    // launches of the same handle run.  The handle-less entry points (vg_gemm, vg_gemm_resid_splitk, vg_attention) build a
+    // temporary handle per call, i.e. read them per call on the caller's thread.
+    int splitk_max = getenv("VG_GEMM_SPLITK") ? atoi(getenv("VG_GEMM_SPLITK")) : 0;          // opt-in split-K tail of the residual GEMMs (splitk_plan)
+    bool att_tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);                    // attention: row-major V + transposing LDS reads
+    bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
+    int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1301,7 +1311,9 @@ static bool is_gemm_weight(const std::string& n) {
 // column tiles per L2 chunk: the largest divisor-friendly count whose weight rows (128*K fp16 each) fit ~2.4 MB
 static int gemm_chunk_tiles(int N, int K) {
     const int ntn = N / GBN;
-    if (getenv("VG_GEMM_NO_CHUNK")) return ntn;
+#ifdef VG_DEV
+    if (getenv("VG_GEMM_NO_CHUNK")) return ntn;        // tile-order sweep (development build)
+#endif
     const long tile_bytes = (long)GBN * K * 2;
     int cw_max = (int)(2400000L / tile_bytes);
     if (cw_max < 1) cw_max = 1;
@@ -2220,19 +2232,15 @@ __global__ __launch_bounds__(256) void k_splitk_resid(const float* __restrict__ 
 
 // how a residual GEMM of ntm x ntn tiles is divided: row tiles [0, r_main) in complete rounds, the rest K-split `parts` ways (0 = no split)
 struct SplitPlan { int r_main, parts; };
-static SplitPlan splitk_plan(int ntm, int ntn, int np, size_t scratch_bytes) {
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 8) n_cu = 256; }
-    // OPT-IN (VG_GEMM_SPLITK=n, read per launch: at most n parts per tile, 8 is the measured optimum; unset / 0 = never split).
+static SplitPlan splitk_plan(int ntm, int ntn, int np, size_t scratch_bytes, int max_parts, int n_cu) {
+    // OPT-IN (VG_GEMM_SPLITK=n, read when the handle is made: at most n parts per tile, 8 is the measured optimum; unset / 0 = never split).
     // Measured (tools/bench_gemm_splitk.py, N = 768, one launch at a time): K = 3072 (c_proj) 356 -> 305 us for 3-15 tail tiles, -12 % at 48,
     // -8 % at 72, -2 % at 126; K = 768 (out_proj: the fourth round costs 16 us, two more launches cost as much) -3 % at 6 tiles, +2 % at 30,
     // +9 % at 48: only long K loops are split.  Whole tower (tools/exp_tile_tail.py): one encode at a time 14.12 -> 13.73 ms at 333 crops,
     // 14.35 -> 13.94 at 338; TWO encodes in flight (what the pipeline runs) 12.94 -> 13.01 / 13.27 -> 13.29: the other encode's tiles
     // already fill the last round, and the partial tiles are 60 MB of extra traffic per launch; pipeline 65.5 vs 65.7 frames/s.  So the
     // split is for one-frame-at-a-time (latency) use and stays off in the throughput configuration.
-    const char* e = getenv("VG_GEMM_SPLITK");
-    const int max_parts = e ? atoi(e) : 0;                 // more parts = more partial-sum traffic than K-loop saved (256 KB per part and tile)
-    if (max_parts < 2) return {ntm, 0};
+    if (max_parts < 2 || n_cu < 8) return {ntm, 0};        // (more parts = more partial-sum traffic than K-loop saved: 256 KB per part and tile)
     if (np < 24) return {ntm, 0};
     const int total = ntm * ntn, full = total / n_cu;
     if (full < 1) return {ntm, 0};
@@ -2258,7 +2266,9 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
     VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
     int cwt = gemm_chunk_tiles_256(ntn);
-    if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep
+#ifdef VG_DEV
+    if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep (development build)
+#endif
     int grid = (M / 256) * ntn;
     if (PERSIST) {
         static int n_cu = 0;
@@ -2332,7 +2342,15 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
     if (ldc == 0) ldc = N;
     vg_vit* v = const_cast<vg_vit*>(cv);
     // f16 ViT shapes (N % 256 == 0, K >= 128) take the ping-pong kernel; k_gemm_f16 serves the remaining legal shapes.
-    const bool use_pp = v->dtype == 1 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 2 && !getenv("VG_GEMM_V4");
+    bool use_pp = v->dtype == 1 && N % 256 == 0 && K % 64 == 0 && K / 64 >= 2;
+#ifdef VG_DEV
+    if (getenv("VG_GEMM_V4")) use_pp = false;          // every shape through k_gemm_f16 (tools/dev/bench_gemm_v4.sh)
+#endif
+    if (!v->n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&v->n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
     const bool prof = v->prof_on && v->prof_n < VG_PROF_MAX;
     if (prof) (void)hipEventRecord(v->prof_ev[2 * v->prof_n], st);
     struct Closer {
@@ -2371,7 +2389,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                 if constexpr (EPI == EPI_BIAS_RESID && LN != 1) {
                     // residual GEMMs with scratch at hand: the row tiles beyond the last complete round of tiles run K-split
                     if (sk_scratch && M % 256 == 0) {
-                        const SplitPlan sp = splitk_plan(M / 256, N / 256, K / 64, sk_bytes);
+                        const SplitPlan sp = splitk_plan(M / 256, N / 256, K / 64, sk_bytes, v->splitk_max, v->n_cu);
                         if (sp.parts) {
                             const int rc = launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, sp.r_main * 256, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
                             if (rc) return rc;
@@ -2390,8 +2408,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                            resid, M, N, K, ldc, gemm_chunk_tiles(N, K));
     } else {
         if (M % 64 || N % 64 || K % 16) return VG_ERR_ARG;
-        const char* mf = getenv("VG_GEMM_F32_MFMA");           // A/B aid: 0 = the vector-ALU kernel for every shape
-        if (M % 128 == 0 && N % 128 == 0 && !(mf && atoi(mf) == 0)) {
+        if (M % 128 == 0 && N % 128 == 0 && v->f32_mfma) {      // (VG_GEMM_F32_MFMA=0: the vector-ALU kernel for every shape, bit-identical)
             hipLaunchKernelGGL((k_gemm_f32_mfma<EPI>), dim3((M / 128) * (N / 128)), dim3(256), 0, st, (const float*)X, (const float*)Wt, bias,
                                (float*)C, resid, M, N, K);
         } else {
@@ -2406,12 +2423,11 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
 
 template <bool TRACE>
 static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st,
-                            int q_tiles = 7) {
+                            int q_tiles = 7, bool tr = true) {
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
     // ViT-B/16: row-major V + transposing LDS reads (VG_ATT_TR=0: the transposed V image of rounds 1-2; same numbers, 1.6 % slower)
-    const char* tr_env = getenv("VG_ATT_TR");           // read per call: tests run both paths in one process and compare them bit for bit
-    const bool tr = !(tr_env && atoi(tr_env) == 0);
+    // (tr: vg_vit::att_tr of the calling handle; tests run both paths in one process and compare them bit for bit)
     if (T == 197 && !TRACE && tr) {
         const dim3 grid7(items < 256 ? items : 256);
         VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true>), AT_LDS_BYTES_TR);
@@ -2584,9 +2600,12 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     vg_vit* v = new vg_vit();
     v->width = width; v->layers = layers; v->heads = heads; v->patch = patch; v->res = resolution;
     v->out_dim = out_dim; v->dtype = dtype; v->T = T;
-    v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16") && !getenv("VG_GEMM_V4");
+    v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16");
     const char* fold = getenv("VG_VIT_LN_FOLD");
-    v->ln_fold = dtype == 1 && width % 256 == 0 && !v->resid_h && !getenv("VG_GEMM_V4") && !(fold && atoi(fold) == 0);
+    v->ln_fold = dtype == 1 && width % 256 == 0 && !v->resid_h && !(fold && atoi(fold) == 0);
+#ifdef VG_DEV
+    if (getenv("VG_GEMM_V4")) v->resid_h = v->ln_fold = false;      // (k_gemm_f16 has neither epilogue)
+#endif
 #ifdef VG_DEV
     // k_gemm_f16_x2 serves K % 256 == 0 and merges at most X2_LN_MAXP partial statistics per row: a tower uses it for all of its
     // projection GEMMs or for none (the two kernels keep the folded LayerNorm's partials at different granularity)
@@ -2662,6 +2681,20 @@ __global__ __launch_bounds__(256) void k_gather_cls(const f16* __restrict__ h, c
         hc[(size_t)c * W + i] = c < n_crops ? h[(size_t)c * T * W + i] : (f16)0.f;
         xc[(size_t)c * W + i] = c < n_crops ? x[(size_t)c * T * W + i] : 0.f;
     }
+}
+
+// The last block's QUERY projection needs the class-token rows only (round 5): their rows of the fp16 residual copy and of the folded
+// LayerNorm's partial statistics, compacted (rows n_crops .. Mc - 1 zeroed: statistics (0, 0) give rstd = 1 / sqrt(eps), finite) ...
+__global__ __launch_bounds__(256) void k_gather_cls_ln(const f16* __restrict__ x16, const LnPartial* __restrict__ st, f16* __restrict__ x16c,
+                                                       LnPartial* __restrict__ stc, int n_crops, int T, int W, int nst) {
+    const int c = blockIdx.x;
+    for (int i = threadIdx.x; i < W; i += 256) x16c[(size_t)c * W + i] = c < n_crops ? x16[(size_t)c * T * W + i] : (f16)0.f;
+    if ((int)threadIdx.x < nst) stc[(size_t)c * nst + threadIdx.x] = c < n_crops ? st[(size_t)c * T * nst + threadIdx.x] : LnPartial{0.f, 0.f};
+}
+// ... and the projected queries back into the class-token rows of the qkv buffer (columns [0, W)), where the attention reads them
+__global__ __launch_bounds__(256) void k_scatter_cls_q(const f16* __restrict__ qc, f16* __restrict__ qkv, int T, int W, int ld) {
+    const int c = blockIdx.x;
+    for (int i = threadIdx.x; i < W; i += 256) qkv[(size_t)c * T * ld + i] = qc[(size_t)c * W + i];
 }
 
 static int64_t pad128(int64_t m) { return (m + 255) / 256 * 256; }   // GEMM row tile (256)
@@ -2793,11 +2826,6 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         else
             hipLaunchKernelGGL((k_layernorm<float>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, (const float*)wp[0], (const float*)wp[1], (float*)h, (int)M, W, 1);
         VG_LAUNCH_CHECK();
-        if (fold && !(l == 0 && ln1_done))
-            rc = launch_gemm<EPI_BIAS, 1>(v, x16, fw1, f1c2, qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld, f1c1, lnst);
-        else
-            rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld);
-        if (rc) return rc;
         // The LAST block: only the class token's row of its output is ever read (ln_post(x[:, 0, :]) @ proj, model.py:235-238), and
         // after the attention every row is processed on its own (out_proj, ln_2, c_fc, QuickGELU, c_proj and the two residual adds).
         // So the block computes all keys and values, the class token's attention row, and then runs its three remaining GEMMs on
@@ -2807,9 +2835,35 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         const bool cls_fits = Mc_ * W * 16 + Mc_ * (W / 64) * 8 <= Mp * (3 * W + 256) * es;       // the compact buffers live in the qkv buffer
                                                                                                    // (statistics sized like vg_vit_workspace_bytes: W / 64 partials per row, k_gemm_f16_x2's count)
         const bool cls_only = v->cls_last && fold && !rh && l == L - 1 && L > 1 && cls_fits;
+        if (cls_only && W % 256 == 0) {
+            // ... and of in_proj's three thirds that block needs K and V for every row but Q for the class-token rows only (round 5: a
+            // third of the launch, 270 -> ~190 us per frame): in_proj's K / V rows (weight rows [W, 3W)) over all tokens, its Q rows over
+            // the compacted class-token rows (the MLP buffer is free here), the queries scattered back to where the attention reads
+            // them.  The other tokens' Q columns keep block L - 2's values: the attention's first query tile computes rows from them
+            // that nobody reads (a query row never meets another query row).  Same kernel, same K loop per row: the same bits.
+            const int nst = W >> 8;
+            char* cb = (char*)mlp;
+            f16* x16q = (f16*)cb;              cb += Mc_ * W * 2;
+            f16* qc = (f16*)cb;                cb += Mc_ * W * 2;
+            LnPartial* lnq = (LnPartial*)cb;
+            rc = launch_gemm<EPI_BIAS, 1>(v, x16, (const f16*)fw1 + (size_t)W * W, f1c2 + W, (f16*)qkv + W, nullptr, (int)Mp, 2 * W, W, st, qkv_ld,
+                                          f1c1 + W, lnst);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_gather_cls_ln, dim3((unsigned)Mc_), dim3(256), 0, st, (const f16*)x16, (const LnPartial*)lnst, x16q, lnq, n_crops, T, W, nst);
+            VG_LAUNCH_CHECK();
+            rc = launch_gemm<EPI_BIAS, 1>(v, x16q, fw1, f1c2, qc, nullptr, (int)Mc_, W, W, st, 0, f1c1, lnq);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_scatter_cls_q, dim3((unsigned)n_crops), dim3(256), 0, st, (const f16*)qc, (f16*)qkv, T, W, qkv_ld);
+            VG_LAUNCH_CHECK();
+        } else
+        if (fold && !(l == 0 && ln1_done))
+            rc = launch_gemm<EPI_BIAS, 1>(v, x16, fw1, f1c2, qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld, f1c1, lnst);
+        else
+            rc = launch_gemm<EPI_BIAS>(v, h, wp[2], (const float*)wp[3], qkv, nullptr, (int)Mp, 3 * W, W, st, qkv_ld);
+        if (rc) return rc;
         if (v->dtype == 1) {
             {
-                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st, cls_only ? 1 : 7);
+                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st, cls_only ? 1 : 7, v->att_tr);
                 if (rc) return rc;
             }
         } else {
@@ -2881,7 +2935,9 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
  * nn.MultiheadAttention); exposed so that the kernel can be unit-tested against a plain fp32 attention. */
 int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, void* stream) {
     if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
-    return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, n_crops * heads, nullptr, (hipStream_t)stream);
+    const char* tr_env = getenv("VG_ATT_TR");           // handle-less test entry point: read per call, on the caller's thread
+    return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, n_crops * heads, nullptr, (hipStream_t)stream, 7,
+                                   !(tr_env && atoi(tr_env) == 0));
 }
 
 #ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces

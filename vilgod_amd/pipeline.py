@@ -211,7 +211,8 @@ class PseudoLabelPipeline:
         # crops.  Started together, the n_workers clustering stages slow each other down and the first GEMM -- the work everything
         # else hides behind -- begins after ~25 ms instead of ~10; a ViT pass (~15 ms) is longer than a lone front stage, so the chain
         # never starves the encoder.  Frames after the first round are not gated.
-        ramp = os.environ.get('VILGOD_FILL_RAMP', '1') != '0' and n_workers > 1
+        ramp_depth = int(os.environ.get('VILGOD_FILL_RAMP', '1'))          # front stages of a block's first round that may run at a time (0: all)
+        ramp = ramp_depth > 0 and n_workers > 1
         front_done = [threading.Event() for _ in range(min(n_workers, len(own_idx)))]
 
         frame_log = [] if os.environ.get('VILGOD_FRAME_LOG') else None      # development aid: per-frame host timeline of the block
@@ -228,8 +229,8 @@ class PseudoLabelPipeline:
                 if gate is not None:
                     gate.set()
             try:
-                if gate is not None and k_ > 0:
-                    front_done[k_ - 1].wait()
+                if gate is not None and k_ >= ramp_depth:
+                    front_done[k_ - ramp_depth].wait()
                 t_go = time.perf_counter()
                 with torch.cuda.stream(worker.stream):
                     worker.stream.wait_event(ev)
@@ -719,7 +720,6 @@ class PseudoLabelPipeline:
             before_classify()                    # the frame's clustering / filtering is done, its crops are about to be queued
         self._mark('valid_lists')
         probs_d, top1, score = self.classify(d_X, d_vindex, d_vseg, fs.transform_to_ego)
-        self._mark('encode+scores')
         box_fut = None
         if self.box_mode == 'reference':
             # host part of the reference-exact box fit (vilgod_amd/boxes.py) in a helper process.  The boxes do not depend on the classes;
@@ -728,7 +728,7 @@ class PseudoLabelPipeline:
             # request used to sit in front of the render, on the frame's critical path)
             xy_ev.synchronize()
             box_fut = self.fit_boxes_async(d_X, v_index, v_seg, d_vindex, d_vseg, xy_host=xy_host, zmin=st[vrows, 1], zmax=st[vrows, 2])
-            self._mark('box_request')
+        self._mark('encode+scores')              # (incl. the box request sent while the GPU encodes)
         if box_fut is None:
             box = self.fit_boxes(d_X, v_index, v_seg, d_vindex, d_vseg)
         top1 = top1.cpu().numpy()
