@@ -82,6 +82,8 @@ struct vg_cluster {
     int* h_counter;                       // pinned
     int* d_dbg;                           // VG_CLUSTER_DEBUG=1: points scanned per thread in the last search round
     unsigned int* d_entries;
+    int* d_csize;                          // points per component, kept at the component's root (sorted index space)
+    unsigned long long* d_giant;           // this round's largest component: size << 32 | root (0 until the first round's kernels ran)
     int *d_far, *d_far_flag;  // cooperative kernels: (node, 64-query) work list of the frame; queries handed on to the next phase
 };
 
@@ -741,10 +743,11 @@ __global__ __launch_bounds__(64) void k_cl_core_far(const float4* __restrict__ s
 
 __global__ void k_cl_b_init(int n, int* __restrict__ comp, int* __restrict__ counter, int* __restrict__ pt_b,
                             double* __restrict__ pt_lb, const double* __restrict__ core2, const float* __restrict__ stt,
-                            int4* __restrict__ aux) {
+                            int4* __restrict__ aux, int* __restrict__ csize, unsigned long long* __restrict__ giant) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *giant = 0ull;
     if (i < n) {
-        comp[i] = i; pt_b[i] = -1; pt_lb[i] = 0.0;
+        comp[i] = i; pt_b[i] = -1; pt_lb[i] = 0.0; csize[i] = 1;
         const long long cb = __double_as_longlong(core2[i]);
         aux[i] = make_int4((int)(cb & 0xFFFFFFFFll), (int)(cb >> 32), i, stt ? __float_as_int(stt[i]) : 0);
     }
@@ -768,17 +771,45 @@ __global__ void k_cl_b_seed(int n, const int* __restrict__ comp, int* __restrict
     else atomicMin(&best_w[c], pt_w[a]);
 }
 
+// THE LARGEST COMPONENT DOES NOT SEARCH (round 5).  Boruvka needs, per round, the minimum edge leaving a component only from the components
+// that are going to merge along it; any subset of the components may sit a round out -- every edge the others pick is still the minimum
+// edge leaving its component, hence an edge of the (unique, strict order) MST, and as long as one other component exists the round makes
+// progress.  The component that sits out is the largest one (if it holds at least n / 8 points): in the late rounds it owns most of the
+// frame's points, its nearest foreign structure is metres away, and its boundary points were the longest walks of the launch -- while the
+// edge that joins it to a neighbour is found from the neighbour's side anyway.  Sizes live at the roots (k_cl_b_init: 1; k_cl_b_compress adds
+// an absorbed root's size to its new root); the maximum over the roots is taken here, one atomic per workgroup.
 __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned long long* __restrict__ best_w,
                                   unsigned long long* __restrict__ best_d, unsigned long long* __restrict__ best_e,
-                                  int* __restrict__ sel_a, const int* __restrict__ flags) {
+                                  int* __restrict__ sel_a, const int* __restrict__ flags, const int* __restrict__ csize,
+                                  unsigned long long* __restrict__ giant) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
+    __shared__ unsigned long long blk_max[4];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) const_cast<int*>(flags)[4] = 0;   // queries the cooperative search hands on to the walk this round
-    if (i >= n) return;
-    best_w[i] = CL_NONE;
-    best_d[i] = ~0ull;
-    best_e[i] = ~0ull;
-    sel_a[i] = -1;
+    unsigned long long mine = 0ull;
+    if (i < n) {
+        best_w[i] = CL_NONE;
+        best_d[i] = ~0ull;
+        best_e[i] = ~0ull;
+        sel_a[i] = -1;
+        if (comp[i] == i) mine = ((unsigned long long)(unsigned int)csize[i] << 32) | (unsigned int)i;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mine, o);
+        mine = other > mine ? other : mine;
+    }
+    if ((threadIdx.x & 63) == 0) blk_max[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = blk_max[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = blk_max[w] > m ? blk_max[w] : m;
+        if (m) atomicMax(giant, m);
+    }
+}
+// does component c sit this round out?
+__device__ __forceinline__ bool cl_sits_out(unsigned long long giant, int c, int min_size) {
+    return (int)(giant >> 32) >= min_size && (int)(giant & 0xFFFFFFFFull) == c;
 }
 
 __device__ __forceinline__ size_t cl_pur_off(int l) {   // offset of level l inside the purity tables
@@ -848,7 +879,8 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                                                      unsigned long long* __restrict__ pt_d,
                                                      unsigned long long* __restrict__ pt_key, int* __restrict__ pt_b,
                                                      double* __restrict__ pt_lb, int* __restrict__ dbg_scan, const int* __restrict__ flags,
-                                                     const int* __restrict__ far_list, const int* __restrict__ far_flag) {
+                                                     const int* __restrict__ far_list, const int* __restrict__ far_flag,
+                                                     const unsigned long long* __restrict__ giant, int sit_min) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     __shared__ unsigned int stack[CL_STACK * NT];
     // far_list != NULL: only the queries the cooperative search (k_cl_b_search_blk) could not finish inside its shell, each
@@ -875,6 +907,10 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
     const double qx = qf.x, qy = qf.y, qz = qf.z, qe = qf.w, qt = qtf;
     if (!far_list && pt_b[a] >= 0) return;           // candidate of an earlier round still valid (k_cl_b_seed)
     const int ca = comp[a];
+    if (cl_sits_out(*giant, ca, sit_min)) {          // the largest component does not search this round (k_cl_b_round_init)
+        pt_w[a] = CL_NONE; pt_d[a] = ~0ull; pt_key[a] = ~0ull; pt_b[a] = -1;
+        return;
+    }
     const double core_a = core2[a];
     // Every edge that leaves a's component from a weighs at least lb_a: its mutual-reachability weight is >= core_a, and
     // >= the bound carried over from earlier rounds (a's own minimum foreign edge then, or the winning weight of its
@@ -1258,11 +1294,15 @@ __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned 
                             const unsigned long long* __restrict__ best_d, const unsigned long long* __restrict__ best_e,
                             const unsigned long long* __restrict__ pt_w, const unsigned long long* __restrict__ pt_d,
                             const unsigned long long* __restrict__ pt_key, const int* __restrict__ pt_b,
-                            int* __restrict__ sel_a, int* __restrict__ sel_b, const int* __restrict__ flags) {
+                            int* __restrict__ sel_a, int* __restrict__ sel_b, const int* __restrict__ flags,
+                            const unsigned long long* __restrict__ giant, int sit_min) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
     const int c = comp[a];
+    // (the component that sits out picks nothing: some of its points still hold candidates of earlier rounds, valid edges but not
+    // necessarily the component's minimum since the others did not search)
+    if (cl_sits_out(*giant, c, sit_min)) return;
     if (pt_w[a] != CL_NONE && pt_w[a] == best_w[c] && pt_d[a] == best_d[c] && pt_key[a] == best_e[c]) {
         sel_a[c] = a;
         sel_b[c] = pt_b[a];
@@ -1300,16 +1340,35 @@ __global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __re
     mst_w[k] = best_w[c];
 }
 
-__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2, int* __restrict__ flags, int4* __restrict__ aux) {
+__global__ void k_cl_b_compress(int n, int* __restrict__ comp, const int* __restrict__ parent2, int* __restrict__ flags, int4* __restrict__ aux,
+                                int* __restrict__ csize, unsigned long long* __restrict__ giant) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) flags[1] = flags[0] >= n - 1;    // read by every kernel of the NEXT round (stream order): rounds are queued in
                                                 // batches without a host read in between, a round after the last one is a no-op
+    if (i == 0) *giant = 0ull;                   // the next round's k_cl_b_round_init takes the maximum again
     if (i >= n) return;
-    int r = comp[i];
+    const int old = comp[i];
+    int r = old;
     while (parent2[r] != r) r = parent2[r];
+    // an absorbed root hands its point count to the new root (only new roots are written, and a new root never reads its own count here)
+    if (old == i && r != i) atomicAdd(&csize[r], csize[i]);
     comp[i] = r;
     aux[i].z = r;
 }
+
+#ifdef VG_DEV
+// Experiment (round 5, VG_CLUSTER_SEEDSIM=1): what would round 1 of the Boruvka search cost if every point whose best edge weighs exactly its
+// own core distance -- the points a pass over the k-NN shell could seed without a walk -- were answered beforehand?  After round 1's search
+// the candidates of all OTHER points are dropped and the search is launched again: that second launch walks only the points a seed could
+// not serve (same results; its duration in the kernel trace is the residual walk).
+__global__ void k_cl_seedsim_drop(int n, const double* __restrict__ core2, const unsigned long long* __restrict__ pt_w, int* __restrict__ pt_b,
+                                  int* __restrict__ counter) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    const bool seedable = pt_b[a] >= 0 && pt_w[a] == (unsigned long long)__double_as_longlong(core2[a]);
+    if (!seedable) { pt_b[a] = -1; atomicAdd(&counter[5], 1); }
+}
+#endif
 
 __global__ void k_cl_iota(int n, int* p) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1463,6 +1522,8 @@ int vg_cluster_create(vg_cluster** out, int max_points) {
     VG_CHECK(hipMalloc(&h->d_best_d, 8 * n));
     VG_CHECK(hipMalloc(&h->d_pt_b, 4 * n));
     VG_CHECK(hipMalloc(&h->d_counter, 64));
+    VG_CHECK(hipMalloc(&h->d_csize, 4 * n));
+    VG_CHECK(hipMalloc(&h->d_giant, 8));
     VG_CHECK(hipMalloc(&h->d_entries, 4 * n));
     VG_CHECK(hipMalloc(&h->d_far, 4 * n));
     VG_CHECK(hipMalloc(&h->d_far_flag, 4 * n));
@@ -1491,7 +1552,7 @@ void vg_cluster_destroy(vg_cluster* h) {
     void* ptrs[] = {h->d_grid, h->d_code, h->d_code_s, h->d_perm_in, h->d_perm, h->d_spts, h->d_st, h->d_cell_start, h->d_cell_comp, h->d_cell_e,
                     h->d_core2, h->d_comp, h->d_parent, h->d_parent2, h->d_best_w, h->d_best_e, h->d_sel_a, h->d_sel_b,
                     h->d_pt_w, h->d_pt_key, h->d_pt_d, h->d_pt_lb, h->d_best_d, h->d_pt_b, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, h->d_mst_w_s,
-                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp, h->d_entries, h->d_far, h->d_far_flag, h->d_aux};
+                    h->d_mst_idx, h->d_mst_idx_s, h->d_temp, h->d_entries, h->d_far, h->d_far_flag, h->d_aux, h->d_csize, h->d_giant};
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(h->h_counter);
     delete h;
@@ -1567,6 +1628,14 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
                 n, k, tot, (double)tot / ((double)n * k), (long long)n * k, sc[n / 2], sc[(size_t)n * 99 / 100], sc[n - 1], walk ? 0 : cnt[2], walk ? 0 : cnt[3]);
     }
 }
+// smallest size at which the largest component sits a round out (k_cl_b_round_init): an eighth of the points
+static int cl_sit_min(int n) {
+#ifdef VG_DEV
+    static const int off = getenv("VG_CLUSTER_SITOUT") && atoi(getenv("VG_CLUSTER_SITOUT")) == 0;      // A/B aid (development build)
+    if (off) return 0x7FFFFFFF;
+#endif
+    return std::max(2, n / 8);
+}
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
 #ifdef VG_DEV
@@ -1590,18 +1659,18 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
         hipLaunchKernelGGL((k_cl_b_search<DIM, 256, true>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
-                           mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr);
+                           mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr, h->d_giant, cl_sit_min(n));
         return;
     }
 #endif
     if (nt == 512)
         hipLaunchKernelGGL((k_cl_b_search<DIM, 512>), dim3(vg_div_up(n, 512)), dim3(512), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, cl_sit_min(n));
     else
         hipLaunchKernelGGL((k_cl_b_search<DIM, 256>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr);
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, cl_sit_min(n));
 }
 
 extern "C" {
@@ -1684,7 +1753,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
     VG_LAUNCH_CHECK();
     // ---- Boruvka ----
     hipLaunchKernelGGL(k_cl_b_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_counter, h->d_pt_b, h->d_pt_lb, h->d_core2,
-                       dim >= 5 ? h->d_st : (const float*)nullptr, h->d_aux);
+                       dim >= 5 ? h->d_st : (const float*)nullptr, h->d_aux, h->d_csize, h->d_giant);
     // Rounds are queued in batches WITHOUT a host read in between: every round's kernels start with `if (flags[1]) return`,
     // and k_cl_b_compress sets flags[1] once the n - 1 edges are out, so a round queued after the last needed one costs a
     // dozen empty launches.  The edge count of every round is copied to its own pinned slot; the host reads them once per batch
@@ -1692,7 +1761,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
     int rounds = 0, edges = 0, needed = 0;
     int* const flags = h->d_counter;
     auto one_round = [&](int r) {
-        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags);
+        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant);
         if (r > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);
         for (int l = 1; l < CL_PUR_LEVELS; ++l)
@@ -1700,15 +1769,30 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         if (dim == 3) cl_launch_search<3>(h, n, st);
         else if (dim == 4) cl_launch_search<4>(h, n, st);
         else cl_launch_search<5>(h, n, st);
+#ifdef VG_DEV
+        if (r == 1 && getenv("VG_CLUSTER_SEEDSIM")) {
+            (void)hipMemsetAsync(h->d_counter + 5, 0, 4, st);
+            hipLaunchKernelGGL(k_cl_seedsim_drop, dim3(nb), dim3(256), 0, st, n, h->d_core2, h->d_pt_w, h->d_pt_b, h->d_counter);
+            hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant);
+            hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
+            if (dim == 3) cl_launch_search<3>(h, n, st);          // walks only the points that were not seedable
+            else if (dim == 4) cl_launch_search<4>(h, n, st);
+            else cl_launch_search<5>(h, n, st);
+            int left = 0;
+            (void)hipMemcpyAsync(&left, h->d_counter + 5, 4, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[cluster seedsim] round 1: %d of %d points have no edge at their own core distance (the second k_cl_b_search launch walks only these)\n", left, n);
+        }
+#endif
         hipLaunchKernelGGL(k_cl_b_select_d, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_pt_w, h->d_pt_d, h->d_best_d, flags);
         hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_best_e, flags);
         hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_pt_w,
-                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b, flags);
+                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b, flags, h->d_giant, cl_sit_min(n));
         hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent, flags);
         hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent, h->d_sel_a, h->d_sel_b, h->d_best_w,
                            h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, flags);
-        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags, h->d_aux);
+        hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags, h->d_aux, h->d_csize, h->d_giant);
         return hipMemcpyAsync(h->h_counter + ((r - 1) & 15), h->d_counter, 4, hipMemcpyDeviceToHost, st);
     };
     while (edges < n - 1) {
