@@ -177,20 +177,23 @@ def test_hip_attention_transposing_reads_equal_transposed_image(cuda, monkeypatc
     """T = 197: the default kernel (row-major V in LDS, V^T fragments by ds_read_b64_tr_b16) and the rounds-1-2 kernel (V written
     transposed, VG_ATT_TR=0; the switch is read per call) run the same MFMAs on the same operands: outputs bit-identical."""
     from vilgod_amd._lib import lib, ptr, stream_ptr, check
-    W, H, T, n_crops = 768, 12, 197, 9
+    W, H, T, n_crops = 768, 12, 197, 30
     ld = 3 * W + 64
     g = torch.Generator().manual_seed(5)
     qkv = torch.zeros(n_crops * T, ld, dtype=torch.float16)
     qkv[:, :3 * W] = (torch.randn(n_crops * T, 3 * W, generator=g) * torch.tensor([1.5] * W + [1.0] * W + [2.0] * W)).half()
     d_qkv = qkv.to(cuda)
     outs = []
-    for tr in ('1', '0'):
+    # (VG_ATT_STAGGER: the SIMD partners issue the next item's loads half a phase apart, k_attention_f16 STAG -- the same instructions
+    # per wave, so the same bits; 30 crops = 360 items on 256 persistent workgroups, so the prefetch paths run)
+    for tr, stag in (('1', '1'), ('1', '0'), ('0', '0')):
         monkeypatch.setenv('VG_ATT_TR', tr)
+        monkeypatch.setenv('VG_ATT_STAGGER', stag)
         out = torch.zeros(n_crops * T, W, dtype=torch.float16, device=cuda)
         check(lib.vg_attention(ptr(d_qkv), ptr(out), n_crops, T, W, H, ld, stream_ptr()))
         torch.cuda.synchronize()
         outs.append(out)
-    assert outs[0].abs().max().item() > 0 and torch.equal(outs[0], outs[1])
+    assert outs[0].abs().max().item() > 0 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.gpu

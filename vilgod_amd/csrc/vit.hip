@@ -868,7 +868,12 @@ typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 // TR: V stays ROW-major in LDS (one 16-byte write per chunk, like K) and the O^T MFMAs' A operand -- V^T[d][8 consecutive keys] -- comes
 // from gfx950's transposing read: per group of 16 lanes ds_read_b64_tr_b16 takes a 4-key x 16-feature block (lane 4q + p of the group
 // supplies the address of key q, features 4p .. 4p + 3) and hands lane i feature i of the four keys.
-template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false>
+// STAG (round 5; MI355X_MICROARCH.md "two waves per SIMD", item 9): the two waves that share a SIMD (w and w + 4) run the same program and
+// leave the staging barrier together, so they want the matrix pipe at the same time (S^T MFMAs), then the vector ALU at the same time
+// (softmax), then the matrix pipe again.  With STAG waves 0-3 issue the NEXT item's twelve loads after their S^T MFMAs (which run on
+// while the loads are issued) and waves 4-6 before theirs, as all waves did: the partners reach the softmax ~1-2 k cycles apart, one's
+// vector work beside the other's matrix work.  Same instructions per wave on the same data: bit-identical output.
+template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false, bool STAG = false>
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
                                                        int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr,
                                                        int q_tiles = 7) {
@@ -957,9 +962,12 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(Qs + r31 * AT_KLD + s * 16 + hh * 8);
     __syncthreads();
     AT_STAMP(0)                                                        // K / V^T into LDS + barrier
-    if (item + (int)gridDim.x < n_items) fetch(item + gridDim.x);      // in flight during the compute below
+    const bool has_next = item + (int)gridDim.x < n_items;
+    const bool computes = q0 < T && wave < q_tiles;   // (q_tiles: query tiles wanted -- 1 in the last block, whose class-token row alone is used)
+    const bool late = STAG && wave < 4 && computes;   // this wave issues the next item's loads behind its S^T MFMAs
+    if (has_next && !late) fetch(item + gridDim.x);                    // in flight during the compute below
     AT_STAMP(1)                                                        // issue of the next item's loads
-    if (q0 < T && wave < q_tiles) {         // (q_tiles: query tiles wanted -- 1 in the last block, whose class-token row alone is used)
+    if (computes) {
 
 
     f32x16 sacc[7];
@@ -975,6 +983,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
             }
         }
     }
+    if (STAG && has_next && late) fetch(item + gridDim.x);             // (the matrix pipe works on the 28 MFMAs meanwhile)
     AT_STAMP(2)                                                        // S^T MFMAs issued
     // softmax over keys (scores scaled by 1/8 = dh^-0.5, model.py via nn.MultiheadAttention).  Only the last key block
     // can hold keys >= T; blocks beyond it were never computed (zeros) and are skipped below.
@@ -1273,6 +1282,7 @@ struct vg_vit {
     // temporary handle per call, i.e. read them per call on the caller's thread.
     int splitk_max = getenv("VG_GEMM_SPLITK") ? atoi(getenv("VG_GEMM_SPLITK")) : 0;          // opt-in split-K tail of the residual GEMMs (splitk_plan)
     bool att_tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);                    // attention: row-major V + transposing LDS reads
+    bool att_stagger = !(getenv("VG_ATT_STAGGER") && atoi(getenv("VG_ATT_STAGGER")) == 0);     // attention: SIMD partners half a phase apart (k_attention_f16 STAG)
     bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
     int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
@@ -2423,11 +2433,18 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
 
 template <bool TRACE>
 static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st,
-                            int q_tiles = 7, bool tr = true) {
+                            int q_tiles = 7, bool tr = true, bool stagger = true) {
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
     // ViT-B/16: row-major V + transposing LDS reads (VG_ATT_TR=0: the transposed V image of rounds 1-2; same numbers, 1.6 % slower)
     // (tr: vg_vit::att_tr of the calling handle; tests run both paths in one process and compare them bit for bit)
+    if (T == 197 && !TRACE && tr && stagger) {
+        const dim3 grid7(items < 256 ? items : 256);
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, true>), AT_LDS_BYTES_TR);
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, true>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
+        VG_LAUNCH_CHECK();
+        return VG_OK;
+    }
     if (T == 197 && !TRACE && tr) {
         const dim3 grid7(items < 256 ? items : 256);
         VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true>), AT_LDS_BYTES_TR);
@@ -2863,7 +2880,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         if (rc) return rc;
         if (v->dtype == 1) {
             {
-                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st, cls_only ? 1 : 7, v->att_tr);
+                rc = launch_attention<false>((const f16*)qkv, (f16*)h, T, W, H, qkv_ld, n_crops * H, nullptr, st, cls_only ? 1 : 7, v->att_tr, v->att_stagger);
                 if (rc) return rc;
             }
         } else {
@@ -2936,8 +2953,9 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
 int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, void* stream) {
     if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
     const char* tr_env = getenv("VG_ATT_TR");           // handle-less test entry point: read per call, on the caller's thread
+    const char* sg_env = getenv("VG_ATT_STAGGER");
     return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, n_crops * heads, nullptr, (hipStream_t)stream, 7,
-                                   !(tr_env && atoi(tr_env) == 0));
+                                   !(tr_env && atoi(tr_env) == 0), !(sg_env && atoi(sg_env) == 0));
 }
 
 #ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces

@@ -364,7 +364,7 @@ def _entry_set(tab, t, i, field, value):
 
 
 def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=None, static_box_of=None, median_of=None,
-                    moving_async=None):
+                    moving_async=None, max_pending=8):
     """The track branch of fit_bounding_boxes_simple for every valid track, in track order: boxes and `static_track` flags of
     the entries (into `tab` for real detections, into the track for its clones) and `track.static`.
     points_of(key) -> cluster points [n,>=3]; static_of(key) -> Detection.static (the entropy flag); to_ego_of(fnr) -> 4x4;
@@ -372,10 +372,19 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=Non
     moving_async(points_list, directions, to_ego_list, centers3) -> object with .result(): the moving tracks' boxes computed
     elsewhere (helper processes, boxes.submit_moving_boxes) while this thread goes on with the next track.  What a track needs is
     decided first for all tracks (nothing of it reads `tab`); the entries are then written in track order, as before -- one detection
-    can sit in two tracks (far-match rule), and the later track's values must win."""
+    can sit in two tracks (far-match rule), and the later track's values must win.  At most `max_pending` moving_async requests are
+    outstanding (each holds its track's packed points until it is answered), and every request is answered BEFORE the first entry is
+    written: a helper that fails leaves `tab` and the tracks untouched."""
     sbox = (lambda k, p: np.array(static_box_of(k), dtype=np.float64)) if static_box_of is not None else (lambda k, p: static_box(p, rectangle))
     need_pts = static_box_of is None                     # the finished static boxes make the points of static tracks unnecessary
     plan = []
+    pending = []                                         # positions in `plan` whose boxes are still being computed elsewhere
+
+    def settle(keep):
+        while len(pending) > keep:
+            j = pending.pop(0)
+            t_, _, kind_, res_ = plan[j]
+            plan[j] = (t_, None, kind_, res_.result())
     for t in tracker.tracks_valid:
         n = len(t)
         pts = [points_of(k) for k in t.source] if need_pts else [None] * n
@@ -398,11 +407,14 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=Non
             c3 = [m[:3] for m in med] if med is not None else None
             egos = [to_ego_of(f) for f in t.frames]
             if moving_async is not None:
+                settle(max(int(max_pending), 1) - 1)
                 plan.append((t, None, 'moving', moving_async(pts, dirs, egos, c3)))
+                pending.append(len(plan) - 1)
             else:
                 plan.append((t, None, 'moving', moving_boxes(pts, dirs, egos, centers3=c3)))
         else:
             plan.append((t, pts, 'still', None))
+    settle(0)
     for t, pts, kind, res in plan:
         n = len(t)
         t.clone_box = [None] * n
@@ -412,7 +424,7 @@ def fit_track_boxes(tracker, tab, points_of, static_of, to_ego_of, rectangle=Non
             for i in range(n):
                 _entry_set(tab, t, i, 'box', sbox(t.source[i], pts[i]))
         elif kind == 'moving':
-            boxes = res.result() if hasattr(res, 'result') else res
+            boxes = res
             for i in range(n):
                 _entry_set(tab, t, i, 'box', boxes[i])
                 _entry_set(tab, t, i, 'static_track', False)

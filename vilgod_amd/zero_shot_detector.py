@@ -938,7 +938,8 @@ class ZeroShotDetector:
             fit_track_boxes(self.tracker, tab, self._cluster_points_host, lambda k: bool(self.lidar_frame_list[k[0]].static[k[1]]),
                             lambda f: self.lidar_frame_list[f].transform_to_ego, static_box_of=gpu_box.__getitem__,
                             median_of=(med.__getitem__ if med else None),
-                            moving_async=(lambda p, d, e, c: _boxes.submit_moving_boxes(p, d, e, c, n_procs=nproc)) if nproc > 0 else None)
+                            moving_async=(lambda p, d, e, c: _boxes.submit_moving_boxes(p, d, e, c, n_procs=nproc)) if nproc > 0 else None,
+                            max_pending=2 * max(nproc, 1))
             self._host_X3 = {}
         self._tab = tab
         with self._part('boxes.write_back'):
