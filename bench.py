@@ -480,11 +480,12 @@ def main():
         frames_total = world * K
         value = frames_total / elapsed
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = traffic_src = None
+        traffic = traffic_src = by_kind = pmc_mfma = None
         tpath = os.path.join(ROOT, 'profiles', 'gemm_traffic.json')       # tools/collect_profiles.sh + summarize_profiles.py
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic = round(tj['hbm_bytes_per_launch'])
+            by_kind, pmc_mfma = tj.get('by_kind') or None, tj.get('mfma_utilisation')
             traffic_src = f"profiles/gemm_traffic.json ({tj.get('kernel', '?')}, {tj.get('tag', '?')}): rocprofv3 PMC passes of this command, not measured in this run"
         out = {
             'metric': 'pseudo-labeled LiDAR frames/sec (150k pts, ~60 clusters)',
@@ -530,6 +531,8 @@ def main():
                 'algorithmic_flops_per_launch': round(gemm_flops / max(launches, 1)),
                 'gemm_ms_per_frame': round(gemm_ms / max(n_pass, 1), 3),
                 'tower_two_in_flight': tower2,
+                'mfma_utilisation_pmc': pmc_mfma,
+                'by_kind_pmc': by_kind,      # per GEMM kind of the full-size blocks: time, FETCH / WRITE against algorithmic bytes, MFMA busy (the same PMC passes as `traffic`)
                 'all_projection_gemms': {'launches': all_launches,
                                          'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
                                          'ms_per_frame': round(all_ms / max(n_pass, 1), 3)},

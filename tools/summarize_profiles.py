@@ -198,5 +198,7 @@ stages = {
 }
 json.dump(stages, open(os.path.join(dst, 'stage_roofline.json'), 'w'), indent=1)
 json.dump(out, open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
-json.dump(dict(out['k_gemm_f16_pp64'], kernel='k_gemm_f16_pp64', tag=tag), open(os.path.join(dst, 'gemm_traffic.json'), 'w'), indent=1)
+json.dump(dict(out['k_gemm_f16_pp64'], kernel='k_gemm_f16_pp64', tag=tag, by_kind=out.get('k_gemm_f16_pp64_by_kind', {}),
+               mfma_utilisation=out.get('k_gemm_f16_pp64_sq', {}).get('mfma_utilisation')),
+          open(os.path.join(dst, 'gemm_traffic.json'), 'w'), indent=1)
 print(json.dumps({'k_gemm_f16_pp64': out['k_gemm_f16_pp64'], 'k_gemm_f16': out['k_gemm_f16']}, indent=1))

@@ -55,6 +55,8 @@ def build(force=False, verbose=True, dev=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    if dev and os.path.isdir(os.path.join(CSRC, 'dev')):           # the development build's kernels (included by vit.hip under VG_DEV)
+        headers += [os.path.join(CSRC, 'dev', f) for f in os.listdir(os.path.join(CSRC, 'dev')) if f.endswith('.inc')]
     headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
     headers.append(os.path.abspath(__file__))
     jobs = []

@@ -213,288 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_f16(const f16* __restrict__ X, 
 }
 
 #ifdef VG_DEV      // superseded K-step-32 ping-pong kernel: kept for the cycle-stamp tools (tools/dev), not in the product library
-// ---------------------------------------------------------------------------------------------
-// Ping-pong GEMM: 256 x 256 x 32 tiles, 8 waves = two groups of four (group = 128-row half of the tile, one wave of each
-// group per SIMD), each wave 128 (m) x 64 (n).  A PHASE is one k16 sub-step of one wave: LOAD segment (6 ds_read_b128 for
-// this sub-step's fragments + 2 LDS-DMA pieces of a tile several K-steps ahead), s_barrier, MFMA segment (8
-// v_mfma_f32_32x32x16_f16 under s_setprio 1), s_barrier.  Group 1 runs ONE BARRIER behind group 0, so on every SIMD one
-// wave's MFMA segment overlaps the other wave's LOAD segment: an LDS-DMA piece costs its issuing wave 60-185 cycles
-// (MI355X_MICROARCH.md, cycle constants), which a lock-step schedule pays with an idle MFMA pipe.
-// Ring of STAGES tiles (32 KB each: X rows 16 KB | W rows 16 KB).  Flat phase p = 2 kt + s issues half-tile q = p + LEAD
-// (q even = X rows of tile q/2, odd = W rows), LEAD = 2 STAGES - 3: the slot's previous tile was last read two phases
-// earlier by either group (WAR), and the counted wait for tile kt+1 (vmcnt = 2 (LEAD - 2) pieces may stay in flight) sits
-// in the LOAD segment of phase (kt, 1), one full barrier before any wave reads that tile (RAW).
-template <int EPI, int STAGES, bool TRACE = false, int PH = 2>
-__global__ __launch_bounds__(512, 1) void k_gemm_f16_pp(const f16* __restrict__ X, const f16* __restrict__ Wt,
-                                                        const float* __restrict__ bias, void* __restrict__ Cout,
-                                                        float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
-                                                        long long* __restrict__ trace) {
-    constexpr int BM = 256, BN = 256, NT = 512, TM = 4, TN = 2;
-    constexpr int STAGE_BYTES = (BM + BN) * 64, W_OFF = BM * 64;
-    constexpr int LEAD = 2 * STAGES - 3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntm = M / BM;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_chunk = ntm * cw;
-    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int grp = wave >> 2, wn = wave & 3;
-
-    // DMA: this wave stages rows [wave*32, +32) of the X half and of the W half (2 pieces of 16 rows each)
-    const int l2 = lane >> 2, pslot = lane & 3;
-    const int R0 = wave * 32 + l2, R1 = R0 + 16;
-    const f16* xs0 = X + (size_t)(m0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
-    const f16* xs1 = X + (size_t)(m0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
-    const f16* ws0 = Wt + (size_t)(n0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
-    const f16* ws1 = Wt + (size_t)(n0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
-    char* const dma_base = smem + wave * 2048;
-#define PP_ISSUE_X(TILE)                                                                                      \
-    do {                                                                                                      \
-        char* sb_ = dma_base + ((TILE) % STAGES) * STAGE_BYTES;                                               \
-        __builtin_amdgcn_global_load_lds((glb_void*)(xs0 + (size_t)(TILE) * GK), (lds_void*)sb_, 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((glb_void*)(xs1 + (size_t)(TILE) * GK), (lds_void*)(sb_ + 1024), 16, 0, 0); \
-    } while (0)
-#define PP_ISSUE_W(TILE)                                                                                      \
-    do {                                                                                                      \
-        char* sb_ = dma_base + ((TILE) % STAGES) * STAGE_BYTES + W_OFF;                                       \
-        __builtin_amdgcn_global_load_lds((glb_void*)(ws0 + (size_t)(TILE) * GK), (lds_void*)sb_, 16, 0, 0);  \
-        __builtin_amdgcn_global_load_lds((glb_void*)(ws1 + (size_t)(TILE) * GK), (lds_void*)(sb_ + 1024), 16, 0, 0); \
-    } while (0)
-
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-
-    const int r31 = lane & 31, hh = lane >> 5;
-    const int sw = (r31 >> 2) & 3;
-    const int xrow = (grp * 128 + r31) * 64, wrow = W_OFF + (wn * 64 + r31) * 64;
-    const int po0 = ((0 + hh) ^ sw) * 16, po1 = ((2 + hh) ^ sw) * 16;
-    const int nk = K / GK;            // host guarantees nk >= STAGES
-    const int nh = 2 * nk;            // half-tiles
-
-    f16x8 fa[TN], fb[TM];
-#define PP_READ(SB, PO)                                                                      \
-    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const f16x8*)((SB) + wrow + ni * 2048 + (PO)); \
-    _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const f16x8*)((SB) + xrow + mi * 2048 + (PO));
-#define PP_MMA()                                                                             \
-    __builtin_amdgcn_s_setprio(1);                                                           \
-    _Pragma("unroll") for (int ni = 0; ni < TN; ++ni)                                        \
-        _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                    \
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-#define PP_BAR()                                  \
-    __builtin_amdgcn_sched_barrier(0);            \
-    __builtin_amdgcn_s_barrier();                 \
-    __builtin_amdgcn_sched_barrier(0);
-    // at most `newer` HALF-tiles issued after the wanted tile may stay in flight (2 pieces each)
-#define PP_WAIT(newer)                                                                       \
-    do {                                                                                     \
-        const int nw_ = (newer);                                                             \
-        if (nw_ >= LEAD - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LEAD - 2)) : "memory"); \
-        else if (nw_ == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 \
-        else if (nw_ == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 \
-        else if (nw_ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
-        else if (nw_ == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  \
-        else if (nw_ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  \
-        else if (nw_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                  \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
-    } while (0)
-
-    long long tr_wait = 0, tr_bar = 0, tr_t0 = 0, tr_load = 0, tr_mma = 0, tr_w0 = 0;
-    if (TRACE) tr_w0 = wall_clock64();
-  if (PH == 1) {
-    // one phase per K-step: LOAD = 12 ds_reads + 4 DMA pieces (tile kt + D) + counted wait for tile kt+1; 16 MFMAs
-    constexpr int D = STAGES - 2;
-    f16x8 fa1[TN], fb1[TM];
-#pragma unroll
-    for (int q = 0; q < D; ++q) { PP_ISSUE_X(q); PP_ISSUE_W(q); }
-    PP_WAIT(2 * (D - 1));
-    PP_BAR()
-    if (grp == 1) { PP_BAR() }
-    if (TRACE) tr_t0 = clock64();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
-        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-        if (TRACE) c0 = clock64();
-        PP_READ(sb, po0)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) fa1[ni] = *(const f16x8*)(sb + wrow + ni * 2048 + po1);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) fb1[mi] = *(const f16x8*)(sb + xrow + mi * 2048 + po1);
-        if (kt + D < nk) { PP_ISSUE_X(kt + D); PP_ISSUE_W(kt + D); }
-        if (TRACE) c1 = clock64();
-        if (kt + 1 < nk) {
-            const int newest = (kt + D < nk - 1) ? kt + D : nk - 1;
-            PP_WAIT(2 * (newest - (kt + 1)));
-        }
-        if (TRACE) c2 = clock64();
-        PP_BAR()
-        if (TRACE) c3 = clock64();
-        PP_MMA()
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1[ni], fb1[mi], acc[ni][mi], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (TRACE) c4 = clock64();
-        PP_BAR()
-        if (TRACE) { const long long c5 = clock64(); tr_load += c1 - c0; tr_wait += c2 - c1; tr_bar += (c3 - c2) + (c5 - c4); tr_mma += c4 - c3; }
-    }
-  } else {
-    // prologue: half-tiles 0 .. LEAD-1, then tile 0 (halves 0,1) must have landed
-#pragma unroll
-    for (int q = 0; q < LEAD; ++q) {
-        if (q & 1) PP_ISSUE_W(q >> 1); else PP_ISSUE_X(q >> 1);
-    }
-    PP_WAIT(LEAD - 2);
-    PP_BAR()
-    if (grp == 1) { PP_BAR() }          // group 1 runs one barrier behind group 0
-    if (TRACE) tr_t0 = clock64();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
-        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-        // ---- phase (kt, 0): LEAD is odd -> half-tile 2kt+LEAD is the W half of tile kt + (LEAD-1)/2
-        if (TRACE) c0 = clock64();
-        PP_READ(sb, po0)
-        if (2 * kt + LEAD < nh) PP_ISSUE_W(kt + (LEAD >> 1));
-        if (TRACE) c1 = clock64();
-        PP_BAR()
-        if (TRACE) c2 = clock64();
-        PP_MMA()
-        if (TRACE) c3 = clock64();
-        PP_BAR()
-        if (TRACE) { c4 = clock64(); tr_load += c1 - c0; tr_bar += (c2 - c1) + (c4 - c3); tr_mma += c3 - c2; }
-        // ---- phase (kt, 1): half-tile 2kt+1+LEAD is the X half of tile kt + (LEAD+1)/2
-        if (TRACE) c0 = clock64();
-        PP_READ(sb, po1)
-        if (2 * kt + 1 + LEAD < nh) PP_ISSUE_X(kt + ((LEAD + 1) >> 1));
-        if (TRACE) c1 = clock64();
-        if (kt + 1 < nk) {
-            // newest half-tile issued so far: min(2kt+1+LEAD, nh-1); tile kt+1 = halves 2kt+2, 2kt+3
-            const int newest = (2 * kt + 1 + LEAD < nh - 1) ? 2 * kt + 1 + LEAD : nh - 1;
-            PP_WAIT(newest - (2 * kt + 3));
-        }
-        if (TRACE) { c2 = clock64(); tr_load += c1 - c0; tr_wait += c2 - c1; }
-        PP_BAR()
-        if (TRACE) c3 = clock64();
-        PP_MMA()
-        if (TRACE) c4 = clock64();
-        PP_BAR()
-        if (TRACE) { const long long c5 = clock64(); tr_bar += (c3 - c2) + (c5 - c4); tr_mma += c4 - c3; }
-    }
-  }
-    if (grp == 0) { PP_BAR() }
-#undef PP_ISSUE_X
-#undef PP_ISSUE_W
-#undef PP_READ
-#undef PP_MMA
-#undef PP_BAR
-#undef PP_WAIT
-    long long tr_t1 = 0;
-    if (TRACE) tr_t1 = clock64();
-    // ---- epilogue through LDS (the whole ring is free: every DMA landed, every fragment is in registers) ----
-    // The tile is laid down with its 16-byte chunks XOR-swizzled by (row & 31) instead of row padding, so a full
-    // 256 x 256 fp16 tile (128 KB) or a 128-row fp32 half fits the ring exactly and both the lane-per-row writes and
-    // the row-contiguous reads are bank-conflict free.  Bias / QuickGELU are applied in registers (a lane's n is fixed).
-    __syncthreads();
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nloc = wn * 64 + ni * 32 + 8 * g + 4 * hh;
-                const float4 b4 = *(const float4*)(bias + n0 + nloc);
-                const int ch = nloc >> 3;
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) {
-                    const int m = grp * 128 + mi * 32 + r31;
-                    float v[4] = {acc[ni][mi][4 * g] + b4.x, acc[ni][mi][4 * g + 1] + b4.y, acc[ni][mi][4 * g + 2] + b4.z,
-                                  acc[ni][mi][4 * g + 3] + b4.w};
-                    f16x4 h4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[e];
-                        if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));   // QuickGELU (model.py:166-168)
-                        h4[e] = (f16)x;
-                    }
-                    *(f16x4*)(smem + m * 512 + ((ch ^ r31) << 4) + hh * 8) = h4;
-                }
-            }
-        __syncthreads();
-        const int j = tid & 31, rr = tid >> 5;
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int m = pass * 16 + rr;
-            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
-            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
-        }
-    } else {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();
-            if (grp == half) {
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nloc = wn * 64 + ni * 32 + 8 * g + 4 * hh;
-                        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
-                        const int ch = nloc >> 2;
-#pragma unroll
-                        for (int mi = 0; mi < TM; ++mi) {
-                            const int m = mi * 32 + r31;
-                            *(float4*)(smem + m * 1024 + ((ch ^ r31) << 4)) =
-                                make_float4(acc[ni][mi][4 * g] + b4.x, acc[ni][mi][4 * g + 1] + b4.y,
-                                            acc[ni][mi][4 * g + 2] + b4.z, acc[ni][mi][4 * g + 3] + b4.w);
-                        }
-                    }
-            }
-            __syncthreads();
-            const int j = tid & 63, rr = tid >> 6;
-#pragma unroll
-            for (int p8 = 0; p8 < 2; ++p8) {
-                // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
-                float4 x4[8];
-                if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int m = (p8 * 8 + q) * 8 + rr;
-                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int m = (p8 * 8 + q) * 8 + rr;
-                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
-                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
-                    if (EPI == EPI_BIAS_RESID) {
-                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
-                        *(float4*)(resid + off) = v;
-                    } else {
-                        *(float4*)((float*)Cout + off) = v;
-                    }
-                }
-            }
-        }
-    }
-    if (TRACE) {
-        const long long tr_t2 = clock64();
-        if (lane == 0 && trace) {
-            long long* o = trace + ((size_t)blockIdx.x * 8 + wave) * 8;
-            o[0] = tr_t1 - tr_t0; o[1] = tr_wait; o[2] = tr_bar; o[3] = tr_t2 - tr_t1; o[4] = tr_load; o[5] = tr_mma; o[6] = wave; o[7] = wall_clock64() - tr_w0;
-        }
-    }
-}
-
+#include "dev/vit_gemm_pp32.inc"
 #endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
@@ -1335,173 +1054,7 @@ static int gemm_chunk_tiles(int N, int K) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef VG_DEV      // K-step-32 predecessor of k_gemm_f16_pp64 (tools/dev only)
-// ---------------------------------------------------------------------------------------------
-// The same ping-pong schedule on v_mfma_f32_16x16x32_f16 (one MFMA spans the whole 32-wide K-step of a 16 x 16 block:
-// 32 MFMAs of 16 cycles per wave and K-step instead of 16 of 32).  MI355X_MICROARCH.md "DVFS give-back" item 7: on
-// random operands the 16x16x32 form holds a higher clock at equal cycles per FLOP.
-//   A operand (weight rows): lane l -> row l & 15, 16-byte K chunk l >> 4;  B operand (activation rows): the same.
-//   D: column (activation row m) = l & 15, rows (features n) = 4 (l >> 4) + r  -> a lane owns 4 consecutive n of one m.
-template <int EPI, int STAGES>
-__global__ __launch_bounds__(512, 1) void k_gemm_f16_pp16(const f16* __restrict__ X, const f16* __restrict__ Wt,
-                                                          const float* __restrict__ bias, void* __restrict__ Cout,
-                                                          float* __restrict__ resid, int M, int N, int K, int ldc, int cw) {
-    constexpr int BM = 256, BN = 256, NT = 512, TM = 8, TN = 4;       // 16 x 16 blocks per wave tile (128 m x 64 n)
-    constexpr int STAGE_BYTES = (BM + BN) * 64, W_OFF = BM * 64;
-    constexpr int D = STAGES - 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntm = M / BM;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_chunk = ntm * cw;
-    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int grp = wave >> 2, wn = wave & 3;
-
-    const int l2 = lane >> 2, pslot = lane & 3;
-    const int R0 = wave * 32 + l2, R1 = R0 + 16;
-    const f16* xs0 = X + (size_t)(m0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
-    const f16* xs1 = X + (size_t)(m0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
-    const f16* ws0 = Wt + (size_t)(n0 + R0) * K + (pslot ^ ((R0 >> 2) & 3)) * 8;
-    const f16* ws1 = Wt + (size_t)(n0 + R1) * K + (pslot ^ ((R1 >> 2) & 3)) * 8;
-    char* const dma_base = smem + wave * 2048;
-    auto issue = [&](int tile) {
-        char* sb_ = dma_base + (tile % STAGES) * STAGE_BYTES;
-        __builtin_amdgcn_global_load_lds((glb_void*)(xs0 + (size_t)tile * GK), (lds_void*)sb_, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(xs1 + (size_t)tile * GK), (lds_void*)(sb_ + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(ws0 + (size_t)tile * GK), (lds_void*)(sb_ + W_OFF), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(ws1 + (size_t)tile * GK), (lds_void*)(sb_ + W_OFF + 1024), 16, 0, 0);
-    };
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int r15 = lane & 15, q4 = lane >> 4;
-    const int po = (q4 ^ ((r15 >> 2) & 3)) * 16;
-    const int xrow = (grp * 128 + r15) * 64 + po, wrow = W_OFF + (wn * 64 + r15) * 64 + po;
-    const int nk = K / GK;
-#define PP_BAR()                                  \
-    __builtin_amdgcn_sched_barrier(0);            \
-    __builtin_amdgcn_s_barrier();                 \
-    __builtin_amdgcn_sched_barrier(0);
-#define PP_WAIT(newer)                                                                       \
-    do {                                                                                     \
-        const int nw_ = (newer);                                                             \
-        if (nw_ >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory"); \
-        else if (nw_ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
-        else if (nw_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
-    } while (0)
-#pragma unroll
-    for (int q = 0; q < D; ++q) issue(q);
-    PP_WAIT(D - 1);
-    PP_BAR()
-    if (grp == 1) { PP_BAR() }
-    f16x8 fa[TN], fb[TM];
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* sb = smem + (kt % STAGES) * STAGE_BYTES;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) fa[ni] = *(const f16x8*)(sb + wrow + ni * 1024);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) fb[mi] = *(const f16x8*)(sb + xrow + mi * 1024);
-        if (kt + D < nk) issue(kt + D);
-        if (kt + 1 < nk) {
-            const int newest = (kt + D < nk - 1) ? kt + D : nk - 1;
-            PP_WAIT(newest - (kt + 1));
-        }
-        PP_BAR()
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ni], fb[mi], acc[ni][mi], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        PP_BAR()
-    }
-    if (grp == 0) { PP_BAR() }
-#undef PP_BAR
-#undef PP_WAIT
-    // ---- epilogue: the same chunk-XOR-swizzled LDS image as k_gemm_f16_pp ----
-    __syncthreads();
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int nloc = wn * 64 + ni * 16 + 4 * q4;
-            const float4 b4 = *(const float4*)(bias + n0 + nloc);
-            const int ch = nloc >> 3, hf = (nloc >> 2) & 1;
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const int m = grp * 128 + mi * 16 + r15;
-                float v[4] = {acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w};
-                f16x4 h4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e];
-                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
-                    h4[e] = (f16)x;
-                }
-                *(f16x4*)(smem + m * 512 + ((ch ^ (m & 31)) << 4) + hf * 8) = h4;
-            }
-        }
-        __syncthreads();
-        const int j = tid & 31, rr = tid >> 5;
-#pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            const int m = pass * 16 + rr;
-            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
-            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
-        }
-    } else {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();
-            if (grp == half) {
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    const int nloc = wn * 64 + ni * 16 + 4 * q4;
-                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
-                    const int ch = nloc >> 2;
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi) {
-                        const int m = mi * 16 + r15;
-                        *(float4*)(smem + m * 1024 + ((ch ^ (m & 31)) << 4)) =
-                            make_float4(acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w);
-                    }
-                }
-            }
-            __syncthreads();
-            const int j = tid & 63, rr = tid >> 6;
-#pragma unroll
-            for (int p8 = 0; p8 < 2; ++p8) {
-                // eight residual loads in flight before the first store (a load / add / store loop serialises on aliasing)
-                float4 x4[8];
-                if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int m = (p8 * 8 + q) * 8 + rr;
-                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int m = (p8 * 8 + q) * 8 + rr;
-                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
-                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
-                    if (EPI == EPI_BIAS_RESID) {
-                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
-                        *(float4*)(resid + off) = v;
-                    } else {
-                        *(float4*)((float*)Cout + off) = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
+#include "dev/vit_gemm_pp16.inc"
 #endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
@@ -1878,315 +1431,7 @@ static int gemm_chunk_tiles_256(int ntn) {
 }
 
 #ifdef VG_DEV      // measured slower than k_gemm_f16_pp64 on every projection shape: development build only (VG_GEMM_X2=1)
-// ---------------------------------------------------------------------------------------------
-// k_gemm_f16_x2: TWO independent 4-wave workgroups per CU, each a 128 x 256 tile (one "group" of k_gemm_f16_pp64).
-// Why: in k_gemm_f16_pp64 the one workgroup that owns a CU reaches its epilogue with all eight waves at once, and the matrix pipe
-// idles while the tile is written -- 3.5 of the 14.7 ms of projection GEMMs per frame; the out_proj /
-// c_proj epilogues (fp32 residual read-modify-write + fp16 copy = 10 B per element) are HBM-bound on top, all CUs at the same time.
-// Two workgroups that share a CU's SIMDs (2 waves per SIMD, as before) drift apart: one's epilogue runs under the other's MFMAs.
-//   * 160 KB of LDS do not hold two K-step-64 rings of X AND W.  In a 4-wave workgroup every W row is read by exactly ONE wave
-//     (wave wn owns columns [64 wn, +64)), so W does not need LDS at all: each lane loads its own MFMA fragments from global
-//     memory (L2-resident weights; 16 rows x 64 B per instruction), one K-tile ahead, straight into registers.  X (read by all four
-//     waves) goes through a 4-stage LDS ring (X2_NST x 16 KB) filled by LDS-DMA as before: 66.5 KB static per workgroup, ~133 KB per CU.
-//   * The fragment reads are software-pipelined across K-tiles: every MFMA group is followed by the ds_read of a fragment the
-//     group after next needs, so the only point a wave waits at is the one barrier per K-tile (placed after the last read of
-//     the current stage; the other workgroup's waves have the pipe meanwhile).
-//   * Epilogue without workgroup barriers: a wave transposes its own 128 x 64 block through a private 12 KB slice of the (now
-//     idle) ring, 64 (fp16) or 32 (fp32) rows at a time, and writes full 128 / 256-byte row segments.
-//   * Folded LayerNorm: the partial row statistics are per 64 columns (one wave's share of a row) instead of per 256, so no
-//     exchange between waves; the consumer merges K / 64 partials (Chan et al.) instead of K / 256.
-#define X2_STAGE 16384
-#define X2_NST 4
-#define X2_LN_MAXP 16                 // partials per row the consumer merges (width <= 1024)
-__device__ __forceinline__ float row16_sum(float v) {             // sum over the 16 lanes of a DPP row, in every lane of it
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    return v;
-}
-
-template <int EPI, int LN = 0, bool TRACE = false>
-__global__ __launch_bounds__(256, 2) void k_gemm_f16_x2(const f16* __restrict__ X, const f16* __restrict__ Wt,
-                                                        const float* __restrict__ bias, void* __restrict__ Cout,
-                                                        float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
-                                                        const float* __restrict__ ln_c1, LnPartial* __restrict__ ln_stats,
-                                                        f16* __restrict__ ln_x16, long long* __restrict__ trace = nullptr) {
-    constexpr int BM = 128, BN = 256, TM = 8, TN = 4;
-    long long tr_entry = 0, tr_w0 = 0, tr_t0 = 0, tr_main = 0, tr_wait = 0, tr_bar = 0;
-    if (TRACE) { tr_entry = clock64(); tr_w0 = wall_clock64(); }
-    __shared__ __attribute__((aligned(16))) char smem[X2_NST * X2_STAGE + 1024];
-    const int tid = threadIdx.x, wn = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int ntm = M / BM;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_chunk = ntm * cw;
-    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // Addressing through buffer descriptors: SGPR base + one VGPR offset per operand + an SGPR offset that carries everything
-    // wave-uniform (tile, K-tile, piece / fragment row).  With 64-bit pointers per piece and fragment row the loop carried 16 VGPRs
-    // of addresses -- and spilled them.
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)((size_t)M * K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, (int)((size_t)N * K * 2), 0x00020000);
-    // X pieces: 8 rows x 128 B per wave instruction; lane -> row l >> 3, chunk slot l & 7 (source chunk = slot ^ ((row >> 1) & 7);
-    // rows 8 i + prow: the swizzle term alternates between two values with i)
-    const int prow = lane >> 3, pslot = lane & 7;
-    const int xv0 = ((wn * 32 + prow) * K + (pslot ^ (prow >> 1)) * 8) * 2;       // odd pieces: ^ 64 (chunk ^ 4)
-    auto issue_x = [&](int kt) {
-        char* d = smem + (kt % X2_NST) * X2_STAGE + (wn * 32) * 128;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(d + i * 1024), 16, (i & 1) ? (xv0 ^ 64) : xv0,
-                                                     ((m0 + 8 * i) * K + kt * 64) * 2, 0, 0);
-    };
-    const int r15 = lane & 15, q4 = lane >> 4;
-    // W fragments of this wave's 64 columns: row n0 + 64 wn + 16 ni + r15, halves [8 q4, +8) of each k32 sub-step
-    const int wv = (r15 * K + q4 * 8) * 2;
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int swz = (r15 >> 1) & 7;
-    const int xo0 = r15 * 128 + ((q4 ^ swz) << 4), xo1 = r15 * 128 + (((4 + q4) ^ swz) << 4);
-    const int np = K / 64;                         // host guarantees K % 256 == 0 (np a multiple of 4)
-
-    // folded LayerNorm, consumer side: thread t < 128 merges the K / 64 partials of tile row t into (mean, rstd)
-    float2 ln_row = make_float2(0.f, 0.f);
-    if (LN == 1 && tid < BM) {
-        const int nst = K >> 6;
-        const LnPartial* sp = ln_stats + (size_t)(m0 + tid) * nst;
-        LnPartial pt[X2_LN_MAXP];
-#pragma unroll
-        for (int u = 0; u < X2_LN_MAXP; ++u) pt[u] = u < nst ? sp[u] : LnPartial{0.f, 0.f};
-        float ms = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int u = 0; u < X2_LN_MAXP; ++u) { ms += pt[u].mean; m2 += pt[u].m2; }
-        const float mean = ms / (float)nst;
-        float dev = 0.f;
-#pragma unroll
-        for (int u = 0; u < X2_LN_MAXP; ++u) if (u < nst) { const float d = pt[u].mean - mean; dev += d * d; }
-        ln_row = make_float2(mean, rsqrtf((m2 + 64.f * dev) / (float)K + 1e-5f));
-    }
-
-    // W fragments: two pairs of sets (the K-tile in work, the next one).  Both k32 halves of a W row -- one 128-byte line -- are
-    // requested back to back: requested half a K-tile apart the line had left the L1 in between and came from L2 twice
-    f16x8 wa0[TN], wa1[TN], wb0[TN], wb1[TN], fb[TM];
-    auto load_w = [&](int kt, f16x8 (&a)[TN], f16x8 (&a2)[TN]) {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            a[ni] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wv, ((n0 + wn * 64 + ni * 16) * K + kt * 64) * 2, 0));
-            a2[ni] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wv, ((n0 + wn * 64 + ni * 16) * K + kt * 64 + 32) * 2, 0));
-        }
-    };
-    issue_x(0);
-    issue_x(1);
-    load_w(0, wa0, wa1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mi = 0; mi < TM - 2; ++mi) fb[mi] = *(const f16x8*)(smem + xo0 + mi * 2048);
-
-    // one K-tile: wc0 / wc1 hold its two sub-steps' W fragments, wn0 / wn1 receive the next tile's.  fb[0..5] hold the first
-    // sub-step's X fragments of rows 0..95 on entry, and the next tile's on exit.  (stage and the two "is there a next / next but
-    // one tile" flags are compile-time: the steady-state body has no branches and every LDS offset is an immediate)
-    auto ktile = [&](auto stage_c, auto more_c, auto more2_c, int j, f16x8 (&wc0)[TN], f16x8 (&wc1)[TN], f16x8 (&wn0)[TN], f16x8 (&wn1)[TN]) {
-        constexpr int STG = decltype(stage_c)::value;
-        constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
-        const char* xb = smem + STG * X2_STAGE;
-        const char* xnb = smem + ((STG + 1) % X2_NST) * X2_STAGE;
-        if (more) load_w(j + 1, wn0, wn1);
-        if (more2) {
-            char* d = smem + ((STG + 2) % X2_NST) * X2_STAGE + (wn * 32) * 128;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int xv = xv0;
-                if (i & 1) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(xv) : "v"(xv0));      // (not kept in a register across the loop)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(d + i * 1024), 16, xv, ((m0 + 8 * i) * K + (j + 2) * 64) * 2, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc0[ni], fb[mi], acc[ni][mi], 0, 0, 0);
-            if (mi < 2) fb[TM - 2 + mi] = *(const f16x8*)(xb + xo0 + (TM - 2 + mi) * 2048);
-            else fb[mi - 2] = *(const f16x8*)(xb + xo1 + (mi - 2) * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc1[ni], fb[mi], acc[ni][mi], 0, 0, 0);
-            if (mi < 2) fb[TM - 2 + mi] = *(const f16x8*)(xb + xo1 + (TM - 2 + mi) * 2048);
-            else if (more) fb[mi - 2] = *(const f16x8*)(xnb + xo0 + (mi - 2) * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-            if (mi == 1 && more) {
-                // the last read of this stage is out; the next stage's pieces (issued one K-tile ago) must have landed, for every
-                // wave.  Still in flight may be this tile's 8 W loads and 4 X pieces (none for the last but one tile)
-                __builtin_amdgcn_s_setprio(0);
-                long long c0 = 0, c1 = 0;
-                if (TRACE) c0 = clock64();
-                if (more2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                if (TRACE) c1 = clock64();
-                __builtin_amdgcn_s_barrier();
-                if (TRACE) { const long long c2 = clock64(); tr_wait += c1 - c0; tr_bar += c2 - c1; }
-                __builtin_amdgcn_s_setprio(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    using std::integral_constant;
-    constexpr integral_constant<int, 0> S0; constexpr integral_constant<int, 1> S1; constexpr integral_constant<int, 2> S2; constexpr integral_constant<int, 3> S3;
-    constexpr integral_constant<bool, true> YES; constexpr integral_constant<bool, false> NO;
-    if (TRACE) tr_t0 = clock64();
-    int j = 0;
-    for (; j < np - 4; j += 4) {                   // host guarantees np % 4 == 0
-        ktile(S0, YES, YES, j, wa0, wa1, wb0, wb1);
-        ktile(S1, YES, YES, j + 1, wb0, wb1, wa0, wa1);
-        ktile(S2, YES, YES, j + 2, wa0, wa1, wb0, wb1);
-        ktile(S3, YES, YES, j + 3, wb0, wb1, wa0, wa1);
-    }
-    ktile(S0, YES, YES, j, wa0, wa1, wb0, wb1);
-    ktile(S1, YES, YES, j + 1, wb0, wb1, wa0, wa1);
-    ktile(S2, YES, NO, j + 2, wa0, wa1, wb0, wb1);
-    ktile(S3, NO, NO, j + 3, wb0, wb1, wa0, wa1);
-    if (TRACE) tr_main = clock64() - tr_t0;
-    __syncthreads();                               // every wave is done with the ring: its slices become the waves' scratch
-    char* sc = smem + wn * 16384;
-    // (the epilogue's per-lane values are derived again from an opaque copy of the lane id: nothing of it lives through the K loop)
-    int lane_e = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_e));
-    const int r15e = lane_e & 15, q4e = lane_e >> 4;
-
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        float ln_mean[TM], ln_rstd[TM];
-        if (LN == 1) {
-            float2* lsm = (float2*)(smem + X2_NST * X2_STAGE);
-            if (tid < BM) lsm[tid] = ln_row;
-            __syncthreads();
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const float2 t2 = lsm[mi * 16 + r15e];
-                ln_mean[mi] = t2.x; ln_rstd[mi] = t2.y;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {              // rows [64 p, +64)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int nloc = wn * 64 + ni * 16 + 4 * q4e;
-                const float4 b4 = *(const float4*)(bias + n0 + nloc);
-                float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (LN == 1) c4 = *(const float4*)(ln_c1 + n0 + nloc);
-                const int ch = ni * 2 + (q4e >> 1);
-#pragma unroll
-                for (int mq = 0; mq < 4; ++mq) {
-                    const int mi = p * 4 + mq, row = mq * 16 + r15e;
-                    float v[4] = {acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w};
-                    if (LN == 1) {
-                        v[0] = ln_rstd[mi] * (acc[ni][mi][0] - ln_mean[mi] * c4.x) + b4.x;
-                        v[1] = ln_rstd[mi] * (acc[ni][mi][1] - ln_mean[mi] * c4.y) + b4.y;
-                        v[2] = ln_rstd[mi] * (acc[ni][mi][2] - ln_mean[mi] * c4.z) + b4.z;
-                        v[3] = ln_rstd[mi] * (acc[ni][mi][3] - ln_mean[mi] * c4.w) + b4.w;
-                    }
-                    f16x4 h4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[e];
-                        if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
-                        h4[e] = (f16)x;
-                    }
-                    *(f16x4*)(sc + row * 128 + ((ch ^ (row & 7)) << 4) + (q4e & 1) * 8) = h4;
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + (lane_e >> 3), c = lane_e & 7;
-                const f16x8 v = *(const f16x8*)(sc + row * 128 + ((c ^ (row & 7)) << 4));
-                *(f16x8*)((f16*)Cout + (size_t)(m0 + p * 64 + row) * ldc + n0 + wn * 64 + c * 8) = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {              // rows [32 p, +32)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int nloc = wn * 64 + ni * 16 + 4 * q4e;
-                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
-                const int ch = ni * 4 + q4e;
-#pragma unroll
-                for (int mq = 0; mq < 2; ++mq) {
-                    const int mi = p * 2 + mq, row = mq * 16 + r15e;
-                    *(float4*)(sc + row * 256 + ((ch ^ (row & 15)) << 4)) =
-                        make_float4(acc[ni][mi][0] + b4.x, acc[ni][mi][1] + b4.y, acc[ni][mi][2] + b4.z, acc[ni][mi][3] + b4.w);
-                }
-            }
-            const int c = lane_e & 15;
-            // eight residual loads in flight before the first store
-            float4 x4[8];
-            if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int row = it * 4 + (lane_e >> 4);
-                    x4[it] = *(const float4*)(resid + (size_t)(m0 + p * 32 + row) * ldc + n0 + wn * 64 + c * 4);
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 4 + (lane_e >> 4);
-                float4 v = *(const float4*)(sc + row * 256 + ((c ^ (row & 15)) << 4));
-                const size_t off = (size_t)(m0 + p * 32 + row) * ldc + n0 + wn * 64 + c * 4;
-                if (EPI == EPI_BIAS_RESID) {
-                    v.x += x4[it].x; v.y += x4[it].y; v.z += x4[it].z; v.w += x4[it].w;
-                    *(float4*)(resid + off) = v;
-                    if (LN == 2) {
-                        // the 16 lanes of a DPP row hold this wave's 64 columns of the row: fp16 copy for the next GEMM + partial statistics
-                        const f16x4 h4 = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                        *(f16x4*)(ln_x16 + off) = h4;
-                        const float mean = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
-                        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-                        const float m2 = row16_sum((a * a + b * b) + (cc * cc + d * d));
-                        if (c == 0) ln_stats[(size_t)(m0 + p * 32 + row) * (N >> 6) + (n0 >> 6) + wn] = LnPartial{mean, m2};
-                    }
-                } else {
-                    *(float4*)((float*)Cout + off) = v;
-                }
-            }
-        }
-    }
-    if (TRACE && (tid & 63) == 0 && trace) {
-        long long* o = trace + ((size_t)blockIdx.x * 4 + wn) * 8;
-        const long long t2 = clock64();
-        o[0] = tr_main; o[1] = tr_wait; o[2] = tr_bar; o[3] = (t2 - tr_entry) - tr_main; o[4] = 0; o[5] = tr_main - tr_wait - tr_bar; o[6] = wn;
-        o[7] = wall_clock64() - tr_w0;
-    }
-}
-
-template <int EPI, int LN = 0, bool TRACE = false>
-static int launch_gemm_x2(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
-                          hipStream_t st, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr, f16* ln_x16 = nullptr,
-                          long long* trace = nullptr) {
-    if (M % 128 || N % 256 || K % 256) return VG_ERR_ARG;
-    if (LN == 1 && (K / 64 > X2_LN_MAXP || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
-    if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
-    const int ntn = N / 256;
-    int cwt = gemm_chunk_tiles_256(ntn);
-    if (getenv("VG_GEMM_CW")) { cwt = atoi(getenv("VG_GEMM_CW")); if (cwt < 1 || ntn % cwt) cwt = ntn; }      // tile-order sweep
-    hipLaunchKernelGGL((k_gemm_f16_x2<EPI, LN, TRACE>), dim3((M / 128) * ntn), dim3(256), 0, st, (const f16*)X, (const f16*)Wt, bias, C, resid,
-                       M, N, K, ldc, cwt, ln_c1, ln_stats, ln_x16, trace);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
+#include "dev/vit_gemm_x2.inc"
 #endif  // VG_DEV
 
 // ---------------------------------------------------------------------------------------------
@@ -2313,36 +1558,7 @@ static int launch_gemm_resid_tail(const void* X, const void* Wt, const float* bi
 
 
 #ifdef VG_DEV
-template <int EPI, int STAGES>
-static int launch_gemm_pp16(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
-                            hipStream_t st) {
-    if (M % 256 || N % 256 || K % GK || K / GK < STAGES) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp16<EPI, STAGES>;
-    const int lds = STAGES * 32768;
-    VG_MAX_DYNAMIC_LDS(kern, lds);
-    const int ntn = N / 256;
-    int cwt = gemm_chunk_tiles_256(ntn);
-    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, cwt);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
-
-template <int EPI, int STAGES, bool TRACE, int PH = 2>
-static int launch_gemm_pp(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
-                          hipStream_t st, long long* trace) {
-    if (M % 256 || N % 256 || K % GK || K / GK < STAGES) return VG_ERR_ARG;
-    auto kern = k_gemm_f16_pp<EPI, STAGES, TRACE, PH>;
-    const int lds = STAGES * 32768;
-    VG_MAX_DYNAMIC_LDS(kern, lds);
-    const int ntn = N / 256;
-    int cwt = gemm_chunk_tiles_256(ntn);
-    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(512), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, cwt, trace);
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
-
+#include "dev/vit_dev_launchers.inc"
 #endif  // VG_DEV
 
 template <int EPI, int LN = 0>
@@ -2959,71 +2175,7 @@ int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int 
 }
 
 #ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces
-/* ablation variants of the f16 GEMMs (development aid, epi 0 only): k_gemm_f16 var 0 = as shipped, 1 = no DMA inside the
- * K loop, 2 = DMA only (no LDS reads / MFMA), 3 = no epilogue; k_gemm_f16_pp var 22 = as shipped (4 stages, one phase per
- * K-step), 20 = two phases per K-step, 21 / 23 = 5 stages */
-int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc, void* stream) {
-    if (M % GBM || N % GBN || K % GK) return VG_ERR_ARG;
-    int nwg = (M / GBM) * (N / GBN);
-    hipStream_t st = (hipStream_t)stream;
-#define VG_VAR(V)                                                                                                          \
-    case V:                                                                                                                \
-        (void)hipFuncSetAttribute((const void*)k_gemm_f16<EPI_BIAS, V>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); \
-        hipLaunchKernelGGL((k_gemm_f16<EPI_BIAS, V>), dim3(nwg), dim3(512), G_LDS_BYTES, st, (const f16*)d_X, (const f16*)d_Wt, \
-                           d_bias, d_C, nullptr, M, N, K, ldc, gemm_chunk_tiles(N, K));                                   \
-        break;
-    switch (var) { VG_VAR(0) VG_VAR(1) VG_VAR(2) VG_VAR(3)
-        case 20: return launch_gemm_pp<EPI_BIAS, 4, false>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
-        case 21: return launch_gemm_pp<EPI_BIAS, 5, false>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
-        case 22: return launch_gemm_pp<EPI_BIAS, 4, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
-        case 23: return launch_gemm_pp<EPI_BIAS, 5, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr);
-        case 30: return launch_gemm_pp16<EPI_BIAS, 4>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
-        case 32: return launch_gemm_pp64<EPI_BIAS>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
-        case 36: return launch_gemm_pp64<EPI_BIAS, false, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st);
-        default: return VG_ERR_ARG; }
-#undef VG_VAR
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
-
-/* k_gemm_f16_pp64 with the folded LayerNorm's CONSUMER epilogue (LN = 1; epi 0 bias, 1 bias + QuickGELU) on caller-supplied row
- * statistics: d_stats [M, K/256] (mean, m2) pairs, d_c1 [N]; for A/B runs against vg_gemm on the same operands */
-int vg_gemm_ln_consumer(int epi, const void* d_X, const void* d_Wt, const float* d_bias, const float* d_c1, const void* d_stats,
-                        void* d_C, int M, int N, int K, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (epi == 0) return launch_gemm_pp64<EPI_BIAS, false, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, N, st, nullptr, d_c1, (LnPartial*)d_stats);
-    if (epi == 1) return launch_gemm_pp64<EPI_BIAS_GELU, false, false, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, N, st, nullptr, d_c1, (LnPartial*)d_stats);
-    return VG_ERR_ARG;
-}
-
-int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
-                  int K, int ldc, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    switch (var) {
-        case 20: return launch_gemm_pp<EPI_BIAS, 4, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
-        case 21: return launch_gemm_pp<EPI_BIAS, 5, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
-        case 22: return launch_gemm_pp<EPI_BIAS, 4, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
-        case 23: return launch_gemm_pp<EPI_BIAS, 5, true, 1>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
-        case 32: return launch_gemm_pp64<EPI_BIAS, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
-        case 33: return launch_gemm_pp64<EPI_BIAS_GELU, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, (long long*)d_trace);
-        case 34: return launch_gemm_pp64<EPI_BIAS_RESID, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
-        case 35: return launch_gemm_pp64<EPI_BIAS_RESID_H, true>(d_X, d_Wt, d_bias, nullptr, (float*)d_C, M, N, K, ldc, st, (long long*)d_trace);
-        case 40: return launch_gemm_x2<EPI_BIAS, 0, true>(d_X, d_Wt, d_bias, d_C, nullptr, M, N, K, ldc, st, nullptr, nullptr, nullptr, (long long*)d_trace);
-        default: return VG_ERR_ARG; }
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-}
-
-/* development aid: k_attention_f16 alone (trace = null) or with per-wave phase cycle counts: d_trace receives, per (workgroup of the
- * persistent grid min(items, 256), wave 0..6), eight int64 (see the AT_STAMP comments in the kernel). */
-int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, int64_t* d_trace, void* stream) {
-    if (!d_qkv || !d_out || n_crops <= 0 || T > AT_MAXT || heads * 64 != W) return VG_ERR_ARG;
-    const int items = n_crops * heads;
-    hipStream_t st = (hipStream_t)stream;
-    if (d_trace) return launch_attention<true>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, items, (long long*)d_trace, st);
-    return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, items, nullptr, st);
-}
-
+#include "dev/vit_dev_entry.inc"
 #endif  // VG_DEV
 
 /* C = X @ Wt^T (+ epilogue), exposed for unit tests / micro-benchmarks of the GEMM itself.
