@@ -40,7 +40,7 @@
 #ifndef CL_LEAF
 #define CL_LEAF 48                    // nodes with at most this many points are scanned instead of subdivided
 #endif
-#define CL_FIRST_BATCH 6      // Boruvka rounds queued before the first host read of the edge counter
+#define CL_FIRST_BATCH 6      // Boruvka rounds queued before the first host read of the edge counter (development build: VG_CLUSTER_FIRST_BATCH)
 #define CL_STACK 44      // DFS stack entries per thread (LDS): the walk never holds more than 1 + 7 * CL_LMAX = 43 nodes (a pop precedes every push of
                          // <= 8 children, level-0 nodes are never expanded); 44 KB per 256-thread block -> three blocks per CU instead of two
 #define CL_K 16                       // neighbours kept (k-th other point = entry k, entry 0 is the point itself)
@@ -781,7 +781,8 @@ __global__ void k_cl_b_seed(int n, const int* __restrict__ comp, int* __restrict
 __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned long long* __restrict__ best_w,
                                   unsigned long long* __restrict__ best_d, unsigned long long* __restrict__ best_e,
                                   int* __restrict__ sel_a, const int* __restrict__ flags, const int* __restrict__ csize,
-                                  unsigned long long* __restrict__ giant) {
+                                  unsigned long long* __restrict__ giant, const unsigned int* __restrict__ code_s,
+                                  int* __restrict__ cell_comp) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     __shared__ unsigned long long blk_max[4];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -793,6 +794,9 @@ __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned 
         best_e[i] = ~0ull;
         sel_a[i] = -1;
         if (comp[i] == i) mine = ((unsigned long long)(unsigned int)csize[i] << 32) | (unsigned int)i;
+        // level-0 purity, first half: the first point of a cell writes its component; k_cl_b_purity (a later launch) overwrites the
+        // entry with -1 where two neighbours inside the cell disagree
+        if (i == 0 || code_s[i - 1] != code_s[i]) cell_comp[code_s[i]] = comp[i];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -818,18 +822,17 @@ __device__ __forceinline__ size_t cl_pur_off(int l) {   // offset of level l ins
     return o;
 }
 
+// Level-0 purity tables: cell_comp[c] = the component that owns every point of cell c, or -1.  All points of a cell agree iff every two
+// neighbours in the sorted order agree: k_cl_b_round_init wrote the first point's component, a thread whose point differs from its
+// predecessor in the same cell writes -1 (same value from every writer).  (Rounds 1-4: the first point's thread walked the whole cell --
+// 29.5 us per launch on average, 79 at worst, for the densest cells' serial loops; now one compare per thread.)
 __global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ comp,
                               int* __restrict__ cell_comp, const int* __restrict__ flags) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || i == 0) return;
     const unsigned int c = code_s[i];
-    if (i > 0 && code_s[i - 1] == c) return;
-    const int k0 = comp[i];
-    int pure = k0;
-    for (int j = i + 1; j < n && code_s[j] == c; ++j)
-        if (comp[j] != k0) { pure = -1; break; }
-    cell_comp[c] = pure;
+    if (code_s[i - 1] == c && comp[i - 1] != comp[i]) cell_comp[c] = -1;
 }
 
 // level l >= 1 from level l-1: thread per OCCUPIED level-l cell (first point of the cell)
@@ -1760,8 +1763,12 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
     // (first batch: CL_FIRST_BATCH rounds -- 150k-point frames need 6-8 -- then one round at a time).
     int rounds = 0, edges = 0, needed = 0;
     int* const flags = h->d_counter;
+    int first_batch = CL_FIRST_BATCH;
+#ifdef VG_DEV
+    if (getenv("VG_CLUSTER_FIRST_BATCH")) first_batch = std::max(1, std::min(12, atoi(getenv("VG_CLUSTER_FIRST_BATCH"))));
+#endif
     auto one_round = [&](int r) {
-        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant);
+        hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
         if (r > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);
         for (int l = 1; l < CL_PUR_LEVELS; ++l)
@@ -1773,8 +1780,11 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         if (r == 1 && getenv("VG_CLUSTER_SEEDSIM")) {
             (void)hipMemsetAsync(h->d_counter + 5, 0, 4, st);
             hipLaunchKernelGGL(k_cl_seedsim_drop, dim3(nb), dim3(256), 0, st, n, h->d_core2, h->d_pt_w, h->d_pt_b, h->d_counter);
-            hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant);
+            hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
             hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
+            hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);   // (round_init rewrote level 0)
+            for (int l = 1; l < CL_PUR_LEVELS; ++l)
+                hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp, flags);
             if (dim == 3) cl_launch_search<3>(h, n, st);          // walks only the points that were not seedable
             else if (dim == 4) cl_launch_search<4>(h, n, st);
             else cl_launch_search<5>(h, n, st);
@@ -1796,7 +1806,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         return hipMemcpyAsync(h->h_counter + ((r - 1) & 15), h->d_counter, 4, hipMemcpyDeviceToHost, st);
     };
     while (edges < n - 1) {
-        const int batch = (rounds == 0 && !h->d_dbg) ? CL_FIRST_BATCH : 1;
+        const int batch = (rounds == 0 && !h->d_dbg) ? first_batch : 1;
         const int first = rounds + 1;
         for (int b = 0; b < batch; ++b) {
             if (++rounds > 64) {

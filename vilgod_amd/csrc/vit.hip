@@ -651,6 +651,34 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
 #pragma unroll
         for (int it = 0; it < 4; ++it) vreg[it] = *(const f16x8*)(vbase + kvoff[it]);
     };
+    // STAG, waves 4-6: the OUTPUT phase of an item (scale by 1 / sum, rows through the wave's tile, stores) is deferred to the start of the
+    // next item's compute -- the accumulators wait in registers across the barrier -- so that these waves reach their S^T MFMAs a third of an
+    // item behind their SIMD partners (MI355X_MICROARCH.md, two waves per SIMD, item 9: "waves 4-7 defer each block's epilogue by one block")
+    f32x16 oacc[2];
+    float inv = 0.f;
+    bool deferred = false;
+    auto write_out = [&](f16* ob) {
+        // output rows through the wave's tile: a lane's 4-feature pieces in, 16-byte parts of whole 128-byte rows out
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
+                *(f16x4*)(Qs + r31 * AT_KLD + dt * 32 + 8 * g + 4 * hh) = h4;
+            }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int qr = q0 + it * 8 + crow;
+            const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
+            if (qr < T) *(f16x8*)(ob + ooff[it]) = v;
+        }
+    };
+    auto obase_of = [&](int it_) {
+        const int crop_ = it_ / heads, head_ = it_ - crop_ * heads;
+        return out + (size_t)crop_ * T * W + head_ * 64;
+    };
     int item = blockIdx.x;
     if (item < n_items) fetch(item);
     for (; item < n_items; item += gridDim.x) {
@@ -681,6 +709,10 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(Qs + r31 * AT_KLD + s * 16 + hh * 8);
     __syncthreads();
     AT_STAMP(0)                                                        // K / V^T into LDS + barrier
+    if (STAG && deferred) {                                            // (qf holds this item's Q fragments: the tile is free again)
+        write_out(obase_of(item - (int)gridDim.x));
+        deferred = false;
+    }
     const bool has_next = item + (int)gridDim.x < n_items;
     const bool computes = q0 < T && wave < q_tiles;   // (q_tiles: query tiles wanted -- 1 in the last block, whose class-token row alone is used)
     const bool late = STAG && wave < 4 && computes;   // this wave issues the next item's loads behind its S^T MFMAs
@@ -749,10 +781,9 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         }
     }
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    inv = 1.0f / sum;
     AT_STAMP(4)                                                        // exp pass
 
-    f32x16 oacc[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -785,27 +816,14 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         }
     }
     AT_STAMP(5)                                                        // P -> fp16, V^T fragments, O^T MFMAs issued
-    // output rows through the wave's tile: a lane's 4-feature pieces in, 16-byte parts of whole 128-byte rows out
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f16x4 h4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
-            *(f16x4*)(Qs + r31 * AT_KLD + dt * 32 + 8 * g + 4 * hh) = h4;
-        }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int qr = q0 + it * 8 + crow;
-        const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
-        if (qr < T) *(f16x8*)(obase + ooff[it]) = v;
-    }
+    if (STAG && wave >= 4) deferred = true;                            // written at the start of the next item (or after the loop)
+    else write_out(obase);
     }
     AT_STAMP(6)                                                        // scaled output (waits for the O^T MFMAs) + stores issued
     __syncthreads();      // every wave is done with this item's K / V^T before the next item overwrites them
     AT_STAMP(7)                                                        // barrier at the end of the item
     }
+    if (STAG && deferred) write_out(obase_of(item - (int)gridDim.x));   // the last item of a deferring wave
     if (TRACE && trace && lane == 0) {
         long long* o = trace + ((size_t)blockIdx.x * 7 + wave) * 8;
 #pragma unroll
