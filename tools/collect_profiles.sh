@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-BENCH="$GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline --no-roofline-pass --no-sequence-pass --no-extras"
+BENCH="$GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --blocks 1 --inflight 1 --no-cpu-baseline --no-roofline-pass --no-sequence-pass --no-extras"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $BENCH > $OUT.trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python3 $BENCH > $OUT.fetch.log 2>&1

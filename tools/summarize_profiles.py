@@ -22,7 +22,7 @@ def per_kernel(path, counter):
 fetch = per_kernel(os.path.join(src, 'fetch', 'bench_counter_collection.csv'), 'FETCH_SIZE')
 write = per_kernel(os.path.join(src, 'write', 'bench_counter_collection.csv'), 'WRITE_SIZE')
 stats = {r['Name']: r for r in csv.DictReader(open(os.path.join(src, 'trace', 'bench_kernel_stats.csv')))}
-out = {'tag': tag, 'command': 'bench.py --steps 4 --warmup 2 --inflight 1 --no-cpu-baseline --no-roofline-pass --no-sequence-pass --no-extras', 'kernels': {}}
+out = {'tag': tag, 'command': 'bench.py --steps 4 --warmup 2 --blocks 1 --inflight 1 --no-cpu-baseline --no-roofline-pass --no-sequence-pass --no-extras', 'kernels': {}}
 def group(match):
     g = {'launches': 0, 'fetch_kb': 0.0, 'write_kb': 0.0, 'dur_ns': 0.0, 'calls_trace': 0}
     for k in sorted(set(fetch) | set(write)):
