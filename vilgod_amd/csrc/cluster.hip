@@ -1634,8 +1634,8 @@ static void cl_launch_core(vg_cluster* h, int n, int k, hipStream_t st) {
 // smallest size at which the largest component sits a round out (k_cl_b_round_init): an eighth of the points
 static int cl_sit_min(int n) {
 #ifdef VG_DEV
-    static const int off = getenv("VG_CLUSTER_SITOUT") && atoi(getenv("VG_CLUSTER_SITOUT")) == 0;      // A/B aid (development build)
-    if (off) return 0x7FFFFFFF;
+    const char* e = getenv("VG_CLUSTER_SITOUT");           // A/B aid (development build), read per call: tools switch it inside one process
+    if (e && atoi(e) == 0) return 0x7FFFFFFF;
 #endif
     return std::max(2, n / 8);
 }

@@ -592,7 +592,7 @@ typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 // (softmax), then the matrix pipe again.  With STAG waves 0-3 issue the NEXT item's twelve loads after their S^T MFMAs (which run on
 // while the loads are issued) and waves 4-6 before theirs, as all waves did: the partners reach the softmax ~1-2 k cycles apart, one's
 // vector work beside the other's matrix work.  Same instructions per wave on the same data: bit-identical output.
-template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false, bool STAG = false>
+template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false, int STAG = 0>      // STAG 1: staggered loads; 2: + deferred output of waves 4-6
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
                                                        int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr,
                                                        int q_tiles = 7) {
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(Qs + r31 * AT_KLD + s * 16 + hh * 8);
     __syncthreads();
     AT_STAMP(0)                                                        // K / V^T into LDS + barrier
-    if (STAG && deferred) {                                            // (qf holds this item's Q fragments: the tile is free again)
+    if (STAG == 2 && deferred) {                                       // (qf holds this item's Q fragments: the tile is free again)
         write_out(obase_of(item - (int)gridDim.x));
         deferred = false;
     }
@@ -816,14 +816,14 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         }
     }
     AT_STAMP(5)                                                        // P -> fp16, V^T fragments, O^T MFMAs issued
-    if (STAG && wave >= 4) deferred = true;                            // written at the start of the next item (or after the loop)
+    if (STAG == 2 && wave >= 4) deferred = true;                       // written at the start of the next item (or after the loop)
     else write_out(obase);
     }
     AT_STAMP(6)                                                        // scaled output (waits for the O^T MFMAs) + stores issued
     __syncthreads();      // every wave is done with this item's K / V^T before the next item overwrites them
     AT_STAMP(7)                                                        // barrier at the end of the item
     }
-    if (STAG && deferred) write_out(obase_of(item - (int)gridDim.x));   // the last item of a deferring wave
+    if (STAG == 2 && deferred) write_out(obase_of(item - (int)gridDim.x));   // the last item of a deferring wave
     if (TRACE && trace && lane == 0) {
         long long* o = trace + ((size_t)blockIdx.x * 7 + wave) * 8;
 #pragma unroll
@@ -1019,7 +1019,7 @@ struct vg_vit {
     // temporary handle per call, i.e. read them per call on the caller's thread.
     int splitk_max = getenv("VG_GEMM_SPLITK") ? atoi(getenv("VG_GEMM_SPLITK")) : 0;          // opt-in split-K tail of the residual GEMMs (splitk_plan)
     bool att_tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);                    // attention: row-major V + transposing LDS reads
-    bool att_stagger = !(getenv("VG_ATT_STAGGER") && atoi(getenv("VG_ATT_STAGGER")) == 0);     // attention: SIMD partners half a phase apart (k_attention_f16 STAG)
+    int att_stagger = getenv("VG_ATT_STAGGER") ? atoi(getenv("VG_ATT_STAGGER")) : 1;           // attention: SIMD partners apart in phase (k_attention_f16 STAG: 0, 1, 2)
     bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
     int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
@@ -1667,15 +1667,22 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
 
 template <bool TRACE>
 static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st,
-                            int q_tiles = 7, bool tr = true, bool stagger = true) {
+                            int q_tiles = 7, bool tr = true, int stagger = 1) {
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
     // ViT-B/16: row-major V + transposing LDS reads (VG_ATT_TR=0: the transposed V image of rounds 1-2; same numbers, 1.6 % slower)
     // (tr: vg_vit::att_tr of the calling handle; tests run both paths in one process and compare them bit for bit)
-    if (T == 197 && !TRACE && tr && stagger) {
+    if (T == 197 && !TRACE && tr && stagger == 2) {
         const dim3 grid7(items < 256 ? items : 256);
-        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, true>), AT_LDS_BYTES_TR);
-        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, true>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, 2>), AT_LDS_BYTES_TR);
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, 2>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
+        VG_LAUNCH_CHECK();
+        return VG_OK;
+    }
+    if (T == 197 && !TRACE && tr && stagger == 1) {
+        const dim3 grid7(items < 256 ? items : 256);
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, 1>), AT_LDS_BYTES_TR);
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, 1>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
         VG_LAUNCH_CHECK();
         return VG_OK;
     }
@@ -2189,7 +2196,7 @@ int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int 
     const char* tr_env = getenv("VG_ATT_TR");           // handle-less test entry point: read per call, on the caller's thread
     const char* sg_env = getenv("VG_ATT_STAGGER");
     return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, n_crops * heads, nullptr, (hipStream_t)stream, 7,
-                                   !(tr_env && atoi(tr_env) == 0), !(sg_env && atoi(sg_env) == 0));
+                                   !(tr_env && atoi(tr_env) == 0), sg_env ? atoi(sg_env) : 1);
 }
 
 #ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces
