@@ -9,8 +9,7 @@ n, T, W, H = int(os.environ.get('CROPS', '337')), 197, 768, 12
 ld = 3 * W + 64
 qkv = (torch.randn(n * T, ld, device=dev) * 1.0).half()
 out = torch.zeros(n * T, W, dtype=torch.float16, device=dev)
-variants = [('stagger 1 (loads)', {'VG_ATT_STAGGER': '1', 'VG_ATT_TR': '1'}), ('stagger 2 (+ output)', {'VG_ATT_STAGGER': '2', 'VG_ATT_TR': '1'}),
-            ('no stagger', {'VG_ATT_STAGGER': '0', 'VG_ATT_TR': '1'}),
+variants = [('stagger', {'VG_ATT_STAGGER': '1', 'VG_ATT_TR': '1'}), ('no stagger', {'VG_ATT_STAGGER': '0', 'VG_ATT_TR': '1'}),
             ('transposed V image', {'VG_ATT_STAGGER': '0', 'VG_ATT_TR': '0'})]
 tot = {name: [] for name, _ in variants}
 sums = {}

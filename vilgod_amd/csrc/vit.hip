@@ -591,8 +591,10 @@ typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
 // leave the staging barrier together, so they want the matrix pipe at the same time (S^T MFMAs), then the vector ALU at the same time
 // (softmax), then the matrix pipe again.  With STAG waves 0-3 issue the NEXT item's twelve loads after their S^T MFMAs (which run on
 // while the loads are issued) and waves 4-6 before theirs, as all waves did: the partners reach the softmax ~1-2 k cycles apart, one's
-// vector work beside the other's matrix work.  Same instructions per wave on the same data: bit-identical output.
-template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false, int STAG = 0>      // STAG 1: staggered loads; 2: + deferred output of waves 4-6
+// vector work beside the other's matrix work.  Same instructions per wave on the same data: bit-identical output.  Alone, 337 crops, variants
+// interleaved in one process: 96.0 us against 99.4 (331 crops: 94.7 / 98.2).  Measured and dropped: waves 4-6 ALSO deferring their output
+// phase to the start of the next item (the guide's full recipe; accumulators kept across the barrier): 98.3 us, no better than no stagger.
+template <bool TRACE = false, int NKB = 7, int TT = 0, bool TR = false, bool STAG = false>
 __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ qkv, f16* __restrict__ out, int T_arg,
                                                        int W, int heads, int ld, int n_items, long long* __restrict__ trace = nullptr,
                                                        int q_tiles = 7) {
@@ -651,34 +653,6 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
 #pragma unroll
         for (int it = 0; it < 4; ++it) vreg[it] = *(const f16x8*)(vbase + kvoff[it]);
     };
-    // STAG, waves 4-6: the OUTPUT phase of an item (scale by 1 / sum, rows through the wave's tile, stores) is deferred to the start of the
-    // next item's compute -- the accumulators wait in registers across the barrier -- so that these waves reach their S^T MFMAs a third of an
-    // item behind their SIMD partners (MI355X_MICROARCH.md, two waves per SIMD, item 9: "waves 4-7 defer each block's epilogue by one block")
-    f32x16 oacc[2];
-    float inv = 0.f;
-    bool deferred = false;
-    auto write_out = [&](f16* ob) {
-        // output rows through the wave's tile: a lane's 4-feature pieces in, 16-byte parts of whole 128-byte rows out
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 h4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
-                *(f16x4*)(Qs + r31 * AT_KLD + dt * 32 + 8 * g + 4 * hh) = h4;
-            }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int qr = q0 + it * 8 + crow;
-            const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
-            if (qr < T) *(f16x8*)(ob + ooff[it]) = v;
-        }
-    };
-    auto obase_of = [&](int it_) {
-        const int crop_ = it_ / heads, head_ = it_ - crop_ * heads;
-        return out + (size_t)crop_ * T * W + head_ * 64;
-    };
     int item = blockIdx.x;
     if (item < n_items) fetch(item);
     for (; item < n_items; item += gridDim.x) {
@@ -709,10 +683,6 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
     for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(Qs + r31 * AT_KLD + s * 16 + hh * 8);
     __syncthreads();
     AT_STAMP(0)                                                        // K / V^T into LDS + barrier
-    if (STAG == 2 && deferred) {                                       // (qf holds this item's Q fragments: the tile is free again)
-        write_out(obase_of(item - (int)gridDim.x));
-        deferred = false;
-    }
     const bool has_next = item + (int)gridDim.x < n_items;
     const bool computes = q0 < T && wave < q_tiles;   // (q_tiles: query tiles wanted -- 1 in the last block, whose class-token row alone is used)
     const bool late = STAG && wave < 4 && computes;   // this wave issues the next item's loads behind its S^T MFMAs
@@ -781,9 +751,10 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         }
     }
     sum += __shfl_xor(sum, 32);
-    inv = 1.0f / sum;
+    const float inv = 1.0f / sum;
     AT_STAMP(4)                                                        // exp pass
 
+    f32x16 oacc[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -816,14 +787,27 @@ __global__ __launch_bounds__(448) void k_attention_f16(const f16* __restrict__ q
         }
     }
     AT_STAMP(5)                                                        // P -> fp16, V^T fragments, O^T MFMAs issued
-    if (STAG == 2 && wave >= 4) deferred = true;                       // written at the start of the next item (or after the loop)
-    else write_out(obase);
+    // output rows through the wave's tile: a lane's 4-feature pieces in, 16-byte parts of whole 128-byte rows out
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x4 h4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h4[e] = (f16)(oacc[dt][4 * g + e] * inv);
+            *(f16x4*)(Qs + r31 * AT_KLD + dt * 32 + 8 * g + 4 * hh) = h4;
+        }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int qr = q0 + it * 8 + crow;
+        const f16x8 v = *(const f16x8*)(Qs + (it * 8 + crow) * AT_KLD + cpart * 8);
+        if (qr < T) *(f16x8*)(obase + ooff[it]) = v;
+    }
     }
     AT_STAMP(6)                                                        // scaled output (waits for the O^T MFMAs) + stores issued
     __syncthreads();      // every wave is done with this item's K / V^T before the next item overwrites them
     AT_STAMP(7)                                                        // barrier at the end of the item
     }
-    if (STAG == 2 && deferred) write_out(obase_of(item - (int)gridDim.x));   // the last item of a deferring wave
     if (TRACE && trace && lane == 0) {
         long long* o = trace + ((size_t)blockIdx.x * 7 + wave) * 8;
 #pragma unroll
@@ -1019,7 +1003,7 @@ struct vg_vit {
     // temporary handle per call, i.e. read them per call on the caller's thread.
     int splitk_max = getenv("VG_GEMM_SPLITK") ? atoi(getenv("VG_GEMM_SPLITK")) : 0;          // opt-in split-K tail of the residual GEMMs (splitk_plan)
     bool att_tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);                    // attention: row-major V + transposing LDS reads
-    int att_stagger = getenv("VG_ATT_STAGGER") ? atoi(getenv("VG_ATT_STAGGER")) : 1;           // attention: SIMD partners apart in phase (k_attention_f16 STAG: 0, 1, 2)
+    bool att_stagger = !(getenv("VG_ATT_STAGGER") && atoi(getenv("VG_ATT_STAGGER")) == 0);     // attention: SIMD partners apart in phase (k_attention_f16 STAG)
     bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
     int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
@@ -1667,22 +1651,15 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
 
 template <bool TRACE>
 static int launch_attention(const f16* qkv, f16* out, int T, int W, int heads, int ld, int items, long long* trace, hipStream_t st,
-                            int q_tiles = 7, bool tr = true, int stagger = 1) {
+                            int q_tiles = 7, bool tr = true, bool stagger = true) {
     const int nkb = (T + 31) / 32;
     if (nkb < 1 || nkb > 7) return VG_ERR_ARG;
     // ViT-B/16: row-major V + transposing LDS reads (VG_ATT_TR=0: the transposed V image of rounds 1-2; same numbers, 1.6 % slower)
     // (tr: vg_vit::att_tr of the calling handle; tests run both paths in one process and compare them bit for bit)
-    if (T == 197 && !TRACE && tr && stagger == 2) {
+    if (T == 197 && !TRACE && tr && stagger) {
         const dim3 grid7(items < 256 ? items : 256);
-        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, 2>), AT_LDS_BYTES_TR);
-        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, 2>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
-        VG_LAUNCH_CHECK();
-        return VG_OK;
-    }
-    if (T == 197 && !TRACE && tr && stagger == 1) {
-        const dim3 grid7(items < 256 ? items : 256);
-        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, 1>), AT_LDS_BYTES_TR);
-        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, 1>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
+        VG_MAX_DYNAMIC_LDS((k_attention_f16<false, 7, 197, true, true>), AT_LDS_BYTES_TR);
+        hipLaunchKernelGGL((k_attention_f16<false, 7, 197, true, true>), grid7, dim3(448), AT_LDS_BYTES_TR, st, qkv, out, T, W, heads, ld, items, trace, q_tiles);
         VG_LAUNCH_CHECK();
         return VG_OK;
     }
@@ -2196,7 +2173,7 @@ int vg_attention(const void* d_qkv, void* d_out, int n_crops, int T, int W, int 
     const char* tr_env = getenv("VG_ATT_TR");           // handle-less test entry point: read per call, on the caller's thread
     const char* sg_env = getenv("VG_ATT_STAGGER");
     return launch_attention<false>((const f16*)d_qkv, (f16*)d_out, T, W, heads, ld, n_crops * heads, nullptr, (hipStream_t)stream, 7,
-                                   !(tr_env && atoi(tr_env) == 0), sg_env ? atoi(sg_env) : 1);
+                                   !(tr_env && atoi(tr_env) == 0), !(sg_env && atoi(sg_env) == 0));
 }
 
 #ifdef VG_DEV      // development aids (tools/dev/vilgod_hip_dev.h): ablations, cycle-stamp traces
