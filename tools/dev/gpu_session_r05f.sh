@@ -5,8 +5,7 @@ TAG=${1:-r05b}
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; tail -n 3 $O/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -n 2 $O/smoke.txt
-timeout 600 python tools/ab_pipeline.py 48 3 conc2: conc3:VILGOD_VIT_CONCURRENCY=3 2>&1 | grep -E "median" > $O/ab_conc.txt; cat $O/ab_conc.txt
-AB_WORKERS=8 timeout 600 python tools/ab_pipeline.py 48 3 workers8: 2>&1 | grep -E "median" >> $O/ab_conc.txt; tail -n 1 $O/ab_conc.txt
 timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err; head -c 700 $O/bench_k20.json; echo
 timeout 1500 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err; head -c 700 $O/bench.json; echo
+timeout 600 bash tools/trace_cluster.sh > $O/cluster_trace.txt 2>&1; tail -n 30 $O/cluster_trace.txt
 timeout 1500 bash tools/collect_profiles.sh $TAG > $O/collect.txt 2>&1; tail -n 12 $O/collect.txt

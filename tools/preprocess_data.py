@@ -92,7 +92,8 @@ def main(argv=None):
                                    max_points=dev.get('max_points', 300_000), clip_model_path=cfg.paths.clip_model,
                                    min_range=ga['min_range'], z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666),
                                    box_mode=dev.get('box_mode', 'reference'), box_workers=dev.get('box_workers', 4),
-                                   angle_mode=dev.get('angle_mode', 'reference'), vit_graph=bool(dev.get('vit_graph', False)))
+                                   angle_mode=dev.get('angle_mode', 'reference'), vit_graph=bool(dev.get('vit_graph', False)),
+                                   cu_reserve=int(dev.get('cu_reserve', 0)), cu_tower=dev.get('cu_tower', 'complement'))
     logger.info(f'CLIP weights: {pipeline.clip.weights_source}')
 
     result_path = Path(cfg.paths.results) / cfg.results_folder / '_'.join(cfg.pipeline_active)
