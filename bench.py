@@ -26,7 +26,9 @@ steady state of a long-running stream: at least three passes, repeated until two
 run that way; not steps of the metric).  The ViT runs as plain stream launches (default) or
 as captured hipGraphs per crop-count bucket (`--vit-graph`; captures then happen INSIDE the timed region and are counted in
 `config.graphs_captured`).  The K timed frames include filling and draining the pipeline (small K therefore reads a little
-lower: the driver's K = 20 run vs the default K = 96).
+lower: the driver's K = 20 run vs the default K = 96).  `value` is the MEDIAN of `--blocks` (3) timed blocks of exactly K steps each, every
+block on its own K distinct clouds and bracketed by its own barrier + synchronize (`block_values`, `block_spread`; `ms_per_step` = the
+median block's time / K): one 0.3 s window on a shared box reads +-4 %.
 
 The JSON line also carries
   roofline      the dominant kernel (the ViT projection GEMM): algorithmic FLOPs / launch duration, measured live with HIP

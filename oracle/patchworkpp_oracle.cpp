@@ -12,7 +12,7 @@
 // frozen in tests/golden/ground_kitti.json as a regression pin, not as reference truth).
 //
 // Where the reference leaves arithmetic to Eigen (float sums of unspecified order, JacobiSVD) this
-// restatement fixes a NUMERIC MODEL that a GPU can reproduce bit for bit (DESIGN.md "ground numerics"):
+// restatement fixes a NUMERIC MODEL that a GPU can reproduce bit for bit (LAB_NOTES.md section 8, "Ground numerics"):
 //   * patch points are ordered by (z, original index)            [std::sort is unstable: tie order is
 //                                                                  unspecified in the reference]
 //   * sums for mean / covariance are float64 over exact float32 products, accumulated in the fixed

@@ -96,3 +96,33 @@ def test_two_frame_sequence_is_the_minimum(pipe):
     assert len(out) == 2
     for fs, res in out:
         assert fs.entropy_scores is not None and set(res) == {'boxes_lidar', 'name', 'score', 'moving'}
+
+
+@pytest.mark.gpu
+def test_cu_masked_stream_lifecycle_through_the_abi(cuda):
+    """vg_stream_create_cu_mask / vg_stream_destroy (include/vilgod_hip.h, "execution resources"): a stream restricted to one CU of every XCD
+    runs a kernel of the library (same result as on the default stream) and can be destroyed when nothing of torch's allocator refers to it;
+    an all-zero mask and a NULL argument are rejected."""
+    import ctypes
+    import numpy as np
+    import torch
+    from vilgod_amd._lib import lib, ptr
+    from vilgod_amd.streams import cu_mask_words, device_cu_count
+    n_cu = device_cu_count(cuda)
+    assert n_cu >= 16
+    words = cu_mask_words(n_cu, 1, 'front')
+    h = ctypes.c_void_p()
+    assert lib.vg_stream_create_cu_mask(ctypes.byref(h), words.ctypes.data_as(ctypes.c_void_p), len(words)) == 0 and h.value
+    pts = torch.randn(5000, 5, device=cuda)
+    T = torch.eye(4, dtype=torch.float64, device=cuda)
+    T[0, 3] = 2.5
+    a, b = torch.empty_like(pts), torch.empty_like(pts)
+    torch.cuda.synchronize()
+    assert lib.vg_ref_transform(ptr(pts), 5000, 5, ptr(T), ptr(a), h) == 0
+    assert lib.vg_ref_transform(ptr(pts), 5000, 5, ptr(T), ptr(b), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float((a[:, 0] - pts[:, 0]).mean()) == pytest.approx(2.5, abs=1e-5)
+    assert lib.vg_stream_destroy(h) == 0
+    zero = np.zeros(len(words), np.uint32)
+    assert lib.vg_stream_create_cu_mask(ctypes.byref(h), zero.ctypes.data_as(ctypes.c_void_p), len(zero)) == 1
+    assert lib.vg_stream_destroy(None) == 1

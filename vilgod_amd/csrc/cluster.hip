@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
     }
 }
 
-#ifdef VG_DEV      // measured slower than the walk alone: kept for the A/B tools only, untested in the product
+#ifdef VG_DEV      // measured slower than the walk alone (LAB_NOTES.md section 3, round 3): kept for the A/B tools only, untested in the product
 // Cooperative nearest-foreign search of a Boruvka round (same layout as k_cl_core_blk: one wave per (0.8 m node, 64 queries),
 // lane = query, the 27 neighbour nodes staged in LDS by coalesced loads: coordinates as float64, component id, squared core
 // distance, original id).  A lane keeps the best edge (w, d2, key) it has met under the walk's strict order.  Everything outside
@@ -1651,7 +1651,7 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
 #ifdef VG_DEV
     // VG_CLUSTER_SEARCH_MODE (A/B aid, development build): 0 = the tree walk alone, 1 = cooperative search, leftovers walk as a compacted
     // list, 2 = cooperative search, leftovers walk in place.  Measured on 150k-point frames the cooperative search + the leftover walks
-    // take longer than the walk alone
+    // take longer than the walk alone (LAB_NOTES.md section 3)
     static const int mode = getenv("VG_CLUSTER_SEARCH_MODE") ? atoi(getenv("VG_CLUSTER_SEARCH_MODE")) : 0;
     static const int core_walk = getenv("VG_CLUSTER_CORE_WALK") ? atoi(getenv("VG_CLUSTER_CORE_WALK")) : 0;  // (no work list then)
     if (mode != 0 && !core_walk) {

@@ -1432,7 +1432,7 @@ static int gemm_chunk_tiles_256(int ntn) {
     return cw;
 }
 
-#ifdef VG_DEV      // measured slower than k_gemm_f16_pp64 on every projection shape: development build only (VG_GEMM_X2=1)
+#ifdef VG_DEV      // measured slower than k_gemm_f16_pp64 on every projection shape (LAB_NOTES.md section 3, round 3): development build only (VG_GEMM_X2=1)
 #include "dev/vit_gemm_x2.inc"
 #endif  // VG_DEV
 
