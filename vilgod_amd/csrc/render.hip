@@ -308,10 +308,19 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
     // 3x3 Gaussian (mv_utils.py:204-220, sigma=3): float32 values as torch computes them
     const float g_c = a.lut[768 + 0], g_e = a.lut[768 + 1], g_m = a.lut[768 + 2];  // corner, edge, middle
 
+    // Per slice only the footprint of its points is processed (round 5: the 110 x 110 passes over a slice that holds a car's side at one
+    // depth -- a few thousand of the 12 100 pixels -- were most of the kernel's 206 us).  Raw slice S: nonzero only inside the bounding box
+    // [r0, r1] x [c0, c1] of the cells its points fall into; row-pooled T: rows [r0 - 4, r1 + 4] (zero rows included, so nothing stale is
+    // read), columns [c0 - 3, c1 + 1]; pooled image, written back into S with the RAW row stride: [r0 - 3, r1 + 1] x [c0 - 3, c1 + 1], which
+    // covers the raw box for every index the convolution reads (< 110), everything else of S is still the zeroed slice; convolution output:
+    // [r0 - 4, r1 + 2] x [c0 - 4, c1 + 2].  Outside those ranges the dense passes produced exact zeros and max(acc, 0) = acc: same bits.
+    __shared__ int bb[4];            // r0, r1, c0, c1 of the current slice
     for (int d = 0; d < 8; ++d) {
         if (!((smask >> d) & 1u)) continue;   // empty slice: pool/conv give 0, acc >= 0 already
         for (int i = tid; i < GR * GR; i += RT) S[i] = 0.0f;
+        if (tid == 0) { bb[0] = GR; bb[1] = -1; bb[2] = GR; bb[3] = -1; }
         __syncthreads();
+        int r0 = GR, r1 = -1, c0 = GR, c1 = -1;
         for (int i = tid; i < P; i += RT) {
             float x = pts[i * 3 + 0], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
             float pv0 = fmaf(z, r[6], fmaf(y, r[3], x * r[0]));
@@ -321,29 +330,44 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
             float val;
             quantise_point(pv0, pv1, pv2, pc, prange, gx, gy, gz, val);
             // grid[z][y][x] then permute(0,1,3,2): image row = x, column = y (mv_utils.py:120-125)
-            if (gz == d) atomicMax((int*)&S[gx * GR + gy], __float_as_int(val));
+            if (gz == d) {
+                atomicMax((int*)&S[gx * GR + gy], __float_as_int(val));
+                r0 = min(r0, gx); r1 = max(r1, gx); c0 = min(c0, gy); c1 = max(c1, gy);
+            }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            r0 = min(r0, __shfl_xor(r0, o)); r1 = max(r1, __shfl_xor(r1, o));
+            c0 = min(c0, __shfl_xor(c0, o)); c1 = max(c1, __shfl_xor(c1, o));
+        }
+        if (lane == 0 && r1 >= 0) { atomicMin(&bb[0], r0); atomicMax(&bb[1], r1); atomicMin(&bb[2], c0); atomicMax(&bb[3], c1); }
         __syncthreads();
+        r0 = bb[0]; r1 = bb[1]; c0 = bb[2]; c1 = bb[3];
+        const int tj0 = max(c0 - 3, 0), tj1 = min(c1 + 1, GO - 1), tw = tj1 - tj0 + 1;          // columns of T and of the pooled image
+        const int ti0 = max(r0 - 4, 0), ti1 = min(r1 + 4, GR - 1);                                  // rows of T
         // MaxPool3d (1,5,5) pad (0,1,1): window [i-1, i+3] x [j-1, j+3]; separable.
-        for (int q = tid; q < GR * GO; q += RT) {
-            int i = q / GO, j = q - i * GO;
+        for (int q = tid; q < (ti1 - ti0 + 1) * tw; q += RT) {
+            const int di = q / tw;
+            const int i = ti0 + di, j = tj0 + (q - di * tw);
             const float* row = S + i * GR;
             float m = row[j];                       // j-1+1 .. (j in [0,110) -> cols j-1..j+3)
             if (j >= 1) m = fmaxf(m, row[j - 1]);
             m = fmaxf(m, row[j + 1]);
             m = fmaxf(m, row[j + 2]);
             if (j + 3 < GR) m = fmaxf(m, row[j + 3]);
-            T[q] = m;
+            T[i * GO + j] = m;
         }
         __syncthreads();
-        for (int q = tid; q < GO * GO; q += RT) {
-            int i = q / GO, j = q - i * GO;
+        const int pi0 = max(r0 - 3, 0), pi1 = min(r1 + 1, GO - 1);                                  // rows of the pooled image
+        for (int q = tid; q < (pi1 - pi0 + 1) * tw; q += RT) {
+            const int di = q / tw;
+            const int i = pi0 + di, j = tj0 + (q - di * tw);
             float m = T[i * GO + j];
             if (i >= 1) m = fmaxf(m, T[(i - 1) * GO + j]);
             m = fmaxf(m, T[(i + 1) * GO + j]);
             m = fmaxf(m, T[(i + 2) * GO + j]);
             if (i + 3 < GR) m = fmaxf(m, T[(i + 3) * GO + j]);
-            S[q] = m;   // pooled [110][110]
+            S[i * GR + j] = m;   // pooled, raw row stride
         }
         __syncthreads();
         // Conv3d (1,3,3) zero pad, FMA chain in row-major tap order; running max over depth.
@@ -351,18 +375,20 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
         // the slice loop and keeps them live across the whole kernel -- 46 spilled registers, their traffic doubled the bytes written)
         int tq = tid;
         asm volatile("" : "+v"(tq));
+        const int ci0 = max(r0 - 4, 0), ci1 = min(r1 + 2, GO - 1), cj0 = max(c0 - 4, 0), cj1 = min(c1 + 2, GO - 1);
 #pragma unroll
         for (int k = 0; k < ACC_PER_THREAD; ++k) {
             int q = tq + k * RT;
             if (q < GO * GO) {
                 int i = q / GO, j = q - i * GO;
+                if (i < ci0 || i > ci1 || j < cj0 || j > cj1) continue;      // the dense pass gives exactly 0 here
                 float s[9];
 #pragma unroll
                 for (int di = 0; di < 3; ++di)
 #pragma unroll
                     for (int dj = 0; dj < 3; ++dj) {
                         int ii = i + di - 1, jj = j + dj - 1;
-                        s[di * 3 + dj] = (ii >= 0 && ii < GO && jj >= 0 && jj < GO) ? S[ii * GO + jj] : 0.0f;
+                        s[di * 3 + dj] = (ii >= 0 && ii < GO && jj >= 0 && jj < GO) ? S[ii * GR + jj] : 0.0f;
                     }
                 float o = s[0] * g_c;
                 o = fmaf(s[1], g_e, o);
