@@ -180,6 +180,7 @@ struct RenderArgs {
     const float* lut;      // [3,256] CLIP-normalised value of each uint8 level
     void* out;
     int n_views;
+    int n_clusters;
     int out_kind;          // 0: uint8 [n,224,224,3] (PIL layout)  1: f32 [n,3,224,224]  2: f16 [n,3,224,224]
                            // 3: f32 [n,110,110] = one channel of get_img() before the resize
                            // 4: f16 patch rows [n*196, 768] = the im2col of kind 2 for 16x16 patches (ViT-B/16 input of
@@ -222,7 +223,27 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
 
     const int tid = threadIdx.x;
     const int V = a.n_views;
-    const int c = blockIdx.x / V, v = blockIdx.x % V;
+    // LARGEST CLUSTERS FIRST (round 5): workgroup b renders the cluster of rank b / V by point count.  One workgroup owns a CU (~100 KB of
+    // LDS) and a frame's ~340 workgroups run in two rounds on 256 CUs: in label order a 15 000-point wall that starts in the second round
+    // ends the launch long after everything else; started first, the short ones fill in behind it.  The rank is recomputed by every
+    // workgroup from the offsets (C <= a few hundred: C^2 / 1024 compares per thread) -- no scratch buffer, no extra launch; the crop a
+    // workgroup writes is still cluster * V + view.
+    __shared__ int s_cluster;
+    {
+        const int C = a.n_clusters, want = (int)blockIdx.x / V;
+        for (int t = tid; t < C; t += RT) {
+            const int sz = a.seg_off[t + 1] - a.seg_off[t];
+            int rank = 0;
+            for (int u = 0; u < C; ++u) {
+                const int su = a.seg_off[u + 1] - a.seg_off[u];
+                rank += (su > sz || (su == sz && u < t)) ? 1 : 0;
+            }
+            if (rank == want) s_cluster = t;
+        }
+        __syncthreads();
+    }
+    const int c = s_cluster, v = blockIdx.x % V;
+    const int crop_id = c * V + v;
     const int p0 = a.seg_off[c], P = a.seg_off[c + 1] - p0;
     const float* pts = a.origin + (size_t)p0 * 3;
     float r[9];
@@ -426,14 +447,14 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
     }
     __syncthreads();
     if (a.out_kind == 3) {   // raw get_img() image, one channel: f32 [n,110,110]
-        float* of = (float*)a.out + (size_t)blockIdx.x * GO * GO;
+        float* of = (float*)a.out + (size_t)crop_id * GO * GO;
         for (int q = tid; q < GO * GO; q += RT) of[q] = T[q];
         return;
     }
 
     // ---- D5 + D6: bilinear 110 -> 224, H<->W swap, uint8 truncation, CLIP normalise ---------
     // T_out[ch][i][j] = norm_ch( uint8( 255 * interp[h = j][w = i] ) )
-    const size_t crop = blockIdx.x;
+    const size_t crop = (size_t)crop_id;
     for (int q4 = tid; q4 < OUT * OUT / 4; q4 += RT) {
         int i = q4 / (OUT / 4);
         int j0 = (q4 - i * (OUT / 4)) * 4;
@@ -589,6 +610,7 @@ int vg_render_crops(const float* d_origin, const int32_t* d_seg_off, int n_clust
     a.lut = d_lut;
     a.out = d_out;
     a.n_views = n_views;
+    a.n_clusters = n_clusters;
     a.out_kind = out_kind;
     hipLaunchKernelGGL(k_render, dim3(n_clusters * n_views), dim3(RT), lds_bytes, (hipStream_t)stream, a);
     VG_LAUNCH_CHECK();
