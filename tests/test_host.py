@@ -296,3 +296,66 @@ def test_pack_clusters_host_equals_numpy_form():
         got, want = pack_clusters(lab, pr, 0.3), pack_clusters_numpy(lab, pr, 0.3)
         for g, w in zip(got, want):
             assert g.dtype == w.dtype and np.array_equal(g, w)
+
+
+def test_profile_summary_splits_the_projection_gemm_per_kind(tmp_path):
+    """tools/summarize_profiles.py (VERDICT r4 task 2: FETCH / WRITE / SQ counters per GEMM KIND): a fabricated rocprofv3 run -- two frames of two
+    blocks each, the instantiations' mangled names as the product library emits them, out_proj and c_proj sharing one instantiation and
+    alternating in dispatch order, plus the small class-token launches of the last block -- must come out with each kind's own time, bytes
+    and MFMA utilisation, and the small launches must not be counted."""
+    import csv
+    import json
+    src, dst = tmp_path / 'prof', tmp_path / 'out'
+    for d in ('trace', 'fetch', 'write', 'sq'):
+        (src / d).mkdir(parents=True)
+    name = lambda epi, ln: f'_Z15k_gemm_f16_pp64ILi{epi}ELb0ELb0ELi{ln}ELb0EEvPKDF16_S1_PKfPvPfiiiiiPxS3_P9LnPartialPDF16_i'
+    rows_m = 65536                                            # 256 row tiles
+    kinds = {'in_proj': (name(0, 1), 9, 270_000, 100.0, 300.0, 0.45), 'out_proj': (name(2, 2), 3, 160_000, 330.0, 300.0, 0.22),
+             'c_fc': (name(1, 1), 12, 400_000, 110.0, 400.0, 0.42), 'c_proj': (name(2, 2), 3, 350_000, 740.0, 301.0, 0.46)}
+    disp = []
+    for frame in range(2):
+        for block in range(2):
+            for k in ('in_proj', 'out_proj', 'c_fc', 'c_proj'):
+                disp.append((k, kinds[k][0], (rows_m // 256) * kinds[k][1] * 512))
+        disp += [('small', name(2, 2), 2 * 3 * 512), ('small', name(1, 1), 2 * 12 * 512)]      # class-token rows of the last block
+    trace, fetch, write, sq = [], [], [], []
+    t = 1_000_000
+    for did, (k, nm, grid) in enumerate(disp, start=1):
+        dur = kinds[k][2] if k in kinds else 30_000
+        trace.append({'Kind': 'KERNEL_DISPATCH', 'Dispatch_Id': did, 'Kernel_Name': nm, 'Start_Timestamp': t, 'End_Timestamp': t + dur, 'Grid_Size_X': grid})
+        base = {'Dispatch_Id': did, 'Kernel_Name': nm, 'Grid_Size': grid, 'Start_Timestamp': t, 'End_Timestamp': t + 2 * dur}
+        f_mb, w_mb, util = (kinds[k][3], kinds[k][4], kinds[k][5]) if k in kinds else (1.0, 1.0, 0.05)
+        fetch.append(dict(base, Counter_Name='FETCH_SIZE', Counter_Value=f_mb * 1e6 / 2048))             # KB, under-reported x2 on gfx950
+        write.append(dict(base, Counter_Name='WRITE_SIZE', Counter_Value=w_mb * 1e6 / 1024))
+        gui = 8 * 2 * dur * 2.0                                                                          # 8 XCDs x ns x GHz
+        for cn, cv in (('GRBM_GUI_ACTIVE', gui), ('SQ_VALU_MFMA_BUSY_CYCLES', util * gui / 8 * 1024), ('SQ_WAVE_CYCLES', 1000.0), ('SQ_WAIT_ANY', 300.0),
+                       ('SQ_WAIT_INST_ANY', 400.0), ('SQ_ACTIVE_INST_ANY', 300.0), ('SQ_BUSY_CYCLES', 1.0)):
+            sq.append(dict(base, Counter_Name=cn, Counter_Value=cv))
+        t += 3 * dur
+
+    def dump(path, rows):
+        with open(path, 'w', newline='') as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    dump(src / 'trace' / 'bench_kernel_trace.csv', trace)
+    dump(src / 'fetch' / 'bench_counter_collection.csv', fetch)
+    dump(src / 'write' / 'bench_counter_collection.csv', write)
+    dump(src / 'sq' / 'bench_counter_collection.csv', sq)
+    stats = {}
+    for r in trace:
+        st = stats.setdefault(r['Kernel_Name'], [0, 0])
+        st[0] += 1
+        st[1] += r['End_Timestamp'] - r['Start_Timestamp']
+    dump(src / 'trace' / 'bench_kernel_stats.csv', [{'Name': k, 'Calls': c, 'TotalDurationNs': d, 'AverageNs': d / c} for k, (c, d) in stats.items()])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'summarize_profiles.py'), 'tst'], capture_output=True, text=True,
+                       env=dict(os.environ, VG_PROFILE_SRC=str(src), VG_PROFILE_OUT=str(dst)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.load(open(dst / 'tst_pmc_summary.json'))['k_gemm_f16_pp64_by_kind']
+    assert set(out) == set(kinds)
+    for k, (_, ntn, dur, f_mb, w_mb, util) in kinds.items():
+        o = out[k]
+        assert o['launches'] == 4 and o['avg_rows'] == rows_m and abs(o['avg_launch_us'] - dur / 1e3) < 0.1
+        assert abs(o['fetch_bytes_corrected_x2'] - f_mb * 1e6) < 1e3 and abs(o['write_bytes'] - w_mb * 1e6) < 1e3
+        assert abs(o['mfma_utilisation'] - util) < 1e-3 and abs(o['sustained_ghz'] - 2.0) < 1e-3
+    assert json.load(open(dst / 'gemm_traffic.json'))['by_kind']['out_proj']['avg_launch_us'] == out['out_proj']['avg_launch_us']

@@ -5,7 +5,7 @@ tallied at 64 B); we report both the raw and the corrected (x2) figure, WRITE_SI
 import csv, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, 'gpurun_out', f'prof_{tag}')
+src = os.environ.get('VG_PROFILE_SRC', os.path.join(root, 'gpurun_out', f'prof_{tag}'))     # (override: tests/test_host.py feeds it a fabricated run)
 dst = os.environ.get('VG_PROFILE_OUT', os.path.join(root, 'profiles'))      # on the GPU box: a directory under gpurun_out/ (comes back)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), os.path.join(dst, f'{tag}_bench_kernel_stats.csv'))
