@@ -496,6 +496,7 @@ def main():
             'value': round(value, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': args.warmup,
             'blocks': B, 'block_values': [round(frames_total / e, 3) for e in block_elapsed],
             'block_spread': round((max(block_elapsed) - min(block_elapsed)) / elapsed, 4),
+            'block_crops_per_frame': [round(sum(p_.shape[0] for _, _, p_ in o) / max(len(o), 1), 1) for _, o in blocks_run],      # the blocks' clouds differ: ms per frame follows the crop count
             'ms_per_step': round(1000.0 * elapsed / K, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f16' if args.dtype == 'f16' else 'f32', 'data': 'synthetic',
             'config': {
