@@ -382,8 +382,8 @@ def main():
             dt_s = time.perf_counter() - t_s
             pipe.new_sequence()
             setup_passes += 1
-            # (round 5: at least three passes and 3 % instead of two and 5 % -- with K = 20 the three timed blocks of one run read 62.2 / 65.6 /
-            # 66.6 and 63.7 / 66.1 / 68.5 frames/s: the process was still warming up -- allocator, clocks, host threads -- when the clock started)
+            # (round 5: at least three passes and 3 % instead of two and 5 %.  It does not change what the timed blocks read -- their spread,
+            # 63.5 / 67 / 68.5 frames/s at K = 20, is the blocks' DATA: 337.6 / 328.4 / 323.6 crops per frame, `block_crops_per_frame`)
             if setup_passes >= 3 and last is not None and abs(dt_s - last) <= 0.03 * last:
                 break
             last = dt_s

@@ -65,8 +65,7 @@ class VitEncoder:
             # every exact-size regrowth was a fresh ~1.5 GB allocation + fill on the worker's stream (and the old block stays in the
             # caching allocator's pool)
             # (round 5: + an eighth of headroom -- a worker whose first frames held 310 crops got a 320-crop workspace and paid the
-            # regrowth, a device-synchronising 1.5 GB hipMalloc, on its first 330-crop frame, typically inside a timed block: the first of a
-            # run's three 20-frame blocks read 5 % below the third; 288 GB of HBM hold the headroom of every worker)
+            # regrowth, a device-synchronising 1.5 GB hipMalloc, on its first 330-crop frame; 288 GB of HBM hold the headroom of every worker)
             cap = (n + max(32, n // 8) + 63) // 64 * 64
             nbytes = lib.vg_vit_workspace_bytes(self._h, cap)
             self._ws = None
