@@ -794,9 +794,17 @@ __global__ void k_cl_b_round_init(int n, const int* __restrict__ comp, unsigned 
         best_e[i] = ~0ull;
         sel_a[i] = -1;
         if (comp[i] == i) mine = ((unsigned long long)(unsigned int)csize[i] << 32) | (unsigned int)i;
-        // level-0 purity, first half: the first point of a cell writes its component; k_cl_b_purity (a later launch) overwrites the
-        // entry with -1 where two neighbours inside the cell disagree
-        if (i == 0 || code_s[i - 1] != code_s[i]) cell_comp[code_s[i]] = comp[i];
+        // purity tables, first half: the first point of every node of levels 0 .. 3 writes its component; k_cl_b_purity (a later launch)
+        // overwrites the entry with -1 where two neighbours inside the node disagree
+        {
+            const unsigned int code = code_s[i], prev = i > 0 ? code_s[i - 1] : ~code;
+            size_t off = 0;
+#pragma unroll
+            for (int l = 0; l < CL_PUR_LEVELS; ++l) {
+                if (i == 0 || (prev >> (3 * l)) != (code >> (3 * l))) cell_comp[off + (code >> (3 * l))] = comp[i];
+                off += (size_t)CL_NCODES >> (3 * l);
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -822,39 +830,24 @@ __device__ __forceinline__ size_t cl_pur_off(int l) {   // offset of level l ins
     return o;
 }
 
-// Level-0 purity tables: cell_comp[c] = the component that owns every point of cell c, or -1.  All points of a cell agree iff every two
-// neighbours in the sorted order agree: k_cl_b_round_init wrote the first point's component, a thread whose point differs from its
-// predecessor in the same cell writes -1 (same value from every writer).  (Rounds 1-4: the first point's thread walked the whole cell --
-// 29.5 us per launch on average, 79 at worst, for the densest cells' serial loops; now one compare per thread.)
+// Purity tables, levels 0 .. 3: entry = the component that owns every point of the node, or -1.  All points of a node agree iff every two
+// neighbours in the sorted order agree: k_cl_b_round_init wrote the first point's component at every level, a thread whose point differs
+// from its predecessor writes -1 at every level at which the two share a node (same value from every writer).  (Rounds 1-4: the first point
+// of a cell walked the whole cell -- 29.5 us per launch, 80 at worst -- and three more launches built levels 1 .. 3 from the level below:
+// 0.33 ms and 28 launches per frame; now one compare per thread and one launch per round.)
 __global__ void k_cl_b_purity(int n, const unsigned int* __restrict__ code_s, const int* __restrict__ comp,
                               int* __restrict__ cell_comp, const int* __restrict__ flags) {
     if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || i == 0) return;
-    const unsigned int c = code_s[i];
-    if (code_s[i - 1] == c && comp[i - 1] != comp[i]) cell_comp[c] = -1;
-}
-
-// level l >= 1 from level l-1: thread per OCCUPIED level-l cell (first point of the cell)
-__global__ void k_cl_b_purity_up(int n, int l, const unsigned int* __restrict__ code_s, const int* __restrict__ cs,
-                                 int* __restrict__ cell_comp, const int* __restrict__ flags) {
-    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned int key = code_s[i] >> (3 * l);
-    if (i > 0 && (code_s[i - 1] >> (3 * l)) == key) return;
-    const int* below = cell_comp + cl_pur_off(l - 1);
-    int pure = -2;
-    for (unsigned int ch = 0; ch < 8; ++ch) {
-        const unsigned int ck = key * 8 + ch;                          // child key at level l-1
-        const unsigned int c0 = ck << (3 * (l - 1));
-        if (cl_start_l(cs, l - 1, c0 >> (3 * (l - 1))) == cl_start_l(cs, l - 1, (c0 >> (3 * (l - 1))) + 1u)) continue;   // empty child
-        const int p = below[ck];
-        if (p < 0) { pure = -1; break; }
-        if (pure == -2) pure = p;
-        else if (pure != p) { pure = -1; break; }
+    if (comp[i - 1] == comp[i]) return;
+    const unsigned int c = code_s[i], p = code_s[i - 1];
+    size_t off = 0;
+#pragma unroll
+    for (int l = 0; l < CL_PUR_LEVELS; ++l) {
+        if ((p >> (3 * l)) == (c >> (3 * l))) cell_comp[off + (c >> (3 * l))] = -1;
+        off += (size_t)CL_NCODES >> (3 * l);
     }
-    cell_comp[cl_pur_off(l) + key] = pure;
 }
 
 __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
@@ -1311,17 +1304,10 @@ __global__ void k_cl_b_pick(int n, const int* __restrict__ comp, const unsigned 
         sel_b[c] = pt_b[a];
     }
 }
-__global__ void k_cl_b_link(int n, const int* __restrict__ comp, const int* __restrict__ sel_a,
-                            const int* __restrict__ sel_b, int* __restrict__ parent, const int* __restrict__ flags) {
-    if (flags[1]) return;                 // the tree was complete before this round: queued ahead without a host read
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    if (comp[c] != c) return;
-    parent[c] = (sel_a[c] >= 0) ? comp[sel_b[c]] : c;
-}
-
-__global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __restrict__ parent,
-                            const int* __restrict__ sel_a, const int* __restrict__ sel_b,
+// Every component root c with a pick hooks onto the component its edge leads to: parent(c) = comp[sel_b[c]] (c itself without a pick).  The
+// two roots of a mutual pair chose the same edge: the smaller id becomes the root, its partner emits the edge.  (Until round 5 the parents were
+// written by a launch of their own, k_cl_b_link; they are a function of the picks, which are complete when this kernel starts.)
+__global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __restrict__ sel_a, const int* __restrict__ sel_b,
                             const unsigned long long* __restrict__ best_w, const int* __restrict__ perm,
                             int* __restrict__ parent2, int* __restrict__ counter, int* __restrict__ mst_a,
                             int* __restrict__ mst_b, unsigned long long* __restrict__ mst_w, const int* __restrict__ flags) {
@@ -1329,9 +1315,10 @@ __global__ void k_cl_b_emit(int n, const int* __restrict__ comp, const int* __re
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     if (comp[c] != c) return;
-    const int p = parent[c];
+    auto parent_of = [&](int r) { return sel_a[r] >= 0 ? comp[sel_b[r]] : r; };
+    const int p = parent_of(c);
     if (p == c) { parent2[c] = c; return; }
-    const bool mutual = parent[p] == c;
+    const bool mutual = parent_of(p) == c;
     if (mutual && c < p) {
         parent2[c] = c;            // the smaller id of a mutual pair becomes the root; its partner emits the edge
         return;
@@ -1771,8 +1758,6 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
         if (r > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);
-        for (int l = 1; l < CL_PUR_LEVELS; ++l)
-            hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp, flags);
         if (dim == 3) cl_launch_search<3>(h, n, st);
         else if (dim == 4) cl_launch_search<4>(h, n, st);
         else cl_launch_search<5>(h, n, st);
@@ -1782,9 +1767,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
             hipLaunchKernelGGL(k_cl_seedsim_drop, dim3(nb), dim3(256), 0, st, n, h->d_core2, h->d_pt_w, h->d_pt_b, h->d_counter);
             hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
             hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
-            hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);   // (round_init rewrote level 0)
-            for (int l = 1; l < CL_PUR_LEVELS; ++l)
-                hipLaunchKernelGGL(k_cl_b_purity_up, dim3(nb), dim3(256), 0, st, n, l, h->d_code_s, h->d_cell_start, h->d_cell_comp, flags);
+            hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);   // (round_init rewrote the pure values)
             if (dim == 3) cl_launch_search<3>(h, n, st);          // walks only the points that were not seedable
             else if (dim == 4) cl_launch_search<4>(h, n, st);
             else cl_launch_search<5>(h, n, st);
@@ -1799,8 +1782,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
                            h->d_pt_key, h->d_best_e, flags);
         hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_pt_w,
                            h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b, flags, h->d_giant, cl_sit_min(n));
-        hipLaunchKernelGGL(k_cl_b_link, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_parent, flags);
-        hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent, h->d_sel_a, h->d_sel_b, h->d_best_w,
+        hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_best_w,
                            h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, flags);
         hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags, h->d_aux, h->d_csize, h->d_giant);
         return hipMemcpyAsync(h->h_counter + ((r - 1) & 15), h->d_counter, 4, hipMemcpyDeviceToHost, st);
