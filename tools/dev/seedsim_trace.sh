@@ -6,11 +6,13 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/seedsim
 cd /tmp && export TMPDIR=/tmp
 export VILGOD_HIP_LIB=$GRAFT_REPO_ROOT/vilgod_amd/libvilgod_hip_dev.so
-for mode in seedsim sitout_on sitout_off; do
+for mode in ${MODES:-seedsim sitout_on sitout_off}; do
   case $mode in
     seedsim) export VG_CLUSTER_SEEDSIM=1; unset VG_CLUSTER_SITOUT;;
     sitout_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT;;
     sitout_off) unset VG_CLUSTER_SEEDSIM; export VG_CLUSTER_SITOUT=0;;
+    xcd_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_XCD_ORDER=1;;
+    xcd_off) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_XCD_ORDER=0;;
   esac
   rocprofv3 --kernel-trace --output-format csv -d $OUT/$mode -o cl -- python3 $GRAFT_REPO_ROOT/tools/bench_cluster.py > $OUT.$mode.log 2>&1
   grep -E "seedsim|mst \(GPU" $OUT.$mode.log | tail -3
