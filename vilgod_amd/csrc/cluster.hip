@@ -88,7 +88,8 @@ struct vg_cluster {
 };
 
 // Consecutive hardware workgroup ids are dealt round-robin to the 8 XCDs (observed placement, speed only): logical block = a contiguous run
-// of the Morton order per XCD, so that the table lines and points a region's queries share are served by ONE L2 instead of eight.
+// of the Morton order per XCD, so that the table lines and points a region's queries share are served by ONE L2 instead of eight
+// (round 5: Sigma k_cl_b_search 2 354 -> 2 280 us per MST, two interleaved pairs of traces).
 __device__ __forceinline__ int cl_xcd_block(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, s = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -868,6 +869,12 @@ __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
 // (that workgroup needs all 160 KB of LDS and every vector register), and the dispatcher deals workgroups round-robin over the CUs:
 // 309 workgroups of 256 threads sit on all 256 CUs for the launch's ~300 us, 155 of 512 threads on 155 (two waves per SIMD either way:
 // 172 registers, 88 KB of stack per CU).  FAR: the far_list / far_flag entry paths of the cooperative search (development build).
+// Measured and dropped (round 5): leaf CHILDREN scanned from their parent's visit.  A walk is a chain of dependent round trips -- one per
+// internal node, two per leaf (its own range, then its points) -- and the parent's trip already brings every child's range and purity, so
+// in near-to-far order the leaf children in front of the first internal child were scanned right there: the same visits in the same order,
+// one round trip less each.  Bit-identical, and SLOWER: Sigma search 2 290 -> 2 610 us per MST (211 instead of 172 registers; what counts is
+// the WAVE's chain: before, all lanes that sat at a leaf in one loop iteration shared its round trip; now a lane scanning five leaf children
+// inside one iteration keeps the other 63 lanes waiting five trips).
 // Measured and dropped (round 4): rounds >= 2 over a compacted list of the points that still have to walk (a few thousand; one 6 us
 // launch builds it): bit-identical, and the rounds take as long as before (332 vs 316 us: a round lasts as long as its longest walks,
 // however few waves carry them) while the pipeline's frames/s do not move (65.1 vs 65.2) -- the walks do not keep GEMM tiles waiting.
@@ -957,55 +964,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
     //  * a leaf scan loads sixteen points per trip, each as two 16-byte records (coordinates; core distance, component, 5th
     //    coordinate): no second trip for the survivors' core distances, none for ids (read only on an exact tie);
     //  * a point of the own component, or farther than the best edge so far, is dropped by a float32 screen.
-    // leaf scan: the points [s0, s1) of one node against the query (used for a popped leaf and for leaf CHILDREN scanned from their parent's visit)
-    auto scan = [&](int s0, int s1) {
-        bool improved = false;
-        scanned += s1 - s0;
-        // the float64 distance of the (exactly converted) float32 coordinates differs from the float32 evaluation by a few
-        // ulp, the threshold carries a 1e-5 margin: a point the screen drops has d2 > bw and could neither win nor tie
-        float thr = (float)bw * 1.00001f + 1e-30f;               // (float)(+inf) stays +inf
-        for (int jb = s0; jb < s1; jb += 16) {
-            float4 pj[16];
-            int4 xj[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int j = jb + u < s1 ? jb + u : s1 - 1;
-                pj[u] = spts[j];
-                xj[u] = aux[j];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const float fx = qf.x - pj[u].x, fy = qf.y - pj[u].y, fz = qf.z - pj[u].z;
-                float sd = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                if (DIM >= 4) { const float fe = qf.w - pj[u].w; sd = fmaf(fe, fe, sd); }
-                if (DIM >= 5) { const float ft = qtf - __int_as_float(xj[u].w); sd = fmaf(ft, ft, sd); }
-                if (!(sd <= thr) || xj[u].z == ca || jb + u >= s1) continue;
-                // (the survivors update the best edge by selects: inside this branch every further branch is paid by the
-                // whole wave; only an exact (w, d2) tie -- rare -- goes on to compare ids)
-                const int j = jb + u;
-                const double dx = qx - (double)pj[u].x, dy = qy - (double)pj[u].y, dz = qz - (double)pj[u].z;
-                double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (DIM >= 4) { const double de = qe - (double)pj[u].w; d2 = d2 + de * de; }
-                if (DIM >= 5) { const double dt = qt - (double)__int_as_float(xj[u].w); d2 = d2 + dt * dt; }
-                const double cj2 = __longlong_as_double(((long long)xj[u].y << 32) | (unsigned int)xj[u].x);
-                const double w = fmax(fmax(d2, core_a), cj2);
-                const bool better = w < bw || (w == bw && d2 < bd2);
-                if (w == bw && d2 == bd2) {      // same weight, same pair distance: the smaller id pair
-                    if (!bkey_valid) { bkey = cl_edge_key(oa, perm[bb]); bkey_valid = true; }
-                    const unsigned long long key = cl_edge_key(oa, perm[j]);
-                    if (key < bkey) { bkey = key; bb = j; }
-                }
-                bw = better ? w : bw;
-                bd2 = better ? d2 : bd2;
-                bb = better ? j : bb;
-                bkey_valid = bkey_valid && !better;
-                improved = improved || better;
-                thr = (float)bw * 1.00001f + 1e-30f;
-            }
-        }
-        if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
-        since_refresh = 64;
-    };
     const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
     const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
     for (int rr = 0; rr < nrx * nry; ++rr) {
@@ -1041,17 +999,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
             const size_t po = has_pur ? cl_pur_off(l) + c : 0;
             const int pure = cell_comp[po];
             const unsigned int erange = DIM >= 4 ? cell_e[po] : 0u;
-            // the eight children's purity entries (and 4th-coordinate ranges) sit side by side one level down: the same trip brings them, and
-            // a child that is a leaf can then be scanned without a visit of its own (below)
-            const bool ch_pur = l >= 1 && l - 1 < CL_PUR_LEVELS;
-            int4 cpa = make_int4(-1, -1, -1, -1), cpb = cpa;
-            uint4 cea = make_uint4(0u, 0u, 0u, 0u), ceb = cea;
-            if (ch_pur) {
-                const size_t co = cl_pur_off(l - 1) + 8 * (size_t)c;
-                cpa = *(const int4*)(cell_comp + co);
-                cpb = *(const int4*)(cell_comp + co + 4);
-                if (DIM >= 4) { cea = *(const uint4*)(cell_e + co); ceb = *(const uint4*)(cell_e + co + 4); }
-            }
             // (the bound: in a late round a whole frame's threads belong to two or three components, and a read per node queues up
             // behind the atomics on those few words)
             const bool refresh = ++since_refresh >= 8;
@@ -1069,7 +1016,52 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                 if (elb > bw || elb > cbest || (elb == bw && ed2 > bd2)) continue;
             }
             if (l == 0 || j1 - j0 <= CL_LEAF) {
-                scan(j0, j1);
+                bool improved = false;
+                scanned += j1 - j0;
+                // the float64 distance of the (exactly converted) float32 coordinates differs from the float32 evaluation by a few
+                // ulp, the threshold carries a 1e-5 margin: a point the screen drops has d2 > bw and could neither win nor tie
+                float thr = (float)bw * 1.00001f + 1e-30f;               // (float)(+inf) stays +inf
+                for (int jb = j0; jb < j1; jb += 16) {
+                    float4 pj[16];
+                    int4 xj[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = jb + u < j1 ? jb + u : j1 - 1;
+                        pj[u] = spts[j];
+                        xj[u] = aux[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const float fx = qf.x - pj[u].x, fy = qf.y - pj[u].y, fz = qf.z - pj[u].z;
+                        float sd = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
+                        if (DIM >= 4) { const float fe = qf.w - pj[u].w; sd = fmaf(fe, fe, sd); }
+                        if (DIM >= 5) { const float ft = qtf - __int_as_float(xj[u].w); sd = fmaf(ft, ft, sd); }
+                        if (!(sd <= thr) || xj[u].z == ca || jb + u >= j1) continue;
+                        // (the survivors update the best edge by selects: inside this branch every further branch is paid by the
+                        // whole wave; only an exact (w, d2) tie -- rare -- goes on to compare ids)
+                        const int j = jb + u;
+                        const double dx = qx - (double)pj[u].x, dy = qy - (double)pj[u].y, dz = qz - (double)pj[u].z;
+                        double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (DIM >= 4) { const double de = qe - (double)pj[u].w; d2 = d2 + de * de; }
+                        if (DIM >= 5) { const double dt = qt - (double)__int_as_float(xj[u].w); d2 = d2 + dt * dt; }
+                        const double cj2 = __longlong_as_double(((long long)xj[u].y << 32) | (unsigned int)xj[u].x);
+                        const double w = fmax(fmax(d2, core_a), cj2);
+                        const bool better = w < bw || (w == bw && d2 < bd2);
+                        if (w == bw && d2 == bd2) {      // same weight, same pair distance: the smaller id pair
+                            if (!bkey_valid) { bkey = cl_edge_key(oa, perm[bb]); bkey_valid = true; }
+                            const unsigned long long key = cl_edge_key(oa, perm[j]);
+                            if (key < bkey) { bkey = key; bb = j; }
+                        }
+                        bw = better ? w : bw;
+                        bd2 = better ? d2 : bd2;
+                        bb = better ? j : bb;
+                        bkey_valid = bkey_valid && !better;
+                        improved = improved || better;
+                        thr = (float)bw * 1.00001f + 1e-30f;
+                    }
+                }
+                if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
+                since_refresh = 64;
                 continue;
             }
             // ---- children: nearest one pushed last.  Sibling boxes share their faces: two distances per axis serve all eight; the
@@ -1095,40 +1087,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                         ad[ax][hb] = d;
                     }
             }
-            // (round 5) LEAF CHILDREN ARE SCANNED FROM HERE.  A launch lasts as long as its longest walks, and a walk is a chain of dependent
-            // memory round trips: one per internal node (its children's ranges) and, until now, TWO per leaf (the leaf's own range, then its
-            // points).  The parent's trip already brought every child's range, purity and 4th-coordinate range: in near-to-far order the
-            // leaf children that come BEFORE the first internal child are scanned right here -- exactly the visits the depth-first order
-            // would have made next, with the same tests on the same bounds, minus one round trip each.  (Most leaves are 0.8 m nodes
-            // under a 1.6 m parent whose children are all leaves.)  The remaining children are pushed as before, nearest last.
-            int u_stop = 0;
-#pragma unroll 1
-            for (; u_stop < 8; ++u_stop) {
-                const int ch = u_stop ^ near;
-                const int hx = ch & 1, hy = (ch >> 1) & 1, hz = (ch >> 2) & 1;
-                const double dxx = hx ? ad[0][1] : ad[0][0], dyy = hy ? ad[1][1] : ad[1][0], dzz = hz ? ad[2][1] : ad[2][0];
-                double cd2 = 0.0;
-                cd2 += dxx * dxx;
-                cd2 += dyy * dyy;
-                cd2 += dzz * dzz;
-                const double clb = fmax(lb_a, cd2);
-                int lo_i = bnd[0], hi_i = bnd[1];        // bnd[ch], bnd[ch + 1] without dynamic register indexing
-#pragma unroll
-                for (int v = 1; v < 8; ++v) { lo_i = ch == v ? bnd[v] : lo_i; hi_i = ch == v ? bnd[v + 1] : hi_i; }
-                if (lo_i == hi_i || clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) continue;      // nothing to visit there
-                if (!(l1 == 0 || hi_i - lo_i <= CL_LEAF)) break;                                          // an internal child: the stack takes over
-                if (ch_pur) {
-                    const int cp = ch == 0 ? cpa.x : ch == 1 ? cpa.y : ch == 2 ? cpa.z : ch == 3 ? cpa.w : ch == 4 ? cpb.x : ch == 5 ? cpb.y : ch == 6 ? cpb.z : cpb.w;
-                    if (cp == ca) continue;              // all ours
-                    if (DIM >= 4) {
-                        const unsigned int ce = ch == 0 ? cea.x : ch == 1 ? cea.y : ch == 2 ? cea.z : ch == 3 ? cea.w : ch == 4 ? ceb.x : ch == 5 ? ceb.y : ch == 6 ? ceb.z : ceb.w;
-                        const double ed2 = cd2 + cl_e_gap2(ce, qe);
-                        const double elb = fmax(lb_a, ed2);
-                        if (elb > bw || elb > cbest || (elb == bw && ed2 > bd2)) continue;
-                    }
-                }
-                scan(lo_i, hi_i);
-            }
 #pragma unroll
             for (int u = 7; u >= 0; --u) {
                 const int ch = u ^ near;
@@ -1142,7 +1100,7 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                 int lo_i = bnd[0], hi_i = bnd[1];        // bnd[ch], bnd[ch + 1] without dynamic register indexing
 #pragma unroll
                 for (int v = 1; v < 8; ++v) { lo_i = ch == v ? bnd[v] : lo_i; hi_i = ch == v ? bnd[v + 1] : hi_i; }
-                const bool keep = u >= u_stop && lo_i != hi_i && !(clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) && sp < CL_STACK;
+                const bool keep = lo_i != hi_i && !(clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) && sp < CL_STACK;
                 st[sp * NT] = cl_pack(l1, 2 * x + hx, 2 * y + hy, 2 * z + hz);      // (slot sp is free: written, kept only if counted)
                 sp += keep ? 1 : 0;
             }
