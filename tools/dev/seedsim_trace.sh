@@ -11,8 +11,6 @@ for mode in ${MODES:-seedsim sitout_on sitout_off}; do
     seedsim) export VG_CLUSTER_SEEDSIM=1; unset VG_CLUSTER_SITOUT;;
     sitout_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT;;
     sitout_off) unset VG_CLUSTER_SEEDSIM; export VG_CLUSTER_SITOUT=0;;
-    pipe_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_PIPE=1;;
-    pipe_off) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_PIPE=0;;
     xcd_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_XCD_ORDER=1;;
     xcd_off) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_XCD_ORDER=0;;
   esac

@@ -875,10 +875,15 @@ __device__ __forceinline__ unsigned long long cl_edge_key(int oa, int ob) {
 // one round trip less each.  Bit-identical, and SLOWER: Sigma search 2 290 -> 2 610 us per MST (211 instead of 172 registers; what counts is
 // the WAVE's chain: before, all lanes that sat at a leaf in one loop iteration shared its round trip; now a lane scanning five leaf children
 // inside one iteration keeps the other 63 lanes waiting five trips).
+// Measured and dropped (round 5), second attempt at the same chain: a leaf's points requested ONE ITERATION LATE, beside the next node's tables
+// (a "pending" range per lane; stale bounds prune less, never wrongly): one round trip per iteration instead of two, bit-identical, 187
+// registers -- and 8 % slower (Sigma search 2 330 -> 2 520 us, two interleaved pairs of traces).  Together with the first attempt this says
+// the walk is NOT bound by its memory round trips: with ~1.2 waves per SIMD a wave pays for the INSTRUCTIONS of every path some lane takes
+// in an iteration (float64 box tests of eight children, the sixteen-point screen + exact chain), and both variants added instructions.
 // Measured and dropped (round 4): rounds >= 2 over a compacted list of the points that still have to walk (a few thousand; one 6 us
 // launch builds it): bit-identical, and the rounds take as long as before (332 vs 316 us: a round lasts as long as its longest walks,
 // however few waves carry them) while the pipeline's frames/s do not move (65.1 vs 65.2) -- the walks do not keep GEMM tiles waiting.
-template <int DIM, int NT = 256, bool FAR = false, bool PIPE = false>
+template <int DIM, int NT = 256, bool FAR = false>
 __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ spts, const float* __restrict__ stt, int n,
                                                      const ClGrid* __restrict__ gp, const int* __restrict__ cs,
                                                      const int* __restrict__ cell_comp, const unsigned int* __restrict__ cell_e,
@@ -964,164 +969,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
     //  * a leaf scan loads sixteen points per trip, each as two 16-byte records (coordinates; core distance, component, 5th
     //    coordinate): no second trip for the survivors' core distances, none for ids (read only on an exact tie);
     //  * a point of the own component, or farther than the best edge so far, is dropped by a float32 screen.
-    const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
-    const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
-    if (PIPE) {
-    // PIPE (round 5): A LEAF IS SCANNED ONE LOOP ITERATION LATE, BESIDE THE NEXT NODE'S READS.  A wave's time is its count of loop iterations
-    // (the slowest lane's pops) times an iteration's dependent round trips, and an iteration in which ANY lane sat at a leaf made two of
-    // them: the node's tables, then -- their addresses known only now -- the leaf's points.  Here a leaf found in iteration t becomes the
-    // lane's PENDING range; iteration t + 1 requests its (first sixteen) points together with the tables of the node popped then: one
-    // round trip per iteration.  The bounds a pop is tested against lack the leaf still pending -- they are upper bounds either way, a
-    // stale one prunes less, never wrongly -- and a lane pops only when its pending range ends with this iteration.
-    int p0 = 0, p1 = 0;                  // the pending leaf's points still to scan
-    bool leaf_improved = false;
-    for (int rr = 0; rr < nrx * nry; ++rr) {
-        int rx = rr % nrx, ry = rr / nrx;
-        if (rr == 0) { rx = rx0; ry = ry0; }
-        else if (rx == rx0 && ry == ry0) { rx = 0; ry = 0; }
-        int sp = 0;
-        st[0] = cl_pack(CL_LMAX, rx, ry, 0);
-        sp = 1;
-        const bool last_root = rr == nrx * nry - 1;
-        while (sp > 0 || (last_root && p0 < p1)) {
-            // ---- pop ----
-            bool have = false;
-            int l = 0, x = 0, y = 0, z = 0;
-            double nd2 = 0.0;
-            if (sp > 0 && p1 - p0 <= 16) {
-                cl_unpack(st[(--sp) * NT], l, x, y, z);
-                // every edge into this node weighs at least lb; it must be able to tie or beat both bounds (ALU only)
-                nd2 = cl_box_d2(g, qx, qy, qz, l, x, y, z);
-                const double lb = fmax(lb_a, nd2);
-                have = !(lb > bw || lb > cbest || (lb == bw && nd2 > bd2));
-            }
-            const unsigned int c = have ? cl_code(x << l, y << l, z << l) >> (3 * l) : 0u;      // the node's number at its level
-            // ---- the node's reads and the pending points, all in flight together ----
-            int bnd[9];
-            {
-                const long long base = l == 0 ? (long long)CL_NCODES - c
-                                     : l == 1 ? (long long)CL_NCODES - 8ll * c
-                                              : (long long)(CL_NCODES + 1) + (long long)cl_lvl_off(l - 1) + 8ll * c;
-                const long long dir = l <= 1 ? -1 : 1;
-#pragma unroll
-                for (int u = 0; u < 9; ++u) {
-                    long long at = base + dir * u;
-                    bnd[u] = have ? cs[at < 0 ? 0 : at] : 0;
-                }
-            }
-            const bool has_pur = l < CL_PUR_LEVELS;
-            const size_t po = (have && has_pur) ? cl_pur_off(l) + c : 0;
-            const int pure = cell_comp[po];
-            const unsigned int erange = DIM >= 4 ? cell_e[po] : 0u;
-            const bool refresh = have && ++since_refresh >= 8;
-            unsigned long long cb = 0;
-            if (refresh) { cb = __hip_atomic_load(&best_w[ca], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); since_refresh = 0; }
-            const int s0 = p0, s1 = p1 < p0 + 16 ? p1 : p0 + 16;
-            float4 pj[16];
-            int4 xj[16];
-            if (s0 < s1) {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int j = s0 + u < s1 ? s0 + u : s1 - 1;
-                    pj[u] = spts[j];
-                    xj[u] = aux[j];
-                }
-            }
-            // ---- the pending points ----
-            if (s0 < s1) {
-                float thr = (float)bw * 1.00001f + 1e-30f;               // (float)(+inf) stays +inf; see the screen's note below
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const float fx = qf.x - pj[u].x, fy = qf.y - pj[u].y, fz = qf.z - pj[u].z;
-                    float sd = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
-                    if (DIM >= 4) { const float fe = qf.w - pj[u].w; sd = fmaf(fe, fe, sd); }
-                    if (DIM >= 5) { const float ft = qtf - __int_as_float(xj[u].w); sd = fmaf(ft, ft, sd); }
-                    if (!(sd <= thr) || xj[u].z == ca || s0 + u >= s1) continue;
-                    const int j = s0 + u;
-                    const double dx = qx - (double)pj[u].x, dy = qy - (double)pj[u].y, dz = qz - (double)pj[u].z;
-                    double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (DIM >= 4) { const double de = qe - (double)pj[u].w; d2 = d2 + de * de; }
-                    if (DIM >= 5) { const double dt = qt - (double)__int_as_float(xj[u].w); d2 = d2 + dt * dt; }
-                    const double cj2 = __longlong_as_double(((long long)xj[u].y << 32) | (unsigned int)xj[u].x);
-                    const double w = fmax(fmax(d2, core_a), cj2);
-                    const bool better = w < bw || (w == bw && d2 < bd2);
-                    if (w == bw && d2 == bd2) {      // same weight, same pair distance: the smaller id pair
-                        if (!bkey_valid) { bkey = cl_edge_key(oa, perm[bb]); bkey_valid = true; }
-                        const unsigned long long key = cl_edge_key(oa, perm[j]);
-                        if (key < bkey) { bkey = key; bb = j; }
-                    }
-                    bw = better ? w : bw;
-                    bd2 = better ? d2 : bd2;
-                    bb = better ? j : bb;
-                    bkey_valid = bkey_valid && !better;
-                    leaf_improved = leaf_improved || better;
-                    thr = (float)bw * 1.00001f + 1e-30f;
-                }
-                scanned += s1 - s0;
-                p0 = s1;
-                if (p0 >= p1) {
-                    if (leaf_improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
-                    leaf_improved = false;
-                    since_refresh = 64;
-                }
-            }
-            if (!have) continue;
-            // ---- the node ----
-            const int j0 = bnd[0], j1 = l == 0 ? bnd[1] : bnd[8];
-            if (refresh) cbest = cb == CL_NONE ? INFINITY : __longlong_as_double((long long)cb);
-            if (lb_a > cbest) { sp = 0; p0 = p1 = 0; rr = nrx * nry; break; }      // this point can no longer win: stop
-            if (j0 == j1) continue;
-            if (has_pur && pure == ca) continue;         // all ours
-            if (DIM >= 4 && has_pur) {
-                const double ed2 = nd2 + cl_e_gap2(erange, qe);
-                const double elb = fmax(lb_a, ed2);
-                if (elb > bw || elb > cbest || (elb == bw && ed2 > bd2)) continue;
-            }
-            if (l == 0 || j1 - j0 <= CL_LEAF) {          // a leaf: its points are requested beside the next node's tables
-                p0 = j0; p1 = j1;
-                continue;
-            }
-            const int l1 = l - 1;
-            const int ox = ((cx >> l1) > 2 * x) ? 1 : 0, oy = ((cy >> l1) > 2 * y) ? 1 : 0, oz = ((cz >> l1) > 2 * z) ? 1 : 0;
-            const int near = ox | (oy << 1) | (oz << 2);
-            double ad[3][2];
-            {
-                const double s1_ = CL_CELL * (double)(1 << l1);
-                const int nbx[3] = {CL_NX >> l1, CL_NY >> l1, CL_NZ >> l1};
-                const int c2[3] = {2 * x, 2 * y, 2 * z};
-                const double q3[3] = {qx, qy, qz}, o3[3] = {g.ox, g.oy, g.oz};
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax)
-#pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) {     // the same expressions as cl_box_d2, per axis
-                        const int cc = c2[ax] + hb;
-                        const double lo = o3[ax] + (double)cc * s1_, hi = lo + s1_;
-                        double d = 0.0;
-                        if (q3[ax] < lo && cc > 0) d = lo - q3[ax];
-                        else if (q3[ax] > hi && cc < nbx[ax] - 1) d = q3[ax] - hi;
-                        ad[ax][hb] = d;
-                    }
-            }
-#pragma unroll
-            for (int u = 7; u >= 0; --u) {
-                const int ch = u ^ near;
-                const int hx = ch & 1, hy = (ch >> 1) & 1, hz = (ch >> 2) & 1;
-                const double dxx = hx ? ad[0][1] : ad[0][0], dyy = hy ? ad[1][1] : ad[1][0], dzz = hz ? ad[2][1] : ad[2][0];
-                double cd2 = 0.0;
-                cd2 += dxx * dxx;
-                cd2 += dyy * dyy;
-                cd2 += dzz * dzz;
-                const double clb = fmax(lb_a, cd2);
-                int lo_i = bnd[0], hi_i = bnd[1];        // bnd[ch], bnd[ch + 1] without dynamic register indexing
-#pragma unroll
-                for (int v = 1; v < 8; ++v) { lo_i = ch == v ? bnd[v] : lo_i; hi_i = ch == v ? bnd[v + 1] : hi_i; }
-                const bool keep = lo_i != hi_i && !(clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) && sp < CL_STACK;
-                st[sp * NT] = cl_pack(l1, 2 * x + hx, 2 * y + hy, 2 * z + hz);      // (slot sp is free: written, kept only if counted)
-                sp += keep ? 1 : 0;
-            }
-        }
-    }
-    } else {
     const int rx0 = cx >> CL_LMAX, ry0 = cy >> CL_LMAX;
     const int nrx = CL_NX >> CL_LMAX, nry = CL_NY >> CL_LMAX;
     for (int rr = 0; rr < nrx * nry; ++rr) {
@@ -1263,7 +1110,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                 sp += keep ? 1 : 0;
             }
         }
-    }
     }
     if (bb >= 0 && !bkey_valid) bkey = cl_edge_key(oa, perm[bb]);
     if (dbg_scan) dbg_scan[a] = (far_list ? dbg_scan[a] : 0) + scanned;
@@ -1831,15 +1677,7 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
         return;
     }
 #endif
-    int pipe = 1;
-#ifdef VG_DEV
-    if (getenv("VG_CLUSTER_PIPE")) pipe = atoi(getenv("VG_CLUSTER_PIPE"));                      // A/B aid (development build), read per call
-#endif
-    if (nt == 512 && pipe)
-        hipLaunchKernelGGL((k_cl_b_search<DIM, 512, false, true>), dim3(vg_div_up(n, 512)), dim3(512), 0, st, h->d_spts, h->d_st, n, h->d_grid,
-                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, cl_sit_min(n), xcd_order);
-    else if (nt == 512)
+    if (nt == 512)
         hipLaunchKernelGGL((k_cl_b_search<DIM, 512>), dim3(vg_div_up(n, 512)), dim3(512), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, cl_sit_min(n), xcd_order);
