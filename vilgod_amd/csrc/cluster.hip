@@ -1026,13 +1026,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                 // the float64 distance of the (exactly converted) float32 coordinates differs from the float32 evaluation by a few
                 // ulp, the threshold carries a 1e-5 margin: a point the screen drops has d2 > bw and could neither win nor tie
                 float thr = (float)bw * 1.00001f + 1e-30f;               // (float)(+inf) stays +inf
-                // (round 5) two more screens in front of the exact chain, which is what a wave's iteration mostly consists of (the walk is
-                // bound by the instructions of the slowest wave, not by its round trips):
-                //  * the candidate's own core distance is part of the edge's weight: core_j > bw cannot win or tie (float32 of the squared
-                //    core distance against the same threshold; the 1e-5 margin covers the conversion's rounding);
-                //  * once bw equals the lower bound of EVERY edge out of a (lb_a: typical in round 1, where the first neighbour with a
-                //    smaller core distance gives w = core_a) nothing can beat it, and a tie needs a pair distance <= bd2: screen on bd2.
-                float thr_d = bw == lb_a ? fminf(thr, (float)bd2 * 1.00001f + 1e-30f) : thr;
                 for (int jb = j0; jb < j1; jb += 16) {
                     float4 pj[16];
                     int4 xj[16];
@@ -1048,8 +1041,7 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                         float sd = fmaf(fz, fz, fmaf(fy, fy, fx * fx));
                         if (DIM >= 4) { const float fe = qf.w - pj[u].w; sd = fmaf(fe, fe, sd); }
                         if (DIM >= 5) { const float ft = qtf - __int_as_float(xj[u].w); sd = fmaf(ft, ft, sd); }
-                        const float cf = (float)__longlong_as_double(((long long)xj[u].y << 32) | (unsigned int)xj[u].x);
-                        if (!(sd <= thr_d) || !(cf <= thr) || xj[u].z == ca || jb + u >= j1) continue;
+                        if (!(sd <= thr) || xj[u].z == ca || jb + u >= j1) continue;
                         // (the survivors update the best edge by selects: inside this branch every further branch is paid by the
                         // whole wave; only an exact (w, d2) tie -- rare -- goes on to compare ids)
                         const int j = jb + u;
@@ -1071,7 +1063,6 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                         bkey_valid = bkey_valid && !better;
                         improved = improved || better;
                         thr = (float)bw * 1.00001f + 1e-30f;
-                        thr_d = bw == lb_a ? fminf(thr, (float)bd2 * 1.00001f + 1e-30f) : thr;
                     }
                 }
                 if (improved) atomicMin(&best_w[ca], (unsigned long long)__double_as_longlong(bw));
