@@ -287,7 +287,8 @@ def test_pack_clusters_host_equals_numpy_form():
     gaps in the label range and thresholded probabilities."""
     from vilgod_amd.frame_state import pack_clusters, pack_clusters_numpy
     rng = np.random.default_rng(5)
-    cases = [(np.zeros(0, np.int64), None), (np.full(7, -1), rng.random(7)), (np.array([3, 3, -1, 9, 3, 9]), None)]
+    cases = [(np.zeros(0, np.int64), None), (np.full(7, -1), rng.random(7)), (np.array([3, 3, -1, 9, 3, 9]), None),
+             (np.array([2_000_000_000, 5, 2_000_000_000, -1, 70_000, 5]), None)]          # label values far beyond the point count
     for n in (1, 17, 1000, 50_000):
         lab = rng.integers(-1, 40, n)
         lab[lab == 5] = 7                                  # a label nobody owns

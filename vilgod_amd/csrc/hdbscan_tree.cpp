@@ -267,13 +267,33 @@ extern "C" int vg_pack_clusters_host(const int32_t* h_labels, const double* h_pr
     if (n < 0 || (n > 0 && !h_labels) || !h_ids || !h_index || !h_seg || !h_n_clusters) return 1;
     int max_label = -1;
     for (int i = 0; i < n; ++i) max_label = std::max(max_label, (int)h_labels[i]);
+    int nc = 0;
+    if ((long long)max_label >= 2ll * n + 1024) {
+        // label VALUES far beyond the point count (not what the hierarchy stage produces: its labels are 0 .. clusters - 1): no table of that
+        // size -- sort the kept points by (label, index) instead
+        static thread_local std::vector<std::pair<int32_t, int32_t>> kept;
+        kept.clear();
+        for (int i = 0; i < n; ++i)
+            if (h_labels[i] >= 0 && !(h_probs && h_probs[i] < threshold)) kept.emplace_back(h_labels[i], i);
+        std::sort(kept.begin(), kept.end());
+        for (size_t k = 0; k < kept.size(); ++k) {
+            if (k == 0 || kept[k].first != kept[k - 1].first) {
+                h_ids[nc] = kept[k].first;
+                h_seg[nc++] = (int32_t)k;
+            }
+            h_index[k] = kept[k].second;
+        }
+        h_seg[nc] = (int32_t)kept.size();
+        *h_n_clusters = nc;
+        return 0;
+    }
     static thread_local std::vector<int> count;
     count.assign((size_t)max_label + 2, 0);
     for (int i = 0; i < n; ++i) {
         const int l = h_labels[i];
         if (l >= 0 && !(h_probs && h_probs[i] < threshold)) count[l + 1]++;
     }
-    int nc = 0, total = 0;
+    int total = 0;
     for (int l = 0; l <= max_label; ++l) {
         const int c = count[l + 1];
         count[l + 1] = total;                              // start of label l's segment (if it has one)
