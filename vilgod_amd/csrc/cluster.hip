@@ -1092,19 +1092,39 @@ __global__ __launch_bounds__(NT) void k_cl_b_search(const float4* __restrict__ s
                         ad[ax][hb] = d;
                     }
             }
+            // child u of the near-first order is octant u ^ near: its range [bnd[u ^ near], bnd[(u ^ near) + 1]) comes out of three conditional
+            // exchange stages over the two boundary arrays (48 selects) instead of a 7-deep select chain per child and end (112), and the
+            // squared axis distances are taken once per axis half (round 5: the walk is bound by its instruction count)
+            int blo[8], bhi[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { blo[v] = bnd[v]; bhi[v] = bnd[v + 1]; }
+#pragma unroll
+            for (int bit = 0; bit < 3; ++bit) {
+                const bool sw = (near >> bit) & 1;
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+                    if (!((v >> bit) & 1)) {
+                        const int w_ = v | (1 << bit);
+                        const int a0 = blo[v], a1 = blo[w_], h0 = bhi[v], h1 = bhi[w_];
+                        blo[v] = sw ? a1 : a0; blo[w_] = sw ? a0 : a1;
+                        bhi[v] = sw ? h1 : h0; bhi[w_] = sw ? h0 : h1;
+                    }
+            }
+            // (after the exchanges position u holds octant u ^ near; the same for the axis distances: index 0 = the near half)
+            const double ax0 = ox ? ad[0][1] : ad[0][0], ax1 = ox ? ad[0][0] : ad[0][1];
+            const double ay0 = oy ? ad[1][1] : ad[1][0], ay1 = oy ? ad[1][0] : ad[1][1];
+            const double az0 = oz ? ad[2][1] : ad[2][0], az1 = oz ? ad[2][0] : ad[2][1];
+            const double sx[2] = {ax0 * ax0, ax1 * ax1}, sy[2] = {ay0 * ay0, ay1 * ay1}, sz[2] = {az0 * az0, az1 * az1};
 #pragma unroll
             for (int u = 7; u >= 0; --u) {
                 const int ch = u ^ near;
                 const int hx = ch & 1, hy = (ch >> 1) & 1, hz = (ch >> 2) & 1;
-                const double dxx = hx ? ad[0][1] : ad[0][0], dyy = hy ? ad[1][1] : ad[1][0], dzz = hz ? ad[2][1] : ad[2][0];
                 double cd2 = 0.0;
-                cd2 += dxx * dxx;
-                cd2 += dyy * dyy;
-                cd2 += dzz * dzz;
+                cd2 += sx[u & 1];
+                cd2 += sy[(u >> 1) & 1];
+                cd2 += sz[(u >> 2) & 1];
                 const double clb = fmax(lb_a, cd2);
-                int lo_i = bnd[0], hi_i = bnd[1];        // bnd[ch], bnd[ch + 1] without dynamic register indexing
-#pragma unroll
-                for (int v = 1; v < 8; ++v) { lo_i = ch == v ? bnd[v] : lo_i; hi_i = ch == v ? bnd[v + 1] : hi_i; }
+                const int lo_i = blo[u], hi_i = bhi[u];
                 const bool keep = lo_i != hi_i && !(clb > bw || clb > cbest || (clb == bw && cd2 > bd2)) && sp < CL_STACK;
                 st[sp * NT] = cl_pack(l1, 2 * x + hx, 2 * y + hy, 2 * z + hz);      // (slot sp is free: written, kept only if counted)
                 sp += keep ? 1 : 0;
