@@ -54,7 +54,7 @@ def build(force=False, verbose=True, dev=False):
     LIB = os.path.join(HERE, 'libvilgod_hip_dev.so' if dev else 'libvilgod_hip.so')
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inc'))]
     if dev and os.path.isdir(os.path.join(CSRC, 'dev')):           # the development build's kernels (included by vit.hip under VG_DEV)
         headers += [os.path.join(CSRC, 'dev', f) for f in os.listdir(os.path.join(CSRC, 'dev')) if f.endswith('.inc')]
     headers += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]

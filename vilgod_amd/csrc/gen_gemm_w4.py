@@ -1,0 +1,291 @@
+"""Generator of the hand-scheduled K loop of k_gemm_f16_w4 (csrc/vit.hip): writes csrc/gemm_w4_loop.inc.
+
+    python vilgod_amd/csrc/gen_gemm_w4.py            # rewrite the .inc
+    python vilgod_amd/csrc/gen_gemm_w4.py --check    # exit 1 if the committed .inc differs from what this script emits
+
+What the loop is (round 6; the projection GEMMs of third_party/CLIP/clip/model.py:171-192):
+  * workgroup = 4 waves, one per SIMD; 256 x 256 x 64 macro tile; wave (wm, wn) owns 128 tokens x 128 features = 8 x 8 tiles of
+    v_mfma_f32_16x16x32_f16, i.e. 256 accumulator registers, which live in a0..a255 for the whole tile (the compiler never sees them:
+    the epilogue fetches them with v_accvgpr_read).  A operand = 16 weight rows, B operand = 16 token rows (the transposed tile, as in
+    k_gemm_f16_pp64): same MFMAs on the same operands in the same K order, hence the same bits.
+  * LDS: a ring of FIVE 32 KB slots (all 160 KB), a slot = 256 rows x 128 B of one operand for one K-tile, 16-byte chunk c of row r at
+    c ^ ((r >> 1) & 7).  X(t) sits in slot 2t mod 5, W(t) in 2t + 1 mod 5.  Filled by LDS-DMA (`buffer_load_dwordx4 ... lds`, a piece =
+    8 rows x 128 B, the swizzle applied to the per-lane SOURCE address); a wave fills rows [64 w, 64 w + 64) of every slot: 8 + 8
+    pieces per K-tile.
+  * ONE barrier per K-tile ("M").  Iteration i: the first k32 sub-step's MFMAs run on fragments read during iteration i - 1 while the
+    second sub-step's fragments are read; `s_waitcnt vmcnt(8) lgkmcnt(0)` + s_barrier: every wave is done with the slots of X(i), W(i)
+    and every wave's pieces of X(i+1), W(i+1) have landed.  Behind M: W(i+2) goes into X(i)'s slot, X(i+3) into W(i)'s, and the first
+    sub-step's fragments of tile i + 1 are read.  So W has one iteration (>= 2 048 cycles of MFMAs) to land and X two.
+  * every LDS read, DMA piece, address update and wait sits at a fixed distance between the MFMAs (the table SCHED below): nothing is
+    left to the compiler's scheduler.
+
+Registers: v128..v255 fragments (W half 0, X half 0, W half 1, X half 1: 32 each), v120..v123 read addresses, s68..s91 (piece offsets,
+slot ring, buffer descriptors, loop counter).  Everything else comes in through named operands.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, 'gemm_w4_loop.inc')
+
+FW = (128, 192)          # W fragments (A operand), k32 half 0 / 1: v[FW[h] + 4 ni .. + 3]
+FX = (160, 224)          # X fragments (B operand)
+VA_W = (120, 121)        # LDS read address of the W fragments, half 0 / 1
+VA_X = (122, 123)
+S_OFF = 68               # s68..s74: piece offsets p * (8 rows) for p = 1..7
+S_DST = 75               # slot + this wave's share: M0 base of the pieces being issued
+S_SLOT = (76, 77, 78, 79, 80)   # a, b, c, d, e = slots of X(i), W(i), X(i+1), W(i+1), X(i+2)
+S_TMP = 81
+S_CNT = 82
+S_WDST = 83              # this wave's byte offset inside a slot (64 rows x 128 B x wave)
+SRD = {'x': 84, 'w': 88}       # s[84:87], s[88:91]
+
+
+def mfma(k):
+    h, kk = divmod(k, 64)
+    ni, mi = divmod(kk, 8)
+    a = 4 * (ni * 8 + mi)
+    return 'v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]' % (
+        a, a + 3, FW[h] + 4 * ni, FW[h] + 4 * ni + 3, FX[h] + 4 * mi, FX[h] + 4 * mi + 3, a, a + 3)
+
+
+def rd(op, h, i):
+    base = (FW if op == 'w' else FX)[h] + 4 * i
+    addr = (VA_W if op == 'w' else VA_X)[h]
+    return 'ds_read_b128 v[%d:%d], v%d offset:%d' % (base, base + 3, addr, 2048 * i)
+
+
+def addr(op, h, slot):
+    return 'v_add_u32 v%d, s%d, %%[%so%d]' % ((VA_W if op == 'w' else VA_X)[h], slot, op, h)
+
+
+def dst(slot):
+    return 's_add_u32 s%d, s%d, s%d' % (S_DST, slot, S_WDST)
+
+
+def m0(p):
+    return 's_mov_b32 m0, s%d' % S_DST if p == 0 else 's_add_u32 m0, s%d, %d' % (S_DST, 1024 * p)
+
+
+def piece(op, p):
+    so = '0' if p == 0 else 's%d' % (S_OFF + p - 1)
+    return 'buffer_load_dwordx4 %%[dv%d], s[%d:%d], %s offen lds' % (p & 1, SRD[op], SRD[op] + 3, so)
+
+
+def advance(op):
+    return ['s_add_u32 s%d, s%d, 128' % (SRD[op], SRD[op]), 's_addc_u32 s%d, s%d, 0' % (SRD[op] + 1, SRD[op] + 1)]
+
+
+def rotate():
+    a, b, c, d, e = S_SLOT
+    t = S_TMP
+    return ['s_mov_b32 s%d, s%d' % p for p in ((t, a), (a, c), (c, e), (e, b), (b, d), (d, t))]
+
+
+# Cycle stamps (trace variants only): s_memtime pairs around the waits and the barrier, differences accumulated in SGPRs.
+# s[92:93] stamp, s94 = sum of M-wait cycles, s95 = barrier, s96 = end-of-iteration wait, s97 previous stamp, s98 scratch,
+# s99 = cost of one stamp pair with nothing between (calibration), s100 loop entry stamp, s101 prologue entry stamp.
+def stamp_first():
+    return ['s_memtime s[92:93]']
+
+
+def stamp_take(acc):
+    """behind a wait that also retired the pending s_memtime: s97 = that stamp; new stamp; acc += new - s97"""
+    return ['s_mov_b32 s97, s92', 's_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_sub_u32 s98, s92, s97', 's_add_u32 s%d, s%d, s98' % (acc, acc)]
+
+
+# The schedule of one iteration: what is issued behind MFMA k (k = 0..127).
+SCHED = dict(
+    rd1_first=1, rd1_pattern=(0, 1),     # second sub-step's fragments: two reads in every three gaps from gap rd1_first on
+    wait_m=31, bar_m=32,                 # s_waitcnt vmcnt(..) lgkmcnt(0) behind MFMA 31, s_barrier behind MFMA 32
+    dma_w_first=34, dma_x_first=50, dma_step=2,
+    rd0_first=67, rd0_pattern=(0, 1),
+    rotate_at=100, loop_at=127, wait_end=126,
+)
+
+
+def body(issue_w, issue_x, vm_at_m, read_next, barrier=True, loop_label=None, sched=SCHED):
+    gaps = {k: [] for k in range(-1, 128)}
+    a, b, c, d, e = S_SLOT
+    s = sched
+    if s.get('no_dma'):
+        issue_w = issue_x = False
+        vm_at_m = 0
+    # ---- in front of M: the second sub-step's fragments of tile i (slots a = X(i), b = W(i))
+    gaps[0] += [addr('w', 1, b), addr('x', 1, a)]
+    g = s['rd1_first']
+    reads = [rd('w', 1, i) for i in range(8)] + [rd('x', 1, i) for i in range(8)]
+    n = 0
+    while n < 16:
+        for o in s['rd1_pattern']:
+            if n < 16:
+                gaps[g + o].append(reads[n]); n += 1
+        g += 3
+    assert g - 3 + max(s['rd1_pattern']) < s['wait_m']
+    if barrier and s.get('trace'):
+        gaps[s['wait_m'] - 1] += stamp_first()       # executes one MFMA in front of the wait; the wait retires it with everything else
+        gaps[s['wait_m']] += ['s_waitcnt vmcnt(%d) lgkmcnt(0)' % vm_at_m] + stamp_take(94) + ['s_mov_b32 s97, s92']
+        gaps[s['bar_m']] += ['s_barrier', 's_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_sub_u32 s98, s92, s97', 's_add_u32 s95, s95, s98']
+    elif barrier:
+        gaps[s['wait_m']].append('s_waitcnt vmcnt(%d) lgkmcnt(0)' % vm_at_m)
+        gaps[s['bar_m']].append('s_barrier')
+    else:
+        gaps[s['wait_m']].append('s_waitcnt lgkmcnt(0)')
+    # ---- behind M: W(i+2) -> slot a, X(i+3) -> slot b
+    for on, op, slot, first in ((issue_w, 'w', a, s['dma_w_first']), (issue_x, 'x', b, s['dma_x_first'])):
+        if not on:
+            continue
+        gaps[first - 1] += [dst(slot), m0(0)]
+        for p in range(8):
+            gaps[first + s['dma_step'] * p].append(piece(op, p))
+            if p < 7:
+                gaps[first + s['dma_step'] * p + 1].append(m0(p + 1))
+        gaps[first + s['dma_step'] * 7 + 1] += advance(op)
+    # ---- first sub-step's fragments of tile i + 1 (slots c = X(i+1), d = W(i+1)); their registers are free behind MFMA 63
+    if read_next:
+        g = s['rd0_first']
+        assert g > 64
+        gaps[g - 1] += [addr('w', 0, d), addr('x', 0, c)]
+        reads = [rd('w', 0, i) for i in range(8)] + [rd('x', 0, i) for i in range(8)]
+        n = 0
+        while n < 16:
+            for o in s['rd0_pattern']:
+                if n < 16:
+                    gaps[g + o].append(reads[n]); n += 1
+            g += 3
+        assert g < s['rotate_at']
+        gaps[s['rotate_at']] += rotate()
+        if s.get('trace'):
+            gaps[s['wait_end'] - 1] += stamp_first()
+            gaps[s['wait_end']] += ['s_waitcnt lgkmcnt(0)'] + stamp_take(96)
+        else:
+            gaps[s['wait_end']].append('s_waitcnt lgkmcnt(0)')
+    if loop_label:
+        gaps[s['loop_at']] += ['s_sub_u32 s%d, s%d, 1' % (S_CNT, S_CNT), 's_cmp_lg_u32 s%d, 0' % S_CNT]
+    out = []
+    for k in range(128):
+        out.append(mfma(k))
+        for ins in gaps[k]:
+            if s.get('no_reads') and ins.startswith('ds_read'):
+                continue
+            if s.get('no_barrier') and ins == 's_barrier':
+                continue
+            out.append(ins)
+    if loop_label:
+        out.append('s_cbranch_scc1 %s' % loop_label)
+    return out
+
+
+def prologue():
+    a, b, c, d, e = S_SLOT
+    out = []
+    out += ['s_mov_b32 s%d, %%[xlo]' % SRD['x'], 's_mov_b32 s%d, %%[xhi]' % (SRD['x'] + 1), 's_mov_b32 s%d, 0x80000000' % (SRD['x'] + 2),
+            's_mov_b32 s%d, 0x00020000' % (SRD['x'] + 3)]
+    out += ['s_mov_b32 s%d, %%[wlo]' % SRD['w'], 's_mov_b32 s%d, %%[whi]' % (SRD['w'] + 1), 's_mov_b32 s%d, 0x80000000' % (SRD['w'] + 2),
+            's_mov_b32 s%d, 0x00020000' % (SRD['w'] + 3)]
+    out.append('s_mov_b32 s%d, %%[rs8]' % S_OFF)
+    for p in range(2, 8):
+        out.append('s_add_u32 s%d, s%d, %%[rs8]' % (S_OFF + p - 1, S_OFF + p - 2))
+    for i, sl in enumerate(S_SLOT):
+        out.append('s_add_u32 s%d, %%[lds0], %d' % (sl, 32768 * i))
+    out.append('s_mov_b32 s%d, %%[wdst]' % S_WDST)
+    out.append('s_sub_u32 s%d, %%[np], 3' % S_CNT)
+    # X(0) -> a, W(0) -> b, X(1) -> c, W(1) -> d, X(2) -> e
+    for op, slot in (('x', a), ('w', b), ('x', c), ('w', d), ('x', e)):
+        out += [dst(slot)]
+        for p in range(8):
+            out += [m0(p), 's_nop 0', piece(op, p)]
+        out += advance(op)
+    out += ['v_accvgpr_write_b32 a%d, 0' % i for i in range(256)]
+    out += ['s_waitcnt vmcnt(24)', 's_barrier']
+    out += [addr('w', 0, b), addr('x', 0, a)]
+    out += [rd('w', 0, i) for i in range(8)] + [rd('x', 0, i) for i in range(8)]
+    out += ['s_waitcnt lgkmcnt(0)']
+    return out
+
+
+def program(sched=SCHED):
+    out = []
+    if sched.get('trace'):
+        out += ['s_mov_b32 s94, 0', 's_mov_b32 s95, 0', 's_mov_b32 s96, 0', 's_mov_b32 s99, 0',
+                's_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_mov_b32 s101, s92'] + stamp_first() + ['s_waitcnt lgkmcnt(0)'] + stamp_take(99)
+    out += prologue()
+    if sched.get('trace'):
+        out += ['s_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_mov_b32 s100, s92']
+    out += ['s_cmp_eq_u32 s%d, 0' % S_CNT, 's_cbranch_scc1 .Lw4_tail_%=', '.p2align 4', '.Lw4_loop_%=:']
+    out += body(True, True, 8, True, loop_label='.Lw4_loop_%=', sched=sched)
+    out += ['.Lw4_tail_%=:']
+    out += body(True, False, 8, True, sched=sched)         # i = np - 3: W(np-1) is the last thing to fetch
+    out += body(False, False, 0, True, sched=sched)        # i = np - 2
+    out += body(False, False, 0, False, barrier=False, sched=sched)    # i = np - 1
+    out += ['s_nop 15', 's_nop 15']           # the last MFMAs have written their accumulators before anything reads them
+    if sched.get('trace'):
+        out += ['s_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_sub_u32 %[t_pro], s100, s101', 's_sub_u32 %[t_loop], s92, s100',
+                's_mov_b32 %[t_wait], s94', 's_mov_b32 %[t_bar], s95', 's_mov_b32 %[t_end], s96', 's_mov_b32 %[t_cal], s99']
+    return out
+
+
+def clobbers():
+    c = ['"memory"', '"scc"', '"m0"']
+    c += ['"v%d"' % i for i in range(120, 256)]
+    c += ['"a%d"' % i for i in range(256)]
+    c += ['"s%d"' % i for i in range(S_OFF, 102)]
+    return c
+
+
+# Development variants (compiled under VG_DEV only; VG_GEMM_W4 = 1 + index): ablations that give WRONG results (what does the loop cost
+# without its DMA / reads / barrier?) and alternative schedules.
+VARIANTS = [
+    dict(),                                  # 0: the product schedule
+    dict(no_dma=True),                       # 1
+    dict(no_reads=True),                     # 2
+    dict(no_barrier=True),                   # 3
+    dict(no_dma=True, no_reads=True, no_barrier=True),   # 4: MFMAs only
+    dict(dma_step=3, dma_x_first=58),                    # 5
+    dict(dma_step=4, dma_x_first=66),                    # 6
+    dict(dma_step=5, dma_x_first=74, rotate_at=112),     # 7
+    dict(dma_step=6, dma_x_first=82, rotate_at=112),     # 8
+    dict(dma_step=5, wait_m=39, bar_m=40, dma_w_first=42, dma_x_first=82, rotate_at=112),      # 9: M later
+    dict(dma_step=4, rd1_pattern=(0,), rd1_first=1, wait_m=55, bar_m=56, dma_w_first=58, dma_x_first=90, rotate_at=121),   # 10: M at 56, one read per 3 gaps
+    dict(dma_step=3, dma_x_first=58, trace=True),       # 11: variant 5 with cycle stamps (vg_gemm_trace var 50)
+]
+
+
+def render():
+    lines = ['// GENERATED by gen_gemm_w4.py -- do not edit; see that file for what the schedule is and why.']
+    for vi, var in enumerate(VARIANTS):
+        sched = dict(SCHED); sched.update(var)
+        if vi == 1:
+            lines.append('#ifdef VG_DEV')
+        lines.append('#define VG_W4_ASM_%d \\' % vi)
+        for ins in program(sched):
+            lines.append('    "%s\\n" \\' % ins)
+        lines.append('    ""')
+    lines.append('#define VG_W4_DEV_RUNS \\')
+    for vi in range(1, len(VARIANTS)):
+        lines.append('    else if constexpr (VAR == %d) { VG_W4_RUN%s(%d); } \\' % (vi, '_TRACE' if VARIANTS[vi].get('trace') else '', vi))
+    lines.append('')
+    lines.append('#define VG_W4_DEV_CASES(EPI, LN) \\')
+    for vi in range(1, len(VARIANTS)):
+        if not VARIANTS[vi].get('trace'):
+            lines.append('    case %d: return launch_gemm_w4<EPI, LN, %d>(X, Wt, bias, C, resid, M, N, K, ldc, st); \\' % (vi + 1, vi))
+    lines.append('')
+    lines.append('#endif  // VG_DEV')
+    lines.append('#define VG_W4_NVAR %d' % len(VARIANTS))
+    lines.append('#define VG_W4_TRACE_VAR %d' % [i for i, v in enumerate(VARIANTS) if v.get('trace')][0])
+    cl = clobbers()
+    lines.append('#define VG_W4_CLOBBERS \\')
+    for i in range(0, len(cl), 16):
+        lines.append('    ' + ', '.join(cl[i:i + 16]) + (', \\' if i + 16 < len(cl) else ''))
+    return '\n'.join(lines) + '\n'
+
+
+if __name__ == '__main__':
+    text = render()
+    if '--check' in sys.argv:
+        ok = os.path.exists(OUT) and open(OUT).read() == text
+        print('gemm_w4_loop.inc', 'up to date' if ok else 'STALE')
+        sys.exit(0 if ok else 1)
+    with open(OUT, 'w') as f:
+        f.write(text)
+    print('wrote', OUT, len(program()), 'instructions')

@@ -33,6 +33,7 @@
 #include <map>
 #include <atomic>
 #include <mutex>
+#include <utility>
 
 typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1005,6 +1006,7 @@ struct vg_vit {
     bool att_tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);                    // attention: row-major V + transposing LDS reads
     bool att_stagger = !(getenv("VG_ATT_STAGGER") && atoi(getenv("VG_ATT_STAGGER")) == 0);     // attention: SIMD partners apart in phase (k_attention_f16 STAG)
     bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
+    int gemm_w4 = getenv("VG_GEMM_W4") ? atoi(getenv("VG_GEMM_W4")) : 0;                      // projection GEMMs by k_gemm_f16_w4 (4 waves, assembly K loop) instead of k_gemm_f16_pp64
     int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
@@ -1421,6 +1423,227 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm_f16_w4 (round 6): the same 256 x 256 x 64 macro tile with FOUR waves, one per SIMD, each 128 tokens x 128 features (8 x 8
+// MFMA tiles, 256 accumulators in a0..a255), and a K loop that is ONE hand-scheduled assembly block (csrc/gen_gemm_w4.py writes
+// gemm_w4_loop.inc: five-slot LDS ring, one barrier per K-tile, every LDS read / DMA piece / wait at a fixed distance between the
+// MFMAs).  A third less LDS read traffic per FLOP than 8 waves x 128 x 64, and no compiler between the MFMAs.  Prologue (tile
+// coordinates, folded LayerNorm statistics) and the epilogues are the HIP code of k_gemm_f16_pp64 re-derived for the 4-wave layout:
+// wave (wm, wn) holds rows wm 128 + mi 16 + (lane & 15), features wn 128 + ni 16 + 4 (lane >> 4) + e in a[4 (8 ni + mi) + e].
+// Same MFMAs, same operands, same K order, same epilogue expressions => the same bits as k_gemm_f16_pp64 (tests/test_gemm.py).
+#include "gemm_w4_loop.inc"
+template <int IDX>
+__device__ __forceinline__ f32x4 w4_acc() {          // accumulator tile IDX = 8 ni + mi out of the AGPRs the K loop left it in
+    f32x4 r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w)
+                 : "n"(4 * IDX), "n"(4 * IDX + 1), "n"(4 * IDX + 2), "n"(4 * IDX + 3));
+    return r;
+}
+template <int I> struct w4_ic { static constexpr int value = I; };
+template <int... Is, typename F>
+__device__ __forceinline__ void w4_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(w4_ic<Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void w4_for(F&& f) { w4_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+#define VG_W4_ASM_OF_(V) VG_W4_ASM_##V
+#define VG_W4_ASM_OF(V) VG_W4_ASM_OF_(V)
+template <int EPI, int LN = 0, int VAR = 0>
+__global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ X, const f16* __restrict__ Wt,
+                                                        const float* __restrict__ bias, void* __restrict__ Cout,
+                                                        float* __restrict__ resid, int M, int N, int K, int ldc, int cw,
+                                                        const float* __restrict__ ln_c1 = nullptr, LnPartial* __restrict__ ln_stats = nullptr,
+                                                        f16* __restrict__ ln_x16 = nullptr, long long* __restrict__ trace = nullptr) {
+    constexpr int BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    [[maybe_unused]] long long tr_entry = 0, tr_asm0 = 0, tr_asm1 = 0;
+    [[maybe_unused]] unsigned t_pro = 0, t_loop = 0, t_wait = 0, t_bar = 0, t_end = 0, t_cal = 0;
+    if (VAR == VG_W4_TRACE_VAR) tr_entry = clock64();
+    const int ntm = M / BM;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = ntm * cw;
+    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
+    const int np = K / 64;                          // host guarantees K % 64 == 0 and np >= 3
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int r15 = lane & 15, q4 = lane >> 4;
+    // folded LayerNorm, consumer side: thread t merges the K / 256 partials of tile row t (requested before the first pieces)
+    float2 ln_row = make_float2(0.f, 0.f);
+    LnPartial pt[4] = {};
+    const int nst = K >> 8;
+    if (LN == 1) {
+        const LnPartial* sp = ln_stats + (size_t)(m0 + tid) * nst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pt[i] = i < nst ? sp[i] : LnPartial{0.f, 0.f};
+    }
+    {
+        // DMA piece p of a wave: rows 64 w + 8 p + (lane >> 3), 16-byte chunk (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1)
+        const unsigned rowb = (unsigned)K * 2u;
+        const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
+        const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
+        const unsigned swz = (unsigned)((r15 >> 1) & 7);
+        const unsigned xo0 = (unsigned)(wm * 128 + r15) * 128u + (((unsigned)q4 ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15) * 128u + (((unsigned)(4 + q4) ^ swz) << 4);
+        const unsigned wo0 = (unsigned)(wn * 128 + r15) * 128u + (((unsigned)q4 ^ swz) << 4), wo1 = (unsigned)(wn * 128 + r15) * 128u + (((unsigned)(4 + q4) ^ swz) << 4);
+        const unsigned long long xp = (unsigned long long)(X + (size_t)(m0 + wave * 64) * K);
+        const unsigned long long wp = (unsigned long long)(Wt + (size_t)(n0 + wave * 64) * K);
+        const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));
+        const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wp), whi = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem);
+        const unsigned rs8 = __builtin_amdgcn_readfirstlane(8u * rowb), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#define VG_W4_RUN(V)                                                                                                              \
+        asm volatile(VG_W4_ASM_OF(V)                                                                                                  \
+                     :                                                                                                                \
+                     : [dv0] "v"(dv0), [dv1] "v"(dv1), [xo0] "v"(xo0), [xo1] "v"(xo1), [wo0] "v"(wo0), [wo1] "v"(wo1),                \
+                       [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [rs8] "s"(rs8), [lds0] "s"(lds0),              \
+                       [wdst] "s"(wdst), [np] "s"(npu)                                                                                \
+                     : VG_W4_CLOBBERS)
+#define VG_W4_RUN_TRACE(V)                                                                                                        \
+        tr_asm0 = clock64();                                                                                                          \
+        asm volatile(VG_W4_ASM_OF(V)                                                                                                  \
+                     : [t_pro] "=s"(t_pro), [t_loop] "=s"(t_loop), [t_wait] "=s"(t_wait), [t_bar] "=s"(t_bar), [t_end] "=s"(t_end),   \
+                       [t_cal] "=s"(t_cal)                                                                                            \
+                     : [dv0] "v"(dv0), [dv1] "v"(dv1), [xo0] "v"(xo0), [xo1] "v"(xo1), [wo0] "v"(wo0), [wo1] "v"(wo1),                \
+                       [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [rs8] "s"(rs8), [lds0] "s"(lds0),              \
+                       [wdst] "s"(wdst), [np] "s"(npu)                                                                                \
+                     : VG_W4_CLOBBERS);                                                                                               \
+        tr_asm1 = clock64()
+        if constexpr (VAR == 0) { VG_W4_RUN(0); }
+#ifdef VG_DEV      // ablations and alternative schedules (gen_gemm_w4.py VARIANTS): development build, VG_GEMM_W4 = 1 + VAR
+        VG_W4_DEV_RUNS
+#endif
+#undef VG_W4_RUN
+#undef VG_W4_RUN_TRACE
+#pragma clang diagnostic pop
+    }
+    if (LN == 1) {
+        float ms = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ms += pt[i].mean; m2 += pt[i].m2; }
+        const float mean = ms / (float)nst;
+        float dev = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < nst) { const float d = pt[i].mean - mean; dev += d * d; }
+        ln_row = make_float2(mean, rsqrtf((m2 + 256.f * dev) / (float)K + 1e-5f));
+    }
+    // ---- epilogue: the chunk-XOR-swizzled LDS images of k_gemm_f16_pp64 ----
+    __syncthreads();
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        float ln_mean[8], ln_rstd[8];
+        if (LN == 1) {
+            float2* lsm = (float2*)(smem + 131072);
+            lsm[tid] = ln_row;
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const float2 t2 = lsm[wm * 128 + mi * 16 + r15];
+                ln_mean[mi] = t2.x; ln_rstd[mi] = t2.y;
+            }
+        }
+        w4_for<8>([&](auto nic) {
+            constexpr int ni = decltype(nic)::value;
+            const int nloc = wn * 128 + ni * 16 + 4 * q4;
+            const float4 b4 = *(const float4*)(bias + n0 + nloc);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LN == 1) c4 = *(const float4*)(ln_c1 + n0 + nloc);
+            const int ch = nloc >> 3, hf = (nloc >> 2) & 1;
+            w4_for<8>([&](auto mic) {
+                constexpr int mi = decltype(mic)::value;
+                const f32x4 a = w4_acc<ni * 8 + mi>();
+                const int m = wm * 128 + mi * 16 + r15;
+                float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
+                if (LN == 1) {
+                    v[0] = ln_rstd[mi] * (a[0] - ln_mean[mi] * c4.x) + b4.x;
+                    v[1] = ln_rstd[mi] * (a[1] - ln_mean[mi] * c4.y) + b4.y;
+                    v[2] = ln_rstd[mi] * (a[2] - ln_mean[mi] * c4.z) + b4.z;
+                    v[3] = ln_rstd[mi] * (a[3] - ln_mean[mi] * c4.w) + b4.w;
+                }
+                f16x4 h4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = v[e];
+                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
+                    h4[e] = (f16)x;
+                }
+                *(f16x4*)(smem + m * 512 + ((ch ^ (m & 31)) << 4) + hf * 8) = h4;
+            });
+        });
+        __syncthreads();
+        const int j = tid & 31, rr = tid >> 5;
+#pragma unroll 4
+        for (int pass = 0; pass < 32; ++pass) {
+            const int m = pass * 8 + rr;
+            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
+            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (wm == half) {
+                w4_for<8>([&](auto nic) {
+                    constexpr int ni = decltype(nic)::value;
+                    const int nloc = wn * 128 + ni * 16 + 4 * q4;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
+                    const int ch = nloc >> 2;
+                    w4_for<8>([&](auto mic) {
+                        constexpr int mi = decltype(mic)::value;
+                        const f32x4 a = w4_acc<ni * 8 + mi>();
+                        const int m = mi * 16 + r15;
+                        *(float4*)(smem + m * 1024 + ((ch ^ (m & 31)) << 4)) = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+                    });
+                });
+            }
+            __syncthreads();
+            const int j = tid & 63, rr = tid >> 6;
+#pragma unroll
+            for (int p8 = 0; p8 < 4; ++p8) {
+                float4 x4[8];                      // eight residual loads in flight before the first store
+                if (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int m = (p8 * 8 + q) * 4 + rr;
+                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int m = (p8 * 8 + q) * 4 + rr;
+                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
+                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
+                    if (EPI == EPI_BIAS_RESID) {
+                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
+                        *(float4*)(resid + off) = v;
+                        if (LN == 2) {
+                            const f16x4 h4 = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
+                            *(f16x4*)(ln_x16 + off) = h4;
+                            const float mean = row256_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+                            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+                            const float m2 = row256_sum((a * a + b * b) + (c * c + d * d));
+                            if (j == 0) ln_stats[(size_t)(m0 + half * 128 + m) * (N >> 8) + tn] = LnPartial{mean, m2};
+                        }
+                    } else {
+                        *(float4*)((float*)Cout + off) = v;
+                    }
+                }
+            }
+        }
+    }
+#ifdef VG_DEV
+    if (VAR == VG_W4_TRACE_VAR && lane == 0 && trace) {      // per wave: cycles of entry -> asm, asm prologue, K loop, its waits, the epilogue
+        long long* o = trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+        const long long t2 = clock64();
+        o[0] = tr_asm0 - tr_entry; o[1] = t_pro; o[2] = t_loop; o[3] = t_wait; o[4] = t_bar; o[5] = t_end; o[6] = t_cal;
+        o[7] = t2 - tr_asm1; o[8] = tr_asm1 - tr_asm0; o[9] = np; o[10] = wave; o[11] = wall_clock64();
+    }
+#endif
+}
+
 // Column tiles (256 wide) per L2 chunk of the tile order for the 256 x 256 kernels.  Measured at M = 64512 (sweep with
 // VG_GEMM_CW): sharing one activation row-tile between ALL column tiles that run together wins as long as there are at most
 // 9 of them (in_proj 9: 278 vs 292 us; c_proj 3, K = 3072: 302 vs 345 us although its 4.7 MB of weights exceed one XCD's L2 --
@@ -1539,6 +1762,23 @@ static int launch_gemm_pp64(const void* X, const void* Wt, const float* bias, vo
     return VG_OK;
 }
 
+template <int EPI, int LN = 0, int VAR = 0>
+static int launch_gemm_w4(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
+                          hipStream_t st, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr, f16* ln_x16 = nullptr,
+                          long long* trace = nullptr) {
+    if (M % 256 || N % 256 || K % 64 || K / 64 < 3) return VG_ERR_ARG;
+    if (LN == 1 && (K % 256 || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
+    if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
+    auto kern = k_gemm_f16_w4<EPI, LN, VAR>;
+    const int lds = 5 * 32768;
+    VG_MAX_DYNAMIC_LDS(kern, lds);
+    const int ntn = N / 256;
+    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(256), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
+                       ldc, gemm_chunk_tiles_256(ntn), ln_c1, ln_stats, ln_x16, trace);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
 // rows [row0, row0 + Mt) of a residual GEMM, K-split `parts` ways through `scratch` (see k_splitk_resid)
 template <int LN>
 static int launch_gemm_resid_tail(const void* X, const void* Wt, const float* bias, float* resid, int row0, int Mt, int N, int K, int ldc,
@@ -1625,6 +1865,14 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                                                               ln_stats, ln_x16);
                         }
                     }
+                }
+                if (v->gemm_w4 && K / 64 >= 3) {
+#ifdef VG_DEV
+                    if constexpr (LN == 0 && EPI == EPI_BIAS) {
+                        switch (v->gemm_w4) { VG_W4_DEV_CASES(EPI, LN) }
+                    }
+#endif
+                    return launch_gemm_w4<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
                 }
                 return launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
             }
