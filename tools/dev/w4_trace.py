@@ -32,6 +32,8 @@ for name, N, K in [('in_proj', 2304, 768), ('out_proj', 768, 768), ('c_proj', 76
           f'epilogue {med[7]:.0f}  whole asm {med[8]:.0f}', flush=True)
     print(f'    per K-tile: M wait {med[3] / (npk - 1) - cal:.0f}  barrier {med[4] / (npk - 1) - cal:.0f}  end wait {med[5] / (npk - 1) - cal:.0f}  '
           f'(stamp pair alone {cal:.0f}; each figure includes ~16-32 cycles of the MFMA between its stamps)', flush=True)
+    first = t[:256 * 4].median(0).values.tolist(); rest = t[256 * 4:].median(0).values.tolist()
+    print(f'    first round of workgroups: prologue {first[1]:.0f}  loop/tile {first[2] / npk:.0f}  epilogue {first[7]:.0f};  later rounds: prologue {rest[1]:.0f}  loop/tile {rest[2] / npk:.0f}  epilogue {rest[7]:.0f}', flush=True)
     for w in range(4):
         tw = t[t[:, 10] == w].median(0).values.tolist()
         print(f'    wave {w}: loop {tw[2] / npk:.0f}/tile  M wait {tw[3] / (npk - 1) - cal:.0f}  barrier {tw[4] / (npk - 1) - cal:.0f}  end {tw[5] / (npk - 1) - cal:.0f}', flush=True)

@@ -6,8 +6,12 @@
 What the loop is (round 6; the projection GEMMs of third_party/CLIP/clip/model.py:171-192):
   * workgroup = 4 waves, one per SIMD; 256 x 256 x 64 macro tile; wave (wm, wn) owns 128 tokens x 128 features = 8 x 8 tiles of
     v_mfma_f32_16x16x32_f16, i.e. 256 accumulator registers, which live in a0..a255 for the whole tile (the compiler never sees them:
-    the epilogue fetches them with v_accvgpr_read).  A operand = 16 weight rows, B operand = 16 token rows (the transposed tile, as in
-    k_gemm_f16_pp64): same MFMAs on the same operands in the same K order, hence the same bits.
+    the epilogue fetches them with v_accvgpr_read).  A operand = 16 token rows (X fragment mi), B operand = 16 weight rows (W fragment
+    ni): lane l of accumulator tile (ni, mi) holds tokens mi 16 + 4 (l >> 4) + e and the feature whose weight row sits at LDS row
+    ni 16 + (l & 15) of the wave's half.  WHICH feature that is the kernel chooses through the W pieces' source addresses (the LDS
+    image of W is a row permutation of the tile): for fp16 outputs LDS row ni 16 + r holds feature 8 r + ni, so a lane's eight tiles
+    ni = 0..7 are eight consecutive features = one 16-byte store, sixteen lanes = 256 contiguous bytes of an output row; for fp32
+    outputs feature 64 (ni >> 2) + 4 r + (ni & 3).  The epilogue therefore needs neither LDS nor barriers.
   * LDS: a ring of FIVE 32 KB slots (all 160 KB), a slot = 256 rows x 128 B of one operand for one K-tile, 16-byte chunk c of row r at
     c ^ ((r >> 1) & 7).  X(t) sits in slot 2t mod 5, W(t) in 2t + 1 mod 5.  Filled by LDS-DMA (`buffer_load_dwordx4 ... lds`, a piece =
     8 rows x 128 B, the swizzle applied to the per-lane SOURCE address); a wave fills rows [64 w, 64 w + 64) of every slot: 8 + 8
@@ -19,8 +23,10 @@ What the loop is (round 6; the projection GEMMs of third_party/CLIP/clip/model.p
   * every LDS read, DMA piece, address update and wait sits at a fixed distance between the MFMAs (the table SCHED below): nothing is
     left to the compiler's scheduler.
 
-Registers: v128..v255 fragments (W half 0, X half 0, W half 1, X half 1: 32 each), v120..v123 read addresses, s68..s91 (piece offsets,
-slot ring, buffer descriptors, loop counter).  Everything else comes in through named operands.
+Registers: v128..v255 fragments (W half 0, X half 0, W half 1, X half 1: 32 each), v120..v123 read addresses, s60..s91 (piece offsets,
+slot ring, buffer descriptors, loop counter; s92..s101 cycle stamps of the trace variant).  Everything else comes in through named
+operands: per-lane DMA offsets dv0/dv1 (X, even / odd pieces) and dw0/dw1 (W), fragment read offsets xo0/xo1/wo0/wo1, the operand
+bases of this wave (xlo/xhi, wlo/whi), rowb = bytes per operand row, wpo = byte offset of W's odd pieces, lds0, wdst, np.
 """
 import os
 import sys
@@ -32,21 +38,21 @@ FW = (128, 192)          # W fragments (A operand), k32 half 0 / 1: v[FW[h] + 4 
 FX = (160, 224)          # X fragments (B operand)
 VA_W = (120, 121)        # LDS read address of the W fragments, half 0 / 1
 VA_X = (122, 123)
-S_OFF = 68               # s68..s74: piece offsets p * (8 rows) for p = 1..7
-S_DST = 75               # slot + this wave's share: M0 base of the pieces being issued
-S_SLOT = (76, 77, 78, 79, 80)   # a, b, c, d, e = slots of X(i), W(i), X(i+1), W(i+1), X(i+2)
-S_TMP = 81
-S_CNT = 82
-S_WDST = 83              # this wave's byte offset inside a slot (64 rows x 128 B x wave)
-SRD = {'x': 84, 'w': 88}       # s[84:87], s[88:91]
+S_OFF = {'x': 60, 'w': 84}     # s60..s66 / s84..s90: source offsets of pieces p = 1..7 (X: p x 8 rows; W: (p & 1) wpo + (p >> 1) rows)
+S_DST = 67               # slot + this wave's share: M0 base of the pieces being issued
+S_SLOT = (68, 69, 70, 71, 72)   # a, b, c, d, e = slots of X(i), W(i), X(i+1), W(i+1), X(i+2)
+S_TMP = 73
+S_CNT = 74
+S_WDST = 75              # this wave's byte offset inside a slot (64 rows x 128 B x wave)
+SRD = {'x': 76, 'w': 80}       # s[76:79], s[80:83]
 
 
 def mfma(k):
     h, kk = divmod(k, 64)
-    ni, mi = divmod(kk, 8)
+    mi, ni = divmod(kk, 8)         # the A operand (token rows) stays for eight MFMAs
     a = 4 * (ni * 8 + mi)
     return 'v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]' % (
-        a, a + 3, FW[h] + 4 * ni, FW[h] + 4 * ni + 3, FX[h] + 4 * mi, FX[h] + 4 * mi + 3, a, a + 3)
+        a, a + 3, FX[h] + 4 * mi, FX[h] + 4 * mi + 3, FW[h] + 4 * ni, FW[h] + 4 * ni + 3, a, a + 3)
 
 
 def rd(op, h, i):
@@ -68,8 +74,8 @@ def m0(p):
 
 
 def piece(op, p):
-    so = '0' if p == 0 else 's%d' % (S_OFF + p - 1)
-    return 'buffer_load_dwordx4 %%[dv%d], s[%d:%d], %s offen lds' % (p & 1, SRD[op], SRD[op] + 3, so)
+    so = '0' if p == 0 else 's%d' % (S_OFF[op] + p - 1)
+    return 'buffer_load_dwordx4 %%[d%s%d], s[%d:%d], %s offen lds' % ('v' if op == 'x' else 'w', p & 1, SRD[op], SRD[op] + 3, so)
 
 
 def advance(op):
@@ -98,7 +104,7 @@ def stamp_take(acc):
 SCHED = dict(
     rd1_first=1, rd1_pattern=(0, 1),     # second sub-step's fragments: two reads in every three gaps from gap rd1_first on
     wait_m=31, bar_m=32,                 # s_waitcnt vmcnt(..) lgkmcnt(0) behind MFMA 31, s_barrier behind MFMA 32
-    dma_w_first=34, dma_x_first=50, dma_step=2,
+    dma_w_first=34, dma_x_first=58, dma_step=3,
     rd0_first=67, rd0_pattern=(0, 1),
     rotate_at=100, loop_at=127, wait_end=126,
 )
@@ -183,9 +189,14 @@ def prologue():
             's_mov_b32 s%d, 0x00020000' % (SRD['x'] + 3)]
     out += ['s_mov_b32 s%d, %%[wlo]' % SRD['w'], 's_mov_b32 s%d, %%[whi]' % (SRD['w'] + 1), 's_mov_b32 s%d, 0x80000000' % (SRD['w'] + 2),
             's_mov_b32 s%d, 0x00020000' % (SRD['w'] + 3)]
-    out.append('s_mov_b32 s%d, %%[rs8]' % S_OFF)
+    ox, ow = S_OFF['x'], S_OFF['w']
+    out.append('s_lshl_b32 s%d, %%[rowb], 3' % ox)                       # X piece p: rows 8 p
     for p in range(2, 8):
-        out.append('s_add_u32 s%d, s%d, %%[rs8]' % (S_OFF + p - 1, S_OFF + p - 2))
+        out.append('s_add_u32 s%d, s%d, s%d' % (ox + p - 1, ox + p - 2, ox))
+    out.append('s_mov_b32 s%d, %%[wpo]' % ow)                            # W piece p: (p & 1) wpo + (p >> 1) rows
+    out.append('s_mov_b32 s%d, %%[rowb]' % (ow + 1))
+    for p in range(3, 8):
+        out.append('s_add_u32 s%d, s%d, %%[rowb]' % (ow + p - 1, ow + p - 3))
     for i, sl in enumerate(S_SLOT):
         out.append('s_add_u32 s%d, %%[lds0], %d' % (sl, 32768 * i))
     out.append('s_mov_b32 s%d, %%[wdst]' % S_WDST)
@@ -229,7 +240,7 @@ def clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += ['"v%d"' % i for i in range(120, 256)]
     c += ['"a%d"' % i for i in range(256)]
-    c += ['"s%d"' % i for i in range(S_OFF, 102)]
+    c += ['"s%d"' % i for i in range(60, 102)]
     return c
 
 
@@ -241,13 +252,9 @@ VARIANTS = [
     dict(no_reads=True),                     # 2
     dict(no_barrier=True),                   # 3
     dict(no_dma=True, no_reads=True, no_barrier=True),   # 4: MFMAs only
-    dict(dma_step=3, dma_x_first=58),                    # 5
+    dict(dma_step=2, dma_x_first=50),                    # 5: the first schedule (a piece every second gap)
     dict(dma_step=4, dma_x_first=66),                    # 6
-    dict(dma_step=5, dma_x_first=74, rotate_at=112),     # 7
-    dict(dma_step=6, dma_x_first=82, rotate_at=112),     # 8
-    dict(dma_step=5, wait_m=39, bar_m=40, dma_w_first=42, dma_x_first=82, rotate_at=112),      # 9: M later
-    dict(dma_step=4, rd1_pattern=(0,), rd1_first=1, wait_m=55, bar_m=56, dma_w_first=58, dma_x_first=90, rotate_at=121),   # 10: M at 56, one read per 3 gaps
-    dict(dma_step=3, dma_x_first=58, trace=True),       # 11: variant 5 with cycle stamps (vg_gemm_trace var 50)
+    dict(trace=True),                                    # 7: the product schedule with cycle stamps (vg_gemm_trace var 50)
 ]
 
 

@@ -1427,17 +1427,21 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 // k_gemm_f16_w4 (round 6): the same 256 x 256 x 64 macro tile with FOUR waves, one per SIMD, each 128 tokens x 128 features (8 x 8
 // MFMA tiles, 256 accumulators in a0..a255), and a K loop that is ONE hand-scheduled assembly block (csrc/gen_gemm_w4.py writes
 // gemm_w4_loop.inc: five-slot LDS ring, one barrier per K-tile, every LDS read / DMA piece / wait at a fixed distance between the
-// MFMAs).  A third less LDS read traffic per FLOP than 8 waves x 128 x 64, and no compiler between the MFMAs.  Prologue (tile
-// coordinates, folded LayerNorm statistics) and the epilogues are the HIP code of k_gemm_f16_pp64 re-derived for the 4-wave layout:
-// wave (wm, wn) holds rows wm 128 + mi 16 + (lane & 15), features wn 128 + ni 16 + 4 (lane >> 4) + e in a[4 (8 ni + mi) + e].
-// Same MFMAs, same operands, same K order, same epilogue expressions => the same bits as k_gemm_f16_pp64 (tests/test_gemm.py).
+// MFMAs).  A third less LDS read traffic per FLOP than 8 waves x 128 x 64, and no compiler between the MFMAs.
+//   A operand = token rows, B operand = weight rows; the LDS image of W is ROW-PERMUTED (through the source addresses of its DMA
+//   pieces) so that the eight accumulator tiles ni = 0..7 of a lane are consecutive features: lane (r = lane & 15, q = lane >> 4) of
+//   tile (ni, mi), register e holds token mi 16 + 4 q + e and
+//       fp16 outputs:  feature 8 r + ni                      -> one 16-byte store per (mi, e), sixteen lanes = 256 contiguous bytes
+//       fp32 outputs:  feature 64 (ni >> 2) + 4 r + (ni & 3) -> two 16-byte accesses per (mi, e), sixteen lanes = 256 contiguous bytes
+//   of the wave's 128 x 128 quadrant (wm, wn).  The epilogue goes straight from the accumulators to global memory: no LDS image, no
+//   barrier.  Same MFMA products in the same K order as k_gemm_f16_pp64 => the same accumulator bits (tests/test_gemm.py).
+//   Folded LayerNorm: the producer (LN = 2) writes one (mean, M2) partial per row and 128-COLUMN half (this wave's), the consumer
+//   (LN = 1) merges K / 128 of them; k_gemm_f16_pp64 keeps one per 256 columns -- a tower uses one kernel family throughout.
 #include "gemm_w4_loop.inc"
-template <int IDX>
-__device__ __forceinline__ f32x4 w4_acc() {          // accumulator tile IDX = 8 ni + mi out of the AGPRs the K loop left it in
-    f32x4 r;
-    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
-                 : "=v"(r.x), "=v"(r.y), "=v"(r.z), "=v"(r.w)
-                 : "n"(4 * IDX), "n"(4 * IDX + 1), "n"(4 * IDX + 2), "n"(4 * IDX + 3));
+template <int IDX, int E>
+__device__ __forceinline__ float w4_acc() {          // register E of accumulator tile IDX = 8 ni + mi, out of the AGPR the K loop left it in
+    float r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(4 * IDX + E));
     return r;
 }
 template <int I> struct w4_ic { static constexpr int value = I; };
@@ -1445,6 +1449,13 @@ template <int... Is, typename F>
 __device__ __forceinline__ void w4_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(w4_ic<Is>{}), ...); }
 template <int N, typename F>
 __device__ __forceinline__ void w4_for(F&& f) { w4_for_impl(std::make_integer_sequence<int, N>{}, f); }
+__device__ __forceinline__ float w4_row16_sum(float v) {      // sum over the 16 lanes of a DPP row (the lanes that share lane >> 4), in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
 
 #define VG_W4_ASM_OF_(V) VG_W4_ASM_##V
 #define VG_W4_ASM_OF(V) VG_W4_ASM_OF_(V)
@@ -1455,6 +1466,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                                                         const float* __restrict__ ln_c1 = nullptr, LnPartial* __restrict__ ln_stats = nullptr,
                                                         f16* __restrict__ ln_x16 = nullptr, long long* __restrict__ trace = nullptr) {
     constexpr int BM = 256, BN = 256;
+    constexpr bool F16OUT = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -1470,47 +1482,51 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     const int np = K / 64;                          // host guarantees K % 64 == 0 and np >= 3
     const int m0 = tm * BM, n0 = tn * BN;
     const int r15 = lane & 15, q4 = lane >> 4;
-    // folded LayerNorm, consumer side: thread t merges the K / 256 partials of tile row t (requested before the first pieces)
-    float2 ln_row = make_float2(0.f, 0.f);
-    LnPartial pt[4] = {};
-    const int nst = K >> 8;
+    // folded LayerNorm, consumer side: lane l of wave (wm, .) merges the K / 128 partials of tile rows wm 128 + l and wm 128 + 64 + l
+    // (requested before the first pieces; both waves of a row half do it) and hands (mean, rstd) to the lanes that need them by ds_bpermute
+    constexpr int NSTMAX = 8;                       // width <= 1024
+    const int nst = K >> 7;
+    LnPartial pt[2][NSTMAX] = {};
     if (LN == 1) {
-        const LnPartial* sp = ln_stats + (size_t)(m0 + tid) * nst;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pt[i] = i < nst ? sp[i] : LnPartial{0.f, 0.f};
+        for (int h = 0; h < 2; ++h) {
+            const LnPartial* sp = ln_stats + (size_t)(m0 + wm * 128 + h * 64 + lane) * nst;
+#pragma unroll
+            for (int i = 0; i < NSTMAX; ++i) pt[h][i] = i < nst ? sp[i] : LnPartial{0.f, 0.f};
+        }
     }
     {
-        // DMA piece p of a wave: rows 64 w + 8 p + (lane >> 3), 16-byte chunk (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1)
+        // DMA piece p of wave w fills LDS rows 64 w + 8 p + (lane >> 3) of a slot, 16-byte chunk slot lane & 7; the source chunk is
+        // (lane & 7) ^ ((LDS row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1).  X: LDS row = tile row.  W: LDS row h 128 + ni 16 + r
+        // (h = w >> 1, ni = 4 (w & 1) + (p >> 1), r = 8 (p & 1) + (lane >> 3)) holds the feature the output layout asks for (above).
         const unsigned rowb = (unsigned)K * 2u;
         const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
         const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
+        const unsigned wlm = F16OUT ? 8u : 4u;                                   // feature step per (lane >> 3)
+        const unsigned dw0 = (unsigned)(lane >> 3) * wlm * rowb + (c0 << 4), dw1 = (unsigned)(lane >> 3) * wlm * rowb + ((c0 ^ 4u) << 4);
+        const unsigned wpo = __builtin_amdgcn_readfirstlane((F16OUT ? 64u : 32u) * rowb);     // odd pieces: r += 8
+        const int wrow0 = (wave >> 1) * 128 + (F16OUT ? (wave & 1) * 4 : (wave & 1) * 64);      // feature of (ni = 4 (w & 1), r = 0)
         const unsigned swz = (unsigned)((r15 >> 1) & 7);
         const unsigned xo0 = (unsigned)(wm * 128 + r15) * 128u + (((unsigned)q4 ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15) * 128u + (((unsigned)(4 + q4) ^ swz) << 4);
         const unsigned wo0 = (unsigned)(wn * 128 + r15) * 128u + (((unsigned)q4 ^ swz) << 4), wo1 = (unsigned)(wn * 128 + r15) * 128u + (((unsigned)(4 + q4) ^ swz) << 4);
         const unsigned long long xp = (unsigned long long)(X + (size_t)(m0 + wave * 64) * K);
-        const unsigned long long wp = (unsigned long long)(Wt + (size_t)(n0 + wave * 64) * K);
+        const unsigned long long wp = (unsigned long long)(Wt + (size_t)(n0 + wrow0) * K);
         const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));
         const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wp), whi = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem);
-        const unsigned rs8 = __builtin_amdgcn_readfirstlane(8u * rowb), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
+        const unsigned rowbs = __builtin_amdgcn_readfirstlane(rowb), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-#define VG_W4_RUN(V)                                                                                                              \
-        asm volatile(VG_W4_ASM_OF(V)                                                                                                  \
-                     :                                                                                                                \
-                     : [dv0] "v"(dv0), [dv1] "v"(dv1), [xo0] "v"(xo0), [xo1] "v"(xo1), [wo0] "v"(wo0), [wo1] "v"(wo1),                \
-                       [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [rs8] "s"(rs8), [lds0] "s"(lds0),              \
-                       [wdst] "s"(wdst), [np] "s"(npu)                                                                                \
-                     : VG_W4_CLOBBERS)
-#define VG_W4_RUN_TRACE(V)                                                                                                        \
+#define VG_W4_IN [dv0] "v"(dv0), [dv1] "v"(dv1), [dw0] "v"(dw0), [dw1] "v"(dw1), [xo0] "v"(xo0), [xo1] "v"(xo1), [wo0] "v"(wo0),            \
+                 [wo1] "v"(wo1), [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [rowb] "s"(rowbs), [wpo] "s"(wpo),         \
+                 [lds0] "s"(lds0), [wdst] "s"(wdst), [np] "s"(npu)
+#define VG_W4_RUN(V) asm volatile(VG_W4_ASM_OF(V) : : VG_W4_IN : VG_W4_CLOBBERS)
+#define VG_W4_RUN_TRACE(V)                                                                                                            \
         tr_asm0 = clock64();                                                                                                          \
         asm volatile(VG_W4_ASM_OF(V)                                                                                                  \
                      : [t_pro] "=s"(t_pro), [t_loop] "=s"(t_loop), [t_wait] "=s"(t_wait), [t_bar] "=s"(t_bar), [t_end] "=s"(t_end),   \
                        [t_cal] "=s"(t_cal)                                                                                            \
-                     : [dv0] "v"(dv0), [dv1] "v"(dv1), [xo0] "v"(xo0), [xo1] "v"(xo1), [wo0] "v"(wo0), [wo1] "v"(wo1),                \
-                       [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [rs8] "s"(rs8), [lds0] "s"(lds0),              \
-                       [wdst] "s"(wdst), [np] "s"(npu)                                                                                \
-                     : VG_W4_CLOBBERS);                                                                                               \
+                     : VG_W4_IN : VG_W4_CLOBBERS);                                                                                    \
         tr_asm1 = clock64()
         if constexpr (VAR == 0) { VG_W4_RUN(0); }
 #ifdef VG_DEV      // ablations and alternative schedules (gen_gemm_w4.py VARIANTS): development build, VG_GEMM_W4 = 1 + VAR
@@ -1518,121 +1534,101 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
 #endif
 #undef VG_W4_RUN
 #undef VG_W4_RUN_TRACE
+#undef VG_W4_IN
 #pragma clang diagnostic pop
     }
+    // ---- epilogue: accumulators -> global memory ----
+    float ln_mean2[2] = {0.f, 0.f}, ln_rstd2[2] = {0.f, 0.f};
     if (LN == 1) {
-        float ms = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ms += pt[i].mean; m2 += pt[i].m2; }
-        const float mean = ms / (float)nst;
-        float dev = 0.f;
+        for (int h = 0; h < 2; ++h) {
+            float ms = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (i < nst) { const float d = pt[i].mean - mean; dev += d * d; }
-        ln_row = make_float2(mean, rsqrtf((m2 + 256.f * dev) / (float)K + 1e-5f));
+            for (int i = 0; i < NSTMAX; ++i) { ms += pt[h][i].mean; m2 += pt[h][i].m2; }
+            const float mean = ms / (float)nst;
+            float dev = 0.f;
+#pragma unroll
+            for (int i = 0; i < NSTMAX; ++i) if (i < nst) { const float d = pt[h][i].mean - mean; dev += d * d; }
+            ln_mean2[h] = mean;
+            ln_rstd2[h] = rsqrtf((m2 + 128.f * dev) / (float)K + 1e-5f);
+        }
     }
-    // ---- epilogue: the chunk-XOR-swizzled LDS images of k_gemm_f16_pp64 ----
-    __syncthreads();
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        float ln_mean[8], ln_rstd[8];
+    if constexpr (F16OUT) {
+        const int ncol = n0 + wn * 128 + r15 * 8;
+        const float4 b0 = *(const float4*)(bias + ncol), b1 = *(const float4*)(bias + ncol + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float cc[8] = {};
         if (LN == 1) {
-            float2* lsm = (float2*)(smem + 131072);
-            lsm[tid] = ln_row;
-            __syncthreads();
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const float2 t2 = lsm[wm * 128 + mi * 16 + r15];
-                ln_mean[mi] = t2.x; ln_rstd[mi] = t2.y;
-            }
+            const float4 c0_ = *(const float4*)(ln_c1 + ncol), c1_ = *(const float4*)(ln_c1 + ncol + 4);
+            cc[0] = c0_.x; cc[1] = c0_.y; cc[2] = c0_.z; cc[3] = c0_.w; cc[4] = c1_.x; cc[5] = c1_.y; cc[6] = c1_.z; cc[7] = c1_.w;
         }
-        w4_for<8>([&](auto nic) {
-            constexpr int ni = decltype(nic)::value;
-            const int nloc = wn * 128 + ni * 16 + 4 * q4;
-            const float4 b4 = *(const float4*)(bias + n0 + nloc);
-            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (LN == 1) c4 = *(const float4*)(ln_c1 + n0 + nloc);
-            const int ch = nloc >> 3, hf = (nloc >> 2) & 1;
-            w4_for<8>([&](auto mic) {
-                constexpr int mi = decltype(mic)::value;
-                const f32x4 a = w4_acc<ni * 8 + mi>();
-                const int m = wm * 128 + mi * 16 + r15;
-                float v[4] = {a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w};
-                if (LN == 1) {
-                    v[0] = ln_rstd[mi] * (a[0] - ln_mean[mi] * c4.x) + b4.x;
-                    v[1] = ln_rstd[mi] * (a[1] - ln_mean[mi] * c4.y) + b4.y;
-                    v[2] = ln_rstd[mi] * (a[2] - ln_mean[mi] * c4.z) + b4.z;
-                    v[3] = ln_rstd[mi] * (a[3] - ln_mean[mi] * c4.w) + b4.w;
+        f16* crow = (f16*)Cout + (size_t)(m0 + wm * 128 + 4 * q4) * ldc + ncol;
+        w4_for<8>([&](auto mic) {
+            constexpr int mi = decltype(mic)::value;
+            w4_for<4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                float mean = 0.f, rstd = 1.f;
+                if (LN == 1) {           // row mi 16 + 4 q + e of the wave's half sits in lane (row & 63), register set mi >> 2
+                    const int src = ((mi * 16 + 4 * q4 + e) & 63) << 2;
+                    mean = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_mean2[mi >> 2])));
+                    rstd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_rstd2[mi >> 2])));
                 }
-                f16x4 h4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e];
-                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
-                    h4[e] = (f16)x;
-                }
-                *(f16x4*)(smem + m * 512 + ((ch ^ (m & 31)) << 4) + hf * 8) = h4;
-            });
-        });
-        __syncthreads();
-        const int j = tid & 31, rr = tid >> 5;
-#pragma unroll 4
-        for (int pass = 0; pass < 32; ++pass) {
-            const int m = pass * 8 + rr;
-            const f16x8 v = *(const f16x8*)(smem + m * 512 + j * 16);
-            *(f16x8*)((f16*)Cout + (size_t)(m0 + m) * ldc + n0 + ((j ^ (m & 31)) << 3)) = v;
-        }
-    } else {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();
-            if (wm == half) {
+                f16x8 h8;
                 w4_for<8>([&](auto nic) {
                     constexpr int ni = decltype(nic)::value;
-                    const int nloc = wn * 128 + ni * 16 + 4 * q4;
-                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (EPI == EPI_BIAS_RESID) b4 = *(const float4*)(bias + n0 + nloc);
-                    const int ch = nloc >> 2;
-                    w4_for<8>([&](auto mic) {
-                        constexpr int mi = decltype(mic)::value;
-                        const f32x4 a = w4_acc<ni * 8 + mi>();
-                        const int m = mi * 16 + r15;
-                        *(float4*)(smem + m * 1024 + ((ch ^ (m & 31)) << 4)) = make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
-                    });
+                    const float a = w4_acc<ni * 8 + mi, e>();
+                    float x = a + bb[ni];
+                    if (LN == 1) x = rstd * (a - mean * cc[ni]) + bb[ni];
+                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
+                    h8[ni] = (f16)x;
                 });
+                *(f16x8*)(crow + (size_t)(mi * 16 + e) * ldc) = h8;
+            });
+        });
+    } else {
+        // fp32: lane holds features 64 g + 4 r + j (ni = 4 g + j) of the wave's 128: two float4 per (mi, e)
+        const int ncol = n0 + wn * 128 + r15 * 4;
+        float4 b4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (EPI == EPI_BIAS_RESID) { b4[0] = *(const float4*)(bias + ncol); b4[1] = *(const float4*)(bias + ncol + 64); }
+        const size_t row0 = (size_t)(m0 + wm * 128 + 4 * q4);
+        float* base = (EPI == EPI_BIAS_RESID ? resid : (float*)Cout) + row0 * ldc + ncol;
+        float4 xa[4][2], xb[4][2];                  // the residual rows of mi (xa) and mi + 1 (xb): eight loads ahead of the stores
+        auto load_rows = [&](float4 (&x4)[4][2], int mi) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x4[e][0] = *(const float4*)(base + (size_t)(mi * 16 + e) * ldc);
+                x4[e][1] = *(const float4*)(base + (size_t)(mi * 16 + e) * ldc + 64);
             }
-            __syncthreads();
-            const int j = tid & 63, rr = tid >> 6;
-#pragma unroll
-            for (int p8 = 0; p8 < 4; ++p8) {
-                float4 x4[8];                      // eight residual loads in flight before the first store
-                if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int m = (p8 * 8 + q) * 4 + rr;
-                        x4[q] = *(const float4*)(resid + (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2));
-                    }
+        };
+        if (EPI == EPI_BIAS_RESID) load_rows(xa, 0);
+        w4_for<8>([&](auto mic) {
+            constexpr int mi = decltype(mic)::value;
+            float4 (&xc)[4][2] = (mi & 1) ? xb : xa;
+            float4 (&xn)[4][2] = (mi & 1) ? xa : xb;
+            if (EPI == EPI_BIAS_RESID && mi < 7) load_rows(xn, mi + 1);
+            w4_for<4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                float4 v[2];
+                w4_for<2>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    v[g] = make_float4(w4_acc<(4 * g + 0) * 8 + mi, e>() + b4[g].x, w4_acc<(4 * g + 1) * 8 + mi, e>() + b4[g].y,
+                                       w4_acc<(4 * g + 2) * 8 + mi, e>() + b4[g].z, w4_acc<(4 * g + 3) * 8 + mi, e>() + b4[g].w);
+                    if (EPI == EPI_BIAS_RESID) { v[g].x += xc[e][g].x; v[g].y += xc[e][g].y; v[g].z += xc[e][g].z; v[g].w += xc[e][g].w; }
+                    *(float4*)(base + (size_t)(mi * 16 + e) * ldc + 64 * g) = v[g];
+                });
+                if (EPI == EPI_BIAS_RESID && LN == 2) {
+                    // fp16 copy for the next GEMM + this row's statistics over the wave's 128 columns
+                    f16* xr = ln_x16 + (row0 + mi * 16 + e) * ldc + ncol;
+                    const f16x4 h0 = {(f16)v[0].x, (f16)v[0].y, (f16)v[0].z, (f16)v[0].w}, h1 = {(f16)v[1].x, (f16)v[1].y, (f16)v[1].z, (f16)v[1].w};
+                    *(f16x4*)xr = h0; *(f16x4*)(xr + 64) = h1;
+                    const float mean = w4_row16_sum(((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w))) * (1.0f / 128.0f);
+                    const float a0 = v[0].x - mean, a1 = v[0].y - mean, a2 = v[0].z - mean, a3 = v[0].w - mean;
+                    const float a4 = v[1].x - mean, a5 = v[1].y - mean, a6 = v[1].z - mean, a7 = v[1].w - mean;
+                    const float m2 = w4_row16_sum(((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7)));
+                    if (r15 == 0) ln_stats[(row0 + mi * 16 + e) * (size_t)(N >> 7) + 2 * tn + wn] = LnPartial{mean, m2};
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int m = (p8 * 8 + q) * 4 + rr;
-                    float4 v = *(const float4*)(smem + m * 1024 + j * 16);
-                    const size_t off = (size_t)(m0 + half * 128 + m) * ldc + n0 + ((j ^ (m & 31)) << 2);
-                    if (EPI == EPI_BIAS_RESID) {
-                        v.x += x4[q].x; v.y += x4[q].y; v.z += x4[q].z; v.w += x4[q].w;
-                        *(float4*)(resid + off) = v;
-                        if (LN == 2) {
-                            const f16x4 h4 = {(f16)v.x, (f16)v.y, (f16)v.z, (f16)v.w};
-                            *(f16x4*)(ln_x16 + off) = h4;
-                            const float mean = row256_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
-                            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-                            const float m2 = row256_sum((a * a + b * b) + (c * c + d * d));
-                            if (j == 0) ln_stats[(size_t)(m0 + half * 128 + m) * (N >> 8) + tn] = LnPartial{mean, m2};
-                        }
-                    } else {
-                        *(float4*)((float*)Cout + off) = v;
-                    }
-                }
-            }
-        }
+            });
+        });
     }
 #ifdef VG_DEV
     if (VAR == VG_W4_TRACE_VAR && lane == 0 && trace) {      // per wave: cycles of entry -> asm, asm prologue, K loop, its waits, the epilogue
@@ -2324,7 +2320,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             // the compacted class-token rows (the MLP buffer is free here), the queries scattered back to where the attention reads
             // them.  The other tokens' Q columns keep block L - 2's values: the attention's first query tile computes rows from them
             // that nobody reads (a query row never meets another query row).  Same kernel, same K loop per row: the same bits.
-            const int nst = W >> 8;
+            const int nst = v->gemm_w4 ? W >> 7 : W >> 8;        // partial statistics per row: per 128 columns (k_gemm_f16_w4) or per 256
             char* cb = (char*)mlp;
             f16* x16q = (f16*)cb;              cb += Mc_ * W * 2;
             f16* qc = (f16*)cb;                cb += Mc_ * W * 2;
