@@ -61,7 +61,7 @@ sys.path.insert(0, ROOT)
 
 VIT_FLOP_PER_CROP = 2 * 17_563_453_440
 PEAK_F16_MFMA_TFLOPS = 2500.0                   # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
-DOMINANT_KERNEL = 'k_gemm_f16_pp64'
+DOMINANT_KERNEL = 'k_gemm_f16_pp64' if os.environ.get('VG_GEMM_W4') == '0' else 'k_gemm_f16_w4'
 
 
 def cpu_baseline(n_points=150_000, n_objects=60, vit_crops=32, with_20k=True):

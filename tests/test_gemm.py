@@ -129,6 +129,7 @@ def test_gemm_resid_splitk_tail(cuda, K, rows, monkeypatch):
     resid = torch.randn(M, N, generator=g).to(cuda)
     scratch = torch.empty(64 << 20, dtype=torch.uint8, device=cuda)
     outs = {}
+    monkeypatch.setenv('VG_GEMM_W4', '0')          # the split-K tail belongs to the k_gemm_f16_pp64 family (one tile per workgroup: rounds of n_cu tiles)
     for mode in ('1', '0', 'small'):
         monkeypatch.setenv('VG_GEMM_SPLITK', '0' if mode == '0' else '8')
         R = resid.clone()
@@ -152,3 +153,59 @@ def test_gemm_resid_splitk_tail(cuda, K, rows, monkeypatch):
     d = (outs['1'][r_main * 256:] - outs['0'][r_main * 256:]).abs().max().item()
     print(f'{rows} row tiles, K {K}: {tail} tail tiles split; max |split - unsplit| = {d:.2e} (values up to {scale:.1f})')
     assert 0 < d < 2e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+@pytest.mark.parametrize('shape', [(256, 256, 256), (512, 768, 320), (256, 2304, 768), (768, 768, 3072), (25600, 768, 256), (66560, 256, 256)])
+def test_gemm_w4_equals_pp64_bit_for_bit(cuda, epi, shape, monkeypatch):
+    """k_gemm_f16_w4 (round 6: persistent workgroups of four waves, the K loop one generated assembly block, token rows as the MFMA's A
+    operand, a row-permuted LDS image of W, epilogues straight from the accumulators, the next tile's first pieces requested in the last
+    K iterations) computes the same MFMA products in the same K order as k_gemm_f16_pp64 (VG_GEMM_W4=0) and applies the same epilogue
+    expressions: the outputs are the same bits.  Shapes: the shortest K loop it takes (four K-tiles), a K that is not a multiple of 256,
+    the ViT-B/16 projections, and launches of 300 / 260 tiles on 256 persistent workgroups (every workgroup's second tile starts from
+    prefetched pieces while the first tile's stores are in flight)."""
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    X = torch.randn(M, K, generator=g).half().to(cuda)
+    W = (torch.randn(N, K, generator=g) * 0.05).half().to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    resid = torch.randn(M, N, generator=g).to(cuda)
+    outs = []
+    for w4 in ('1', '0', '1'):
+        monkeypatch.setenv('VG_GEMM_W4', w4)
+        C = torch.zeros(M, N, dtype=torch.float32 if epi == 3 else torch.float16, device=cuda)
+        R = resid.clone()
+        check(lib.vg_gemm(1, epi, ptr(X), ptr(W), ptr(bias), ptr(C), ptr(R), M, N, K, stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(R if epi == 2 else C)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]), (outs[0].float() - outs[1].float()).abs().max().item()
+    assert torch.equal(outs[0], outs[2])
+    if M <= 768:
+        want = _ref(X.cpu(), W.cpu(), bias.cpu(), resid.cpu(), epi)
+        assert (outs[0].float().cpu() - want.float()).abs().max().item() < 3e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_gemm_w4_repeated_launches_are_deterministic(cuda):
+    """Race screen for the hand-placed waits of k_gemm_f16_w4 (a read issued before its DMA piece has landed returns the old LDS bytes
+    without any fault): 40 launches of a 780-tile GEMM, K = 768, every result equal to the first."""
+    from vilgod_amd._lib import lib, ptr, stream_ptr, check
+    M, N, K = 66560, 768, 768
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(M, K, generator=g).half().to(cuda)
+    W = (torch.randn(N, K, generator=g) * 0.05).half().to(cuda)
+    bias = torch.randn(N, generator=g).to(cuda)
+    R = torch.zeros(1, device=cuda)
+    first = None
+    for it in range(40):
+        C = torch.full((M, N), float('nan'), dtype=torch.float16, device=cuda)
+        check(lib.vg_gemm(1, 0, ptr(X), ptr(W), ptr(bias), ptr(C), ptr(R), M, N, K, stream_ptr()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = C
+            assert torch.isfinite(C.float()).all()
+        else:
+            assert torch.equal(first, C), it

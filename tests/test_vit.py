@@ -295,11 +295,14 @@ def test_hip_folded_layernorm_on_trained_like_statistics(cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('family', ['w4', 'pp64'])
 @pytest.mark.parametrize('width,heads', [(256, 4), (512, 8), (1024, 16)])
-def test_hip_folded_layernorm_other_widths(cuda, width, heads):
-    """The consumer GEMM merges K / 256 partial row statistics (1, 2 and 4 here; 3 for ViT-B/16): the folded fp16 tower agrees with
-    the tower that runs separate LayerNorm kernels and with the fp32 tower at every width the 256 x 256 kernel serves."""
+def test_hip_folded_layernorm_other_widths(cuda, width, heads, family, monkeypatch):
+    """The consumer GEMM merges K / 128 (k_gemm_f16_w4, the default) or K / 256 (k_gemm_f16_pp64, VG_GEMM_W4=0) partial row statistics --
+    2 .. 8 resp. 1 .. 4 here, 6 / 3 for ViT-B/16: the folded fp16 tower agrees with the tower that runs separate LayerNorm kernels and
+    with the fp32 tower at every width the 256 x 256 kernels serve, in either kernel family."""
     from vilgod_amd.clip_wrapper import VitEncoder
+    monkeypatch.setenv('VG_GEMM_W4', '1' if family == 'w4' else '0')
     rng = np.random.default_rng(width)
     wd = cw.synthetic_vit_weights(4, width=width, layers=2, heads=heads, patch=16, resolution=64, output_dim=128)
     crops = torch.from_numpy(rng.uniform(-1.8, 2.2, (40, 3, 64, 64)).astype(np.float32)).to(cuda)
@@ -345,6 +348,7 @@ def test_hip_tower_with_split_k_tails(cuda, n, monkeypatch):
     runs c_proj's share of those row tiles K-split when VG_GEMM_SPLITK=8 (opt-in: launch_gemm / splitk_plan).  The features stay within the fp16 tower's bound against the fp32 tower and
     within fp16 rounding of the unsplit run (VG_GEMM_SPLITK=0); crops whose rows lie in complete rounds only change through nothing at all
     in the first block and through attention-free row-wise work afterwards: rows never mix, so THEIR features are the same numbers."""
+    monkeypatch.setenv('VG_GEMM_W4', '0')          # split-K tails exist in the k_gemm_f16_pp64 family only (read when the handle is made)
     from vilgod_amd.clip_wrapper import VitEncoder
     wd = cw.synthetic_vit_weights(3, **cw.VIT_B16)
     x = torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(n)).to(cuda)
@@ -459,3 +463,20 @@ def test_hip_clipwrapper_loads_a_checkpoint_end_to_end(cuda, tmp_path, form):
     assert torch.equal(probs, want[0]) and torch.equal(top1, want[1])
     names, scores = clip.predict_clip_labels(x)
     assert names == [cfg['class_list'][int(i)] for i in top1.cpu()] and len(scores) == 6
+
+
+@pytest.mark.gpu
+def test_hip_tower_kernel_families_agree(cuda, monkeypatch):
+    """The fp16 ViT-B/16 tower on k_gemm_f16_w4 (default) and on k_gemm_f16_pp64 (VG_GEMM_W4=0): the projection GEMMs themselves are
+    bit-identical (tests/test_gemm.py); the folded LayerNorm's row statistics are merged from 128- resp. 256-column partials, so the
+    features agree to fp32 rounding of those sums -- far inside the fp16 tower's distance to the fp32 tower."""
+    from vilgod_amd.clip_wrapper import VitEncoder
+    wd = cw.synthetic_vit_weights(2, **cw.VIT_B16)
+    x = torch.randn(40, 3, 224, 224, generator=torch.Generator().manual_seed(40)).to(cuda)
+    f_w4 = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    monkeypatch.setenv('VG_GEMM_W4', '0')
+    f_pp = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    assert torch.isfinite(f_w4).all()
+    rel = ((f_w4 - f_pp).norm() / f_pp.norm()).item()
+    print(f'k_gemm_f16_w4 vs k_gemm_f16_pp64 tower: relative L2 {rel:.2e}')
+    assert rel < 5e-4           # (measured 1.7e-4: a last-bit difference of a row's rstd moves fp16 roundings downstream; the fp16 tower sits 3.4e-4 from the fp32 tower)

@@ -3,7 +3,8 @@
     python vilgod_amd/csrc/gen_gemm_w4.py            # rewrite the .inc
     python vilgod_amd/csrc/gen_gemm_w4.py --check    # exit 1 if the committed .inc differs from what this script emits
 
-What the loop is (round 6; the projection GEMMs of third_party/CLIP/clip/model.py:171-192):
+What the block is (round 6; the projection GEMMs of third_party/CLIP/clip/model.py:171-192).  ONE assembly block = the whole K loop of
+one 256 x 256 output tile of a PERSISTENT workgroup, including the first DMA pieces of the workgroup's NEXT tile:
   * workgroup = 4 waves, one per SIMD; 256 x 256 x 64 macro tile; wave (wm, wn) owns 128 tokens x 128 features = 8 x 8 tiles of
     v_mfma_f32_16x16x32_f16, i.e. 256 accumulator registers, which live in a0..a255 for the whole tile (the compiler never sees them:
     the epilogue fetches them with v_accvgpr_read).  A operand = 16 token rows (X fragment mi), B operand = 16 weight rows (W fragment
@@ -13,20 +14,28 @@ What the loop is (round 6; the projection GEMMs of third_party/CLIP/clip/model.p
     ni = 0..7 are eight consecutive features = one 16-byte store, sixteen lanes = 256 contiguous bytes of an output row; for fp32
     outputs feature 64 (ni >> 2) + 4 r + (ni & 3).  The epilogue therefore needs neither LDS nor barriers.
   * LDS: a ring of FIVE 32 KB slots (all 160 KB), a slot = 256 rows x 128 B of one operand for one K-tile, 16-byte chunk c of row r at
-    c ^ ((r >> 1) & 7).  X(t) sits in slot 2t mod 5, W(t) in 2t + 1 mod 5.  Filled by LDS-DMA (`buffer_load_dwordx4 ... lds`, a piece =
-    8 rows x 128 B, the swizzle applied to the per-lane SOURCE address); a wave fills rows [64 w, 64 w + 64) of every slot: 8 + 8
-    pieces per K-tile.
+    c ^ ((r >> 1) & 7).  Filled by LDS-DMA (`buffer_load_dwordx4 ... lds`, a piece = 8 rows x 128 B, the swizzle applied to the
+    per-lane SOURCE address); a wave fills rows [64 w, 64 w + 64) of every slot: 8 + 8 pieces per K-tile.  At iteration i the ring
+    registers a..e hold the slots of X(i), W(i), X(i+1), W(i+1), X(i+2).
   * ONE barrier per K-tile ("M").  Iteration i: the first k32 sub-step's MFMAs run on fragments read during iteration i - 1 while the
     second sub-step's fragments are read; `s_waitcnt vmcnt(8) lgkmcnt(0)` + s_barrier: every wave is done with the slots of X(i), W(i)
     and every wave's pieces of X(i+1), W(i+1) have landed.  Behind M: W(i+2) goes into X(i)'s slot, X(i+3) into W(i)'s, and the first
     sub-step's fragments of tile i + 1 are read.  So W has one iteration (>= 2 048 cycles of MFMAs) to land and X two.
+  * the last three iterations have nothing of this tile left to fetch: their DMA slots carry the NEXT output tile's X'(0), W'(0),
+    X'(1), W'(1), X'(2) (source bases nxlo/nxhi, nwlo/nwhi), so the block leaves the ring exactly as the first tile's prologue does
+    and the next block starts its MFMAs as soon as X'(0), W'(0) have landed.  The pieces are issued BEFORE the epilogue's stores:
+    vector memory operations retire in order, so the next block can wait for them with a count that leaves the stores in flight
+    (`vmcnt(24 + S)`, `vmcnt(8 + S)` at the first M; S = the epilogue's stores, a property of the kernel instantiation: ST below).
+    The first iteration's MFMAs take 0 as their C operand: no zeroing pass over the accumulators.
   * every LDS read, DMA piece, address update and wait sits at a fixed distance between the MFMAs (the table SCHED below): nothing is
     left to the compiler's scheduler.
 
 Registers: v128..v255 fragments (W half 0, X half 0, W half 1, X half 1: 32 each), v120..v123 read addresses, s60..s91 (piece offsets,
 slot ring, buffer descriptors, loop counter; s92..s101 cycle stamps of the trace variant).  Everything else comes in through named
 operands: per-lane DMA offsets dv0/dv1 (X, even / odd pieces) and dw0/dw1 (W), fragment read offsets xo0/xo1/wo0/wo1, the operand
-bases of this wave (xlo/xhi, wlo/whi), rowb = bytes per operand row, wpo = byte offset of W's odd pieces, lds0, wdst, np.
+bases of this wave for this tile (xlo/xhi, wlo/whi) and the next (nxlo/nxhi, nwlo/nwhi), rowb = bytes per operand row, wpo = byte
+offset of W's odd pieces, lds0, wdst, np (>= 4), first (1: nothing has been prefetched, run the prologue), ring (in/out: byte offset of
+slot a).
 """
 import os
 import sys
@@ -34,8 +43,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, 'gemm_w4_loop.inc')
 
-FW = (128, 192)          # W fragments (A operand), k32 half 0 / 1: v[FW[h] + 4 ni .. + 3]
-FX = (160, 224)          # X fragments (B operand)
+FW = (128, 192)          # W fragments (B operand), k32 half 0 / 1: v[FW[h] + 4 ni .. + 3]
+FX = (160, 224)          # X fragments (A operand)
 VA_W = (120, 121)        # LDS read address of the W fragments, half 0 / 1
 VA_X = (122, 123)
 S_OFF = {'x': 60, 'w': 84}     # s60..s66 / s84..s90: source offsets of pieces p = 1..7 (X: p x 8 rows; W: (p & 1) wpo + (p >> 1) rows)
@@ -45,14 +54,21 @@ S_TMP = 73
 S_CNT = 74
 S_WDST = 75              # this wave's byte offset inside a slot (64 rows x 128 B x wave)
 SRD = {'x': 76, 'w': 80}       # s[76:79], s[80:83]
+S_END = 91               # lds0 + 5 slots (ring wrap)
+
+# vmcnt allowances by output kind: how many of the epilogue's vector-memory operations (its stores) may still be in flight when the
+# next block waits for its first pieces.  'h': fp16 outputs, exactly 32 16-byte stores per lane; 'f': fp32 outputs, >= 64 (the count is
+# capped by the 6-bit counter).  tests/test_abi.py checks the store counts of every instantiation against these.
+ST = {'h': 32, 'f': 64}
 
 
-def mfma(k):
+def mfma(k, c0=False):
     h, kk = divmod(k, 64)
     mi, ni = divmod(kk, 8)         # the A operand (token rows) stays for eight MFMAs
     a = 4 * (ni * 8 + mi)
-    return 'v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], a[%d:%d]' % (
-        a, a + 3, FX[h] + 4 * mi, FX[h] + 4 * mi + 3, FW[h] + 4 * ni, FW[h] + 4 * ni + 3, a, a + 3)
+    c = '0' if (c0 and h == 0) else 'a[%d:%d]' % (a, a + 3)
+    return 'v_mfma_f32_16x16x32_f16 a[%d:%d], v[%d:%d], v[%d:%d], %s' % (
+        a, a + 3, FX[h] + 4 * mi, FX[h] + 4 * mi + 3, FW[h] + 4 * ni, FW[h] + 4 * ni + 3, c)
 
 
 def rd(op, h, i):
@@ -78,8 +94,13 @@ def piece(op, p):
     return 'buffer_load_dwordx4 %%[d%s%d], s[%d:%d], %s offen lds' % ('v' if op == 'x' else 'w', p & 1, SRD[op], SRD[op] + 3, so)
 
 
-def advance(op):
-    return ['s_add_u32 s%d, s%d, 128' % (SRD[op], SRD[op]), 's_addc_u32 s%d, s%d, 0' % (SRD[op] + 1, SRD[op] + 1)]
+def advance(op, n=1):
+    return ['s_add_u32 s%d, s%d, %d' % (SRD[op], SRD[op], 128 * n), 's_addc_u32 s%d, s%d, 0' % (SRD[op] + 1, SRD[op] + 1)]
+
+
+def srd_base(op, nxt=False):
+    lo, hi = ('n' if nxt else '') + op + 'lo', ('n' if nxt else '') + op + 'hi'
+    return ['s_mov_b32 s%d, %%[%s]' % (SRD[op], lo), 's_mov_b32 s%d, %%[%s]' % (SRD[op] + 1, hi)]
 
 
 def rotate():
@@ -90,7 +111,7 @@ def rotate():
 
 # Cycle stamps (trace variants only): s_memtime pairs around the waits and the barrier, differences accumulated in SGPRs.
 # s[92:93] stamp, s94 = sum of M-wait cycles, s95 = barrier, s96 = end-of-iteration wait, s97 previous stamp, s98 scratch,
-# s99 = cost of one stamp pair with nothing between (calibration), s100 loop entry stamp, s101 prologue entry stamp.
+# s99 = cost of one stamp pair with nothing between (calibration), s100 loop entry stamp, s101 block entry stamp.
 def stamp_first():
     return ['s_memtime s[92:93]']
 
@@ -110,13 +131,16 @@ SCHED = dict(
 )
 
 
-def body(issue_w, issue_x, vm_at_m, read_next, barrier=True, loop_label=None, sched=SCHED):
+def body(dma_w, dma_x, vm_at_m, read_next, c0=False, loop_label=None, sched=SCHED):
+    """One K-tile: 128 MFMAs with everything else between them.  dma_w / dma_x: None, 'cur' (this output tile's W(i+2) / X(i+3)),
+    'next0' (the next output tile's first piece set of that operand: the descriptor's base is switched first) or 'next'."""
     gaps = {k: [] for k in range(-1, 128)}
     a, b, c, d, e = S_SLOT
     s = sched
     if s.get('no_dma'):
-        issue_w = issue_x = False
-        vm_at_m = 0
+        dma_w = dma_x = None
+        vm_at_m = None
+    wait_m = 's_waitcnt lgkmcnt(0)' if vm_at_m is None else 's_waitcnt vmcnt(%d) lgkmcnt(0)' % vm_at_m
     # ---- in front of M: the second sub-step's fragments of tile i (slots a = X(i), b = W(i))
     gaps[0] += [addr('w', 1, b), addr('x', 1, a)]
     g = s['rd1_first']
@@ -128,20 +152,18 @@ def body(issue_w, issue_x, vm_at_m, read_next, barrier=True, loop_label=None, sc
                 gaps[g + o].append(reads[n]); n += 1
         g += 3
     assert g - 3 + max(s['rd1_pattern']) < s['wait_m']
-    if barrier and s.get('trace'):
+    if s.get('trace'):
         gaps[s['wait_m'] - 1] += stamp_first()       # executes one MFMA in front of the wait; the wait retires it with everything else
-        gaps[s['wait_m']] += ['s_waitcnt vmcnt(%d) lgkmcnt(0)' % vm_at_m] + stamp_take(94) + ['s_mov_b32 s97, s92']
+        gaps[s['wait_m']] += [wait_m] + stamp_take(94) + ['s_mov_b32 s97, s92']
         gaps[s['bar_m']] += ['s_barrier', 's_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_sub_u32 s98, s92, s97', 's_add_u32 s95, s95, s98']
-    elif barrier:
-        gaps[s['wait_m']].append('s_waitcnt vmcnt(%d) lgkmcnt(0)' % vm_at_m)
-        gaps[s['bar_m']].append('s_barrier')
     else:
-        gaps[s['wait_m']].append('s_waitcnt lgkmcnt(0)')
-    # ---- behind M: W(i+2) -> slot a, X(i+3) -> slot b
-    for on, op, slot, first in ((issue_w, 'w', a, s['dma_w_first']), (issue_x, 'x', b, s['dma_x_first'])):
-        if not on:
+        gaps[s['wait_m']].append(wait_m)
+        gaps[s['bar_m']].append('s_barrier')
+    # ---- behind M: W(i+2) -> slot a, X(i+3) -> slot b (or the next output tile's pieces)
+    for what, op, slot, first in ((dma_w, 'w', a, s['dma_w_first']), (dma_x, 'x', b, s['dma_x_first'])):
+        if not what:
             continue
-        gaps[first - 1] += [dst(slot), m0(0)]
+        gaps[first - 1] += (srd_base(op, nxt=True) if what == 'next0' else []) + [dst(slot), m0(0)]
         for p in range(8):
             gaps[first + s['dma_step'] * p].append(piece(op, p))
             if p < 7:
@@ -160,17 +182,17 @@ def body(issue_w, issue_x, vm_at_m, read_next, barrier=True, loop_label=None, sc
                     gaps[g + o].append(reads[n]); n += 1
             g += 3
         assert g < s['rotate_at']
-        gaps[s['rotate_at']] += rotate()
         if s.get('trace'):
             gaps[s['wait_end'] - 1] += stamp_first()
             gaps[s['wait_end']] += ['s_waitcnt lgkmcnt(0)'] + stamp_take(96)
         else:
             gaps[s['wait_end']].append('s_waitcnt lgkmcnt(0)')
+    gaps[s['rotate_at']] += rotate()
     if loop_label:
         gaps[s['loop_at']] += ['s_sub_u32 s%d, s%d, 1' % (S_CNT, S_CNT), 's_cmp_lg_u32 s%d, 0' % S_CNT]
     out = []
     for k in range(128):
-        out.append(mfma(k))
+        out.append(mfma(k, c0))
         for ins in gaps[k]:
             if s.get('no_reads') and ins.startswith('ds_read'):
                 continue
@@ -182,13 +204,10 @@ def body(issue_w, issue_x, vm_at_m, read_next, barrier=True, loop_label=None, sc
     return out
 
 
-def prologue():
-    a, b, c, d, e = S_SLOT
-    out = []
-    out += ['s_mov_b32 s%d, %%[xlo]' % SRD['x'], 's_mov_b32 s%d, %%[xhi]' % (SRD['x'] + 1), 's_mov_b32 s%d, 0x80000000' % (SRD['x'] + 2),
-            's_mov_b32 s%d, 0x00020000' % (SRD['x'] + 3)]
-    out += ['s_mov_b32 s%d, %%[wlo]' % SRD['w'], 's_mov_b32 s%d, %%[whi]' % (SRD['w'] + 1), 's_mov_b32 s%d, 0x80000000' % (SRD['w'] + 2),
-            's_mov_b32 s%d, 0x00020000' % (SRD['w'] + 3)]
+def setup():
+    """descriptor flags, piece offsets, the ring registers from `ring`, loop count"""
+    out = ['s_mov_b32 s%d, 0x80000000' % (SRD['x'] + 2), 's_mov_b32 s%d, 0x00020000' % (SRD['x'] + 3),
+           's_mov_b32 s%d, 0x80000000' % (SRD['w'] + 2), 's_mov_b32 s%d, 0x00020000' % (SRD['w'] + 3)]
     ox, ow = S_OFF['x'], S_OFF['w']
     out.append('s_lshl_b32 s%d, %%[rowb], 3' % ox)                       # X piece p: rows 8 p
     for p in range(2, 8):
@@ -197,38 +216,51 @@ def prologue():
     out.append('s_mov_b32 s%d, %%[rowb]' % (ow + 1))
     for p in range(3, 8):
         out.append('s_add_u32 s%d, s%d, %%[rowb]' % (ow + p - 1, ow + p - 3))
-    for i, sl in enumerate(S_SLOT):
-        out.append('s_add_u32 s%d, %%[lds0], %d' % (sl, 32768 * i))
+    out.append('s_add_u32 s%d, %%[lds0], %d' % (S_END, 5 * 32768))
+    out.append('s_add_u32 s%d, %%[lds0], %%[ring]' % S_SLOT[0])
+    for i in range(1, 5):                                                 # next slot = + 32 KB, wrapping at the end of the ring
+        sl, pr = S_SLOT[i], S_SLOT[i - 1]
+        out += ['s_add_u32 s%d, s%d, 32768' % (sl, pr), 's_sub_u32 s%d, s%d, %d' % (S_TMP, sl, 5 * 32768), 's_cmp_ge_u32 s%d, s%d' % (sl, S_END),
+                's_cselect_b32 s%d, s%d, s%d' % (sl, S_TMP, sl)]
     out.append('s_mov_b32 s%d, %%[wdst]' % S_WDST)
-    out.append('s_sub_u32 s%d, %%[np], 3' % S_CNT)
-    # X(0) -> a, W(0) -> b, X(1) -> c, W(1) -> d, X(2) -> e
+    out.append('s_sub_u32 s%d, %%[np], 4' % S_CNT)
+    return out
+
+
+def program(sched=SCHED, st='h'):
+    a, b, c, d, e = S_SLOT
+    S = ST[st]
+    n_entry, n_first = min(63, 24 + S), min(63, 8 + S)
+    out = []
+    if sched.get('trace'):
+        out += ['s_mov_b32 s94, 0', 's_mov_b32 s95, 0', 's_mov_b32 s96, 0', 's_mov_b32 s99, 0',
+                's_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_mov_b32 s101, s92'] + stamp_first() + ['s_waitcnt lgkmcnt(0)'] + stamp_take(99)
+    out += setup()
+    out += srd_base('x') + srd_base('w')
+    out += ['s_cmp_eq_u32 %[first], 0', 's_cbranch_scc1 .Lw4_pref_%=']
+    # ---- nothing prefetched (a workgroup's first tile): X(0) -> a, W(0) -> b, X(1) -> c, W(1) -> d, X(2) -> e
     for op, slot in (('x', a), ('w', b), ('x', c), ('w', d), ('x', e)):
         out += [dst(slot)]
         for p in range(8):
             out += [m0(p), 's_nop 0', piece(op, p)]
         out += advance(op)
-    out += ['v_accvgpr_write_b32 a%d, 0' % i for i in range(256)]
-    out += ['s_waitcnt vmcnt(24)', 's_barrier']
+    out += ['s_waitcnt vmcnt(8)', 's_branch .Lw4_go_%=']           # (X(1), W(1) too: the first M's allowance is the prefetched case's)
+    # ---- the previous block has issued them: the descriptors continue behind them
+    out += ['.Lw4_pref_%=:'] + advance('x', 3) + advance('w', 2) + ['s_waitcnt vmcnt(%d)' % n_entry]
+    out += ['.Lw4_go_%=:', 's_barrier']
     out += [addr('w', 0, b), addr('x', 0, a)]
     out += [rd('w', 0, i) for i in range(8)] + [rd('x', 0, i) for i in range(8)]
     out += ['s_waitcnt lgkmcnt(0)']
-    return out
-
-
-def program(sched=SCHED):
-    out = []
-    if sched.get('trace'):
-        out += ['s_mov_b32 s94, 0', 's_mov_b32 s95, 0', 's_mov_b32 s96, 0', 's_mov_b32 s99, 0',
-                's_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_mov_b32 s101, s92'] + stamp_first() + ['s_waitcnt lgkmcnt(0)'] + stamp_take(99)
-    out += prologue()
     if sched.get('trace'):
         out += ['s_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_mov_b32 s100, s92']
+    out += body('cur', 'cur', n_first, True, c0=True, sched=sched)                 # i = 0
     out += ['s_cmp_eq_u32 s%d, 0' % S_CNT, 's_cbranch_scc1 .Lw4_tail_%=', '.p2align 4', '.Lw4_loop_%=:']
-    out += body(True, True, 8, True, loop_label='.Lw4_loop_%=', sched=sched)
+    out += body('cur', 'cur', 8, True, loop_label='.Lw4_loop_%=', sched=sched)     # i = 1 .. np - 4
     out += ['.Lw4_tail_%=:']
-    out += body(True, False, 8, True, sched=sched)         # i = np - 3: W(np-1) is the last thing to fetch
-    out += body(False, False, 0, True, sched=sched)        # i = np - 2
-    out += body(False, False, 0, False, barrier=False, sched=sched)    # i = np - 1
+    out += body('cur', 'next0', 8, True, sched=sched)        # i = np - 3: W(np-1), X'(0)
+    out += body('next0', 'next', 8, True, sched=sched)       # i = np - 2: W'(0), X'(1)
+    out += body('next', 'next', None, False, sched=sched)    # i = np - 1: W'(1), X'(2); M = every wave is done with the last slots (no data awaited)
+    out += ['s_sub_u32 %%[ring], s%d, %%[lds0]' % a]
     out += ['s_nop 15', 's_nop 15']           # the last MFMAs have written their accumulators before anything reads them
     if sched.get('trace'):
         out += ['s_memtime s[92:93]', 's_waitcnt lgkmcnt(0)', 's_sub_u32 %[t_pro], s100, s101', 's_sub_u32 %[t_loop], s92, s100',
@@ -264,13 +296,14 @@ def render():
         sched = dict(SCHED); sched.update(var)
         if vi == 1:
             lines.append('#ifdef VG_DEV')
-        lines.append('#define VG_W4_ASM_%d \\' % vi)
-        for ins in program(sched):
-            lines.append('    "%s\\n" \\' % ins)
-        lines.append('    ""')
+        for st in ('h', 'f') if vi == 0 else ('h',):
+            lines.append('#define VG_W4_ASM_%d%s \\' % (vi, st.upper()))
+            for ins in program(sched, st):
+                lines.append('    "%s\\n" \\' % ins)
+            lines.append('    ""')
     lines.append('#define VG_W4_DEV_RUNS \\')
     for vi in range(1, len(VARIANTS)):
-        lines.append('    else if constexpr (VAR == %d) { VG_W4_RUN%s(%d); } \\' % (vi, '_TRACE' if VARIANTS[vi].get('trace') else '', vi))
+        lines.append('    else if constexpr (VAR == %d) { VG_W4_RUN%s(%dH); } \\' % (vi, '_TRACE' if VARIANTS[vi].get('trace') else '', vi))
     lines.append('')
     lines.append('#define VG_W4_DEV_CASES(EPI, LN) \\')
     for vi in range(1, len(VARIANTS)):
@@ -280,6 +313,8 @@ def render():
     lines.append('#endif  // VG_DEV')
     lines.append('#define VG_W4_NVAR %d' % len(VARIANTS))
     lines.append('#define VG_W4_TRACE_VAR %d' % [i for i, v in enumerate(VARIANTS) if v.get('trace')][0])
+    lines.append('#define VG_W4_STORES_H %d' % ST['h'])
+    lines.append('#define VG_W4_STORES_F %d' % ST['f'])
     cl = clobbers()
     lines.append('#define VG_W4_CLOBBERS \\')
     for i in range(0, len(cl), 16):
@@ -295,4 +330,4 @@ if __name__ == '__main__':
         sys.exit(0 if ok else 1)
     with open(OUT, 'w') as f:
         f.write(text)
-    print('wrote', OUT, len(program()), 'instructions')
+    print('wrote', OUT, len(program()), 'instructions per block')

@@ -1006,7 +1006,7 @@ struct vg_vit {
     bool att_tr = !(getenv("VG_ATT_TR") && atoi(getenv("VG_ATT_TR")) == 0);                    // attention: row-major V + transposing LDS reads
     bool att_stagger = !(getenv("VG_ATT_STAGGER") && atoi(getenv("VG_ATT_STAGGER")) == 0);     // attention: SIMD partners apart in phase (k_attention_f16 STAG)
     bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
-    int gemm_w4 = getenv("VG_GEMM_W4") ? atoi(getenv("VG_GEMM_W4")) : 0;                      // projection GEMMs by k_gemm_f16_w4 (4 waves, assembly K loop) instead of k_gemm_f16_pp64
+    int gemm_w4 = getenv("VG_GEMM_W4") ? atoi(getenv("VG_GEMM_W4")) : 1;                      // projection GEMMs by k_gemm_f16_w4 (round 6: persistent, 4 waves, assembly K loop); 0: k_gemm_f16_pp64 (a tower uses one family: their LayerNorm partials differ in granularity)
     int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
@@ -1475,61 +1475,128 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     if (VAR == VG_W4_TRACE_VAR) tr_entry = clock64();
     const int ntm = M / BM;
     const int wm = wave >> 1, wn = wave & 1;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    // PERSISTENT: one workgroup per CU walks its XCD's contiguous run of tiles (slot s of G / 8 takes tiles s, s + G / 8, ...: at any time
+    // the CUs of an XCD work on neighbouring tiles, the chunked order of the one-tile-per-workgroup kernels)
+    const int nt_all = ntm * (N / BN);
+    const int xq = nt_all >> 3, xr_ = nt_all & 7, xcd = blockIdx.x & 7;
+    const int xbase = (xcd < xr_) ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq;
+    const int xcnt = xq + (xcd < xr_ ? 1 : 0);
+    const int tstride = (int)(gridDim.x >> 3);
     const int per_chunk = ntm * cw;
-    const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-    const int tm = tc / cw, tn = chunk * cw + (tc - tm * cw);
-    const int np = K / 64;                          // host guarantees K % 64 == 0 and np >= 3
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int r15 = lane & 15, q4 = lane >> 4;
-    // folded LayerNorm, consumer side: lane l of wave (wm, .) merges the K / 128 partials of tile rows wm 128 + l and wm 128 + 64 + l
-    // (requested before the first pieces; both waves of a row half do it) and hands (mean, rstd) to the lanes that need them by ds_bpermute
+    auto tile_mn = [&](int t, int& m0_, int& n0_, int& tn_) {
+        const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
+        const int tm = tc / cw;
+        tn_ = chunk * cw + (tc - tm * cw);
+        m0_ = tm * BM; n0_ = tn_ * BN;
+    };
+    const int np = K / 64;                          // host guarantees K % 64 == 0 and np >= 4
+    const int r15k = lane & 15, q4k = lane >> 4;
     constexpr int NSTMAX = 8;                       // width <= 1024
     const int nst = K >> 7;
-    LnPartial pt[2][NSTMAX] = {};
-    if (LN == 1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const LnPartial* sp = ln_stats + (size_t)(m0 + wm * 128 + h * 64 + lane) * nst;
-#pragma unroll
-            for (int i = 0; i < NSTMAX; ++i) pt[h][i] = i < nst ? sp[i] : LnPartial{0.f, 0.f};
+    // DMA piece p of wave w fills LDS rows 64 w + 8 p + (lane >> 3) of a slot, 16-byte chunk slot lane & 7; the source chunk is
+    // (lane & 7) ^ ((LDS row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1).  X: LDS row = tile row.  W: LDS row h 128 + ni 16 + r
+    // (h = w >> 1, ni = 4 (w & 1) + (p >> 1), r = 8 (p & 1) + (lane >> 3)) holds the feature the output layout asks for (above).
+    const unsigned rowb = (unsigned)K * 2u;
+    const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
+    const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
+    const unsigned wlm = F16OUT ? 8u : 4u;                                   // feature step per (lane >> 3)
+    const unsigned dw0 = (unsigned)(lane >> 3) * wlm * rowb + (c0 << 4), dw1 = (unsigned)(lane >> 3) * wlm * rowb + ((c0 ^ 4u) << 4);
+    const unsigned wpo = __builtin_amdgcn_readfirstlane((F16OUT ? 64u : 32u) * rowb);     // odd pieces: r += 8
+    const int wrow0 = (wave >> 1) * 128 + (F16OUT ? (wave & 1) * 4 : (wave & 1) * 64);      // feature of (ni = 4 (w & 1), r = 0)
+    const unsigned swz = (unsigned)((r15k >> 1) & 7);
+    const unsigned xo0 = (unsigned)(wm * 128 + r15k) * 128u + (((unsigned)q4k ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15k) * 128u + (((unsigned)(4 + q4k) ^ swz) << 4);
+    const unsigned wo0 = (unsigned)(wn * 128 + r15k) * 128u + (((unsigned)q4k ^ swz) << 4), wo1 = (unsigned)(wn * 128 + r15k) * 128u + (((unsigned)(4 + q4k) ^ swz) << 4);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem);
+    const unsigned rowbs = __builtin_amdgcn_readfirstlane(rowb), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
+    unsigned ring = 0, first = 1;
+    int ti = (int)(blockIdx.x >> 3);
+    if (ti >= xcnt) return;
+    int m0, n0, tn;
+    tile_mn(xbase + ti, m0, n0, tn);
+    // Per-tile operands of the epilogue (bias, and for the folded LayerNorm's consumer c1 and the K / 128 partial statistics of the
+    // rows wm 128 + lane, wm 128 + 64 + lane).  Vector memory operations retire IN ORDER and the compiler cannot see the K loop's DMA
+    // pieces: a load it waits for behind the assembly block would wait for every prefetched piece, and one issued behind the epilogue's
+    // stores for the stores to drain.  So tile t + 1's operands are REQUESTED in front of tile t's K loop (older than everything tile t
+    // issues) and TAKEN behind tile t's stores, where the compiler's own count of younger operations already allows them to be in flight.
+    float4 raw_b[2] = {}, raw_c[2] = {};
+    LnPartial raw_pt[2][NSTMAX] = {};
+    float4 cur_b[2] = {}, cur_c[2] = {};
+    float ln_mean2[2] = {0.f, 0.f}, ln_rstd2[2] = {0.f, 0.f};
+    auto issue_raw = [&](int m0_, int n0_) {
+        if constexpr (F16OUT) {
+            const int ncol = n0_ + wn * 128 + r15k * 8;
+            raw_b[0] = *(const float4*)(bias + ncol); raw_b[1] = *(const float4*)(bias + ncol + 4);
+            if (LN == 1) { raw_c[0] = *(const float4*)(ln_c1 + ncol); raw_c[1] = *(const float4*)(ln_c1 + ncol + 4); }
+        } else if (EPI == EPI_BIAS_RESID) {
+            const int ncol = n0_ + wn * 128 + r15k * 4;
+            raw_b[0] = *(const float4*)(bias + ncol); raw_b[1] = *(const float4*)(bias + ncol + 64);
         }
-    }
+        if (LN == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const LnPartial* sp = ln_stats + (size_t)(m0_ + wm * 128 + h * 64 + lane) * nst;
+#pragma unroll
+                for (int i = 0; i < NSTMAX; ++i) raw_pt[h][i] = sp[i < nst ? i : nst - 1];     // unconditional loads (a branch around a load costs a vmcnt(0)); the extras are zeroed when taken
+            }
+        }
+    };
+    auto take_raw = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {             // (pinned here: the wait for the loads sits at this point of the program)
+            asm volatile("" : "+v"(raw_b[i].x), "+v"(raw_b[i].y), "+v"(raw_b[i].z), "+v"(raw_b[i].w));
+            if (LN == 1) asm volatile("" : "+v"(raw_c[i].x), "+v"(raw_c[i].y), "+v"(raw_c[i].z), "+v"(raw_c[i].w));
+            cur_b[i] = raw_b[i]; cur_c[i] = raw_c[i];
+        }
+        if (LN == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float ms = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSTMAX; ++i) {
+                    asm volatile("" : "+v"(raw_pt[h][i].mean), "+v"(raw_pt[h][i].m2));
+                    if (i >= nst) raw_pt[h][i] = LnPartial{0.f, 0.f};
+                    ms += raw_pt[h][i].mean; m2 += raw_pt[h][i].m2;
+                }
+                const float mean = ms / (float)nst;
+                float dev = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSTMAX; ++i) if (i < nst) { const float d = raw_pt[h][i].mean - mean; dev += d * d; }
+                ln_mean2[h] = mean;
+                ln_rstd2[h] = rsqrtf((m2 + 128.f * dev) / (float)K + 1e-5f);
+            }
+        }
+    };
+    issue_raw(m0, n0);
+    take_raw();
+    for (; ti < xcnt; ti += tstride) {
+    int m0n = m0, n0n = n0, tnn = tn;               // the next tile, whose first pieces this tile's last K iterations request (none left: this tile again -- the
+    if (ti + tstride < xcnt) tile_mn(xbase + ti + tstride, m0n, n0n, tnn);       // pieces land in slots nobody reads and are drained before the workgroup ends)
+    issue_raw(m0n, n0n);                            // the NEXT tile's bias / LayerNorm operands: older than this tile's stores (see issue_raw)
     {
-        // DMA piece p of wave w fills LDS rows 64 w + 8 p + (lane >> 3) of a slot, 16-byte chunk slot lane & 7; the source chunk is
-        // (lane & 7) ^ ((LDS row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1).  X: LDS row = tile row.  W: LDS row h 128 + ni 16 + r
-        // (h = w >> 1, ni = 4 (w & 1) + (p >> 1), r = 8 (p & 1) + (lane >> 3)) holds the feature the output layout asks for (above).
-        const unsigned rowb = (unsigned)K * 2u;
-        const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
-        const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
-        const unsigned wlm = F16OUT ? 8u : 4u;                                   // feature step per (lane >> 3)
-        const unsigned dw0 = (unsigned)(lane >> 3) * wlm * rowb + (c0 << 4), dw1 = (unsigned)(lane >> 3) * wlm * rowb + ((c0 ^ 4u) << 4);
-        const unsigned wpo = __builtin_amdgcn_readfirstlane((F16OUT ? 64u : 32u) * rowb);     // odd pieces: r += 8
-        const int wrow0 = (wave >> 1) * 128 + (F16OUT ? (wave & 1) * 4 : (wave & 1) * 64);      // feature of (ni = 4 (w & 1), r = 0)
-        const unsigned swz = (unsigned)((r15 >> 1) & 7);
-        const unsigned xo0 = (unsigned)(wm * 128 + r15) * 128u + (((unsigned)q4 ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15) * 128u + (((unsigned)(4 + q4) ^ swz) << 4);
-        const unsigned wo0 = (unsigned)(wn * 128 + r15) * 128u + (((unsigned)q4 ^ swz) << 4), wo1 = (unsigned)(wn * 128 + r15) * 128u + (((unsigned)(4 + q4) ^ swz) << 4);
-        const unsigned long long xp = (unsigned long long)(X + (size_t)(m0 + wave * 64) * K);
-        const unsigned long long wp = (unsigned long long)(Wt + (size_t)(n0 + wrow0) * K);
+        const unsigned long long xp = (unsigned long long)(X + (size_t)(m0 + wave * 64) * K), xpn = (unsigned long long)(X + (size_t)(m0n + wave * 64) * K);
+        const unsigned long long wp = (unsigned long long)(Wt + (size_t)(n0 + wrow0) * K), wpn = (unsigned long long)(Wt + (size_t)(n0n + wrow0) * K);
         const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));
         const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wp), whi = __builtin_amdgcn_readfirstlane((unsigned)(wp >> 32));
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem);
-        const unsigned rowbs = __builtin_amdgcn_readfirstlane(rowb), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
+        const unsigned nxlo = __builtin_amdgcn_readfirstlane((unsigned)xpn), nxhi = __builtin_amdgcn_readfirstlane((unsigned)(xpn >> 32));
+        const unsigned nwlo = __builtin_amdgcn_readfirstlane((unsigned)wpn), nwhi = __builtin_amdgcn_readfirstlane((unsigned)(wpn >> 32));
+        const unsigned firsts = __builtin_amdgcn_readfirstlane(first);
+        ring = __builtin_amdgcn_readfirstlane(ring);
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #define VG_W4_IN [dv0] "v"(dv0), [dv1] "v"(dv1), [dw0] "v"(dw0), [dw1] "v"(dw1), [xo0] "v"(xo0), [xo1] "v"(xo1), [wo0] "v"(wo0),            \
-                 [wo1] "v"(wo1), [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [rowb] "s"(rowbs), [wpo] "s"(wpo),         \
-                 [lds0] "s"(lds0), [wdst] "s"(wdst), [np] "s"(npu)
-#define VG_W4_RUN(V) asm volatile(VG_W4_ASM_OF(V) : : VG_W4_IN : VG_W4_CLOBBERS)
+                 [wo1] "v"(wo1), [xlo] "s"(xlo), [xhi] "s"(xhi), [wlo] "s"(wlo), [whi] "s"(whi), [nxlo] "s"(nxlo), [nxhi] "s"(nxhi),        \
+                 [nwlo] "s"(nwlo), [nwhi] "s"(nwhi), [rowb] "s"(rowbs), [wpo] "s"(wpo), [lds0] "s"(lds0), [wdst] "s"(wdst), [np] "s"(npu),  \
+                 [first] "s"(firsts)
+#define VG_W4_RUN(V) asm volatile(VG_W4_ASM_OF(V) : [ring] "+s"(ring) : VG_W4_IN : VG_W4_CLOBBERS)
 #define VG_W4_RUN_TRACE(V)                                                                                                            \
         tr_asm0 = clock64();                                                                                                          \
         asm volatile(VG_W4_ASM_OF(V)                                                                                                  \
-                     : [t_pro] "=s"(t_pro), [t_loop] "=s"(t_loop), [t_wait] "=s"(t_wait), [t_bar] "=s"(t_bar), [t_end] "=s"(t_end),   \
-                       [t_cal] "=s"(t_cal)                                                                                            \
+                     : [ring] "+s"(ring), [t_pro] "=&s"(t_pro), [t_loop] "=&s"(t_loop), [t_wait] "=&s"(t_wait), [t_bar] "=&s"(t_bar),  \
+                       [t_end] "=&s"(t_end), [t_cal] "=&s"(t_cal)                                                                      \
                      : VG_W4_IN : VG_W4_CLOBBERS);                                                                                    \
         tr_asm1 = clock64()
-        if constexpr (VAR == 0) { VG_W4_RUN(0); }
-#ifdef VG_DEV      // ablations and alternative schedules (gen_gemm_w4.py VARIANTS): development build, VG_GEMM_W4 = 1 + VAR
+        if constexpr (VAR == 0) { if constexpr (F16OUT) { VG_W4_RUN(0H); } else { VG_W4_RUN(0F); } }
+#ifdef VG_DEV      // ablations and alternative schedules (gen_gemm_w4.py VARIANTS): development build, VG_GEMM_W4 = 1 + VAR; fp16 outputs only
         VG_W4_DEV_RUNS
 #endif
 #undef VG_W4_RUN
@@ -1538,30 +1605,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
 #pragma clang diagnostic pop
     }
     // ---- epilogue: accumulators -> global memory ----
-    float ln_mean2[2] = {0.f, 0.f}, ln_rstd2[2] = {0.f, 0.f};
-    if (LN == 1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float ms = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < NSTMAX; ++i) { ms += pt[h][i].mean; m2 += pt[h][i].m2; }
-            const float mean = ms / (float)nst;
-            float dev = 0.f;
-#pragma unroll
-            for (int i = 0; i < NSTMAX; ++i) if (i < nst) { const float d = pt[h][i].mean - mean; dev += d * d; }
-            ln_mean2[h] = mean;
-            ln_rstd2[h] = rsqrtf((m2 + 128.f * dev) / (float)K + 1e-5f);
-        }
-    }
+    // (the lane id is re-derived behind an opaque asm per tile: otherwise the compiler hoists the epilogue's 32 row addresses out of the
+    // tile loop, across the K loop's assembly block, and spills)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int r15 = lane_e & 15, q4 = lane_e >> 4;
     if constexpr (F16OUT) {
         const int ncol = n0 + wn * 128 + r15 * 8;
-        const float4 b0 = *(const float4*)(bias + ncol), b1 = *(const float4*)(bias + ncol + 4);
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float cc[8] = {};
-        if (LN == 1) {
-            const float4 c0_ = *(const float4*)(ln_c1 + ncol), c1_ = *(const float4*)(ln_c1 + ncol + 4);
-            cc[0] = c0_.x; cc[1] = c0_.y; cc[2] = c0_.z; cc[3] = c0_.w; cc[4] = c1_.x; cc[5] = c1_.y; cc[6] = c1_.z; cc[7] = c1_.w;
-        }
+        const float bb[8] = {cur_b[0].x, cur_b[0].y, cur_b[0].z, cur_b[0].w, cur_b[1].x, cur_b[1].y, cur_b[1].z, cur_b[1].w};
+        const float cc[8] = {cur_c[0].x, cur_c[0].y, cur_c[0].z, cur_c[0].w, cur_c[1].x, cur_c[1].y, cur_c[1].z, cur_c[1].w};
         f16* crow = (f16*)Cout + (size_t)(m0 + wm * 128 + 4 * q4) * ldc + ncol;
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
@@ -1588,24 +1640,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     } else {
         // fp32: lane holds features 64 g + 4 r + j (ni = 4 g + j) of the wave's 128: two float4 per (mi, e)
         const int ncol = n0 + wn * 128 + r15 * 4;
-        float4 b4[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        if (EPI == EPI_BIAS_RESID) { b4[0] = *(const float4*)(bias + ncol); b4[1] = *(const float4*)(bias + ncol + 64); }
+        const float4 b4[2] = {cur_b[0], cur_b[1]};          // (zero unless EPI_BIAS_RESID)
         const size_t row0 = (size_t)(m0 + wm * 128 + 4 * q4);
         float* base = (EPI == EPI_BIAS_RESID ? resid : (float*)Cout) + row0 * ldc + ncol;
-        float4 xa[4][2], xb[4][2];                  // the residual rows of mi (xa) and mi + 1 (xb): eight loads ahead of the stores
-        auto load_rows = [&](float4 (&x4)[4][2], int mi) {
+        float4 xr[4][2];                            // residual rows: eight loads in flight; row (mi + 1, e) is requested right behind the store of (mi, e)
+        if (EPI == EPI_BIAS_RESID) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                x4[e][0] = *(const float4*)(base + (size_t)(mi * 16 + e) * ldc);
-                x4[e][1] = *(const float4*)(base + (size_t)(mi * 16 + e) * ldc + 64);
+                xr[e][0] = *(const float4*)(base + (size_t)e * ldc);
+                xr[e][1] = *(const float4*)(base + (size_t)e * ldc + 64);
             }
-        };
-        if (EPI == EPI_BIAS_RESID) load_rows(xa, 0);
+        }
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
-            float4 (&xc)[4][2] = (mi & 1) ? xb : xa;
-            float4 (&xn)[4][2] = (mi & 1) ? xa : xb;
-            if (EPI == EPI_BIAS_RESID && mi < 7) load_rows(xn, mi + 1);
             w4_for<4>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 float4 v[2];
@@ -1613,14 +1660,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                     constexpr int g = decltype(gc)::value;
                     v[g] = make_float4(w4_acc<(4 * g + 0) * 8 + mi, e>() + b4[g].x, w4_acc<(4 * g + 1) * 8 + mi, e>() + b4[g].y,
                                        w4_acc<(4 * g + 2) * 8 + mi, e>() + b4[g].z, w4_acc<(4 * g + 3) * 8 + mi, e>() + b4[g].w);
-                    if (EPI == EPI_BIAS_RESID) { v[g].x += xc[e][g].x; v[g].y += xc[e][g].y; v[g].z += xc[e][g].z; v[g].w += xc[e][g].w; }
+                    if (EPI == EPI_BIAS_RESID) { v[g].x += xr[e][g].x; v[g].y += xr[e][g].y; v[g].z += xr[e][g].z; v[g].w += xr[e][g].w; }
                     *(float4*)(base + (size_t)(mi * 16 + e) * ldc + 64 * g) = v[g];
                 });
+                if (EPI == EPI_BIAS_RESID && mi < 7) {
+                    xr[e][0] = *(const float4*)(base + (size_t)((mi + 1) * 16 + e) * ldc);
+                    xr[e][1] = *(const float4*)(base + (size_t)((mi + 1) * 16 + e) * ldc + 64);
+                }
                 if (EPI == EPI_BIAS_RESID && LN == 2) {
                     // fp16 copy for the next GEMM + this row's statistics over the wave's 128 columns
-                    f16* xr = ln_x16 + (row0 + mi * 16 + e) * ldc + ncol;
+                    f16* x16r = ln_x16 + (row0 + mi * 16 + e) * ldc + ncol;
                     const f16x4 h0 = {(f16)v[0].x, (f16)v[0].y, (f16)v[0].z, (f16)v[0].w}, h1 = {(f16)v[1].x, (f16)v[1].y, (f16)v[1].z, (f16)v[1].w};
-                    *(f16x4*)xr = h0; *(f16x4*)(xr + 64) = h1;
+                    *(f16x4*)x16r = h0; *(f16x4*)(x16r + 64) = h1;
                     const float mean = w4_row16_sum(((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w))) * (1.0f / 128.0f);
                     const float a0 = v[0].x - mean, a1 = v[0].y - mean, a2 = v[0].z - mean, a3 = v[0].w - mean;
                     const float a4 = v[1].x - mean, a5 = v[1].y - mean, a6 = v[1].z - mean, a7 = v[1].w - mean;
@@ -1631,13 +1682,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
         });
     }
 #ifdef VG_DEV
-    if (VAR == VG_W4_TRACE_VAR && lane == 0 && trace) {      // per wave: cycles of entry -> asm, asm prologue, K loop, its waits, the epilogue
-        long long* o = trace + ((size_t)blockIdx.x * 4 + wave) * 12;
+    if (VAR == VG_W4_TRACE_VAR && lane == 0 && trace) {      // per tile and wave: cycles of entry -> asm, block entry, K loop, its waits, the epilogue
+        long long* o = trace + ((size_t)(xbase + ti) * 4 + wave) * 12;
         const long long t2 = clock64();
         o[0] = tr_asm0 - tr_entry; o[1] = t_pro; o[2] = t_loop; o[3] = t_wait; o[4] = t_bar; o[5] = t_end; o[6] = t_cal;
-        o[7] = t2 - tr_asm1; o[8] = tr_asm1 - tr_asm0; o[9] = np; o[10] = wave; o[11] = wall_clock64();
+        o[7] = t2 - tr_asm1; o[8] = tr_asm1 - tr_asm0; o[9] = first; o[10] = wave; o[11] = wall_clock64();
+        tr_entry = clock64();
     }
 #endif
+    take_raw();
+    m0 = m0n; n0 = n0n; tn = tnn; first = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last block's pieces for a "next tile" have landed before the LDS is given back
 }
 
 // Column tiles (256 wide) per L2 chunk of the tile order for the 256 x 256 kernels.  Measured at M = 64512 (sweep with
@@ -1762,14 +1818,20 @@ template <int EPI, int LN = 0, int VAR = 0>
 static int launch_gemm_w4(const void* X, const void* Wt, const float* bias, void* C, float* resid, int M, int N, int K, int ldc,
                           hipStream_t st, const float* ln_c1 = nullptr, LnPartial* ln_stats = nullptr, f16* ln_x16 = nullptr,
                           long long* trace = nullptr) {
-    if (M % 256 || N % 256 || K % 64 || K / 64 < 3) return VG_ERR_ARG;
-    if (LN == 1 && (K % 256 || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
+    if (M % 256 || N % 256 || K % 64 || K / 64 < 4) return VG_ERR_ARG;
+    if (LN == 1 && (K % 128 || K > 1024 || !ln_c1 || !ln_stats)) return VG_ERR_ARG;
     if (LN == 2 && (ldc != N || !ln_stats || !ln_x16)) return VG_ERR_ARG;
     auto kern = k_gemm_f16_w4<EPI, LN, VAR>;
     const int lds = 5 * 32768;
     VG_MAX_DYNAMIC_LDS(kern, lds);
     const int ntn = N / 256;
-    hipLaunchKernelGGL(kern, dim3((M / 256) * ntn), dim3(256), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
+    static std::atomic<int> n_cu_{0};                // persistent grid: one workgroup per CU, a multiple of 8 (slot s of XCD x = block 8 s + x)
+    int n_cu = n_cu_.load();
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 8) n_cu = 256; n_cu_.store(n_cu); }
+    int grid = (M / 256) * ntn;
+    if (grid > n_cu) grid = n_cu;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
                        ldc, gemm_chunk_tiles_256(ntn), ln_c1, ln_stats, ln_x16, trace);
     VG_LAUNCH_CHECK();
     return VG_OK;
@@ -1852,7 +1914,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
 #endif
                 if constexpr (EPI == EPI_BIAS_RESID && LN != 1) {
                     // residual GEMMs with scratch at hand: the row tiles beyond the last complete round of tiles run K-split
-                    if (sk_scratch && M % 256 == 0) {
+                    if (sk_scratch && M % 256 == 0 && !(v->gemm_w4 && K / 64 >= 4)) {        // (k_gemm_f16_w4 has no tile rounds to fill: persistent workgroups)
                         const SplitPlan sp = splitk_plan(M / 256, N / 256, K / 64, sk_bytes, v->splitk_max, v->n_cu);
                         if (sp.parts) {
                             const int rc = launch_gemm_pp64<EPI, false, false, LN>(X, Wt, bias, C, resid, sp.r_main * 256, N, K, ldc, st, nullptr, ln_c1, ln_stats, ln_x16);
@@ -1862,7 +1924,7 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
                         }
                     }
                 }
-                if (v->gemm_w4 && K / 64 >= 3) {
+                if (v->gemm_w4 && K / 64 >= 4) {
 #ifdef VG_DEV
                     if constexpr (LN == 0 && EPI == EPI_BIAS) {
                         switch (v->gemm_w4) { VG_W4_DEV_CASES(EPI, LN) }
