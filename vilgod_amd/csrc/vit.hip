@@ -1490,24 +1490,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
         m0_ = tm * BM; n0_ = tn_ * BN;
     };
     const int np = K / 64;                          // host guarantees K % 64 == 0 and np >= 4
-    const int r15k = lane & 15, q4k = lane >> 4;
     constexpr int NSTMAX = 8;                       // width <= 1024
     const int nst = K >> 7;
-    // DMA piece p of wave w fills LDS rows 64 w + 8 p + (lane >> 3) of a slot, 16-byte chunk slot lane & 7; the source chunk is
-    // (lane & 7) ^ ((LDS row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1).  X: LDS row = tile row.  W: LDS row h 128 + ni 16 + r
-    // (h = w >> 1, ni = 4 (w & 1) + (p >> 1), r = 8 (p & 1) + (lane >> 3)) holds the feature the output layout asks for (above).
-    const unsigned rowb = (unsigned)K * 2u;
-    const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
-    const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
-    const unsigned wlm = F16OUT ? 8u : 4u;                                   // feature step per (lane >> 3)
-    const unsigned dw0 = (unsigned)(lane >> 3) * wlm * rowb + (c0 << 4), dw1 = (unsigned)(lane >> 3) * wlm * rowb + ((c0 ^ 4u) << 4);
-    const unsigned wpo = __builtin_amdgcn_readfirstlane((F16OUT ? 64u : 32u) * rowb);     // odd pieces: r += 8
-    const int wrow0 = (wave >> 1) * 128 + (F16OUT ? (wave & 1) * 4 : (wave & 1) * 64);      // feature of (ni = 4 (w & 1), r = 0)
-    const unsigned swz = (unsigned)((r15k >> 1) & 7);
-    const unsigned xo0 = (unsigned)(wm * 128 + r15k) * 128u + (((unsigned)q4k ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15k) * 128u + (((unsigned)(4 + q4k) ^ swz) << 4);
-    const unsigned wo0 = (unsigned)(wn * 128 + r15k) * 128u + (((unsigned)q4k ^ swz) << 4), wo1 = (unsigned)(wn * 128 + r15k) * 128u + (((unsigned)(4 + q4k) ^ swz) << 4);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem);
-    const unsigned rowbs = __builtin_amdgcn_readfirstlane(rowb), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
+    const unsigned rowbs = __builtin_amdgcn_readfirstlane((unsigned)K * 2u), wdst = (unsigned)wave * 8192u, npu = (unsigned)__builtin_amdgcn_readfirstlane(np);
     unsigned ring = 0, first = 1;
     int ti = (int)(blockIdx.x >> 3);
     if (ti >= xcnt) return;
@@ -1522,7 +1508,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     LnPartial raw_pt[2][NSTMAX] = {};
     float4 cur_b[2] = {}, cur_c[2] = {};
     float ln_mean2[2] = {0.f, 0.f}, ln_rstd2[2] = {0.f, 0.f};
-    auto issue_raw = [&](int m0_, int n0_) {
+    auto issue_raw = [&](int m0_, int n0_, int lane_) {
+        const int r15k = lane_ & 15;
         if constexpr (F16OUT) {
             const int ncol = n0_ + wn * 128 + r15k * 8;
             raw_b[0] = *(const float4*)(bias + ncol); raw_b[1] = *(const float4*)(bias + ncol + 4);
@@ -1534,7 +1521,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
         if (LN == 1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const LnPartial* sp = ln_stats + (size_t)(m0_ + wm * 128 + h * 64 + lane) * nst;
+                const LnPartial* sp = ln_stats + (size_t)(m0_ + wm * 128 + h * 64 + lane_) * nst;
 #pragma unroll
                 for (int i = 0; i < NSTMAX; ++i) raw_pt[h][i] = sp[i < nst ? i : nst - 1];     // unconditional loads (a branch around a load costs a vmcnt(0)); the extras are zeroed when taken
             }
@@ -1566,13 +1553,32 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
             }
         }
     };
-    issue_raw(m0, n0);
+    issue_raw(m0, n0, lane);
     take_raw();
     for (; ti < xcnt; ti += tstride) {
     int m0n = m0, n0n = n0, tnn = tn;               // the next tile, whose first pieces this tile's last K iterations request (none left: this tile again -- the
     if (ti + tstride < xcnt) tile_mn(xbase + ti + tstride, m0n, n0n, tnn);       // pieces land in slots nobody reads and are drained before the workgroup ends)
-    issue_raw(m0n, n0n);                            // the NEXT tile's bias / LayerNorm operands: older than this tile's stores (see issue_raw)
+    int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_t));
+    issue_raw(m0n, n0n, lane_t);                    // the NEXT tile's bias / LayerNorm operands: older than this tile's stores (see issue_raw)
     {
+    // per-lane operands of the K loop, re-derived per tile from the lane id (a dozen integer instructions): kept live across the tile
+    // loop they are what the register allocator spills first -- and it reloads spills behind a vmcnt(0), i.e. behind the previous tile's stores
+    // DMA piece p of wave w fills LDS rows 64 w + 8 p + (lane >> 3) of a slot, 16-byte chunk slot lane & 7; the source chunk is
+    // (lane & 7) ^ ((LDS row >> 1) & 7) = (lane & 7) ^ (lane >> 4) ^ 4 (p & 1).  X: LDS row = tile row.  W: LDS row h 128 + ni 16 + r
+    // (h = w >> 1, ni = 4 (w & 1) + (p >> 1), r = 8 (p & 1) + (lane >> 3)) holds the feature the output layout asks for (above).
+    const unsigned rowb = (unsigned)K * 2u;
+    const int lane = lane_t;
+    const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
+    const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
+    const unsigned wlm = F16OUT ? 8u : 4u;                                   // feature step per (lane >> 3)
+    const unsigned dw0 = (unsigned)(lane >> 3) * wlm * rowb + (c0 << 4), dw1 = (unsigned)(lane >> 3) * wlm * rowb + ((c0 ^ 4u) << 4);
+    const unsigned wpo = __builtin_amdgcn_readfirstlane((F16OUT ? 64u : 32u) * rowb);     // odd pieces: r += 8
+    const int wrow0 = (wave >> 1) * 128 + (F16OUT ? (wave & 1) * 4 : (wave & 1) * 64);      // feature of (ni = 4 (w & 1), r = 0)
+    const int r15t = lane & 15, q4t = lane >> 4;
+    const unsigned swz = (unsigned)((r15t >> 1) & 7);
+    const unsigned xo0 = (unsigned)(wm * 128 + r15t) * 128u + (((unsigned)q4t ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15t) * 128u + (((unsigned)(4 + q4t) ^ swz) << 4);
+    const unsigned wo0 = (unsigned)(wn * 128 + r15t) * 128u + (((unsigned)q4t ^ swz) << 4), wo1 = (unsigned)(wn * 128 + r15t) * 128u + (((unsigned)(4 + q4t) ^ swz) << 4);
         const unsigned long long xp = (unsigned long long)(X + (size_t)(m0 + wave * 64) * K), xpn = (unsigned long long)(X + (size_t)(m0n + wave * 64) * K);
         const unsigned long long wp = (unsigned long long)(Wt + (size_t)(n0 + wrow0) * K), wpn = (unsigned long long)(Wt + (size_t)(n0n + wrow0) * K);
         const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xp), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xp >> 32));
@@ -1605,16 +1611,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
 #pragma clang diagnostic pop
     }
     // ---- epilogue: accumulators -> global memory ----
-    // (the lane id is re-derived behind an opaque asm per tile: otherwise the compiler hoists the epilogue's 32 row addresses out of the
-    // tile loop, across the K loop's assembly block, and spills)
-    int lane_e = lane;
+    // Addresses are a wave-uniform row pointer (SGPR pair) plus ONE per-lane byte offset: 32 row pointers per lane would not leave room
+    // for the residual rows in flight.  The lane id is re-derived per tile (mbcnt) behind an opaque asm: nothing of the epilogue's
+    // address arithmetic is hoisted out of the tile loop, across the K loop's assembly block.
+    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane_e));
     const int r15 = lane_e & 15, q4 = lane_e >> 4;
+    const int urow = m0 + wm * 128;                         // wave-uniform first row of the quadrant
     if constexpr (F16OUT) {
-        const int ncol = n0 + wn * 128 + r15 * 8;
         const float bb[8] = {cur_b[0].x, cur_b[0].y, cur_b[0].z, cur_b[0].w, cur_b[1].x, cur_b[1].y, cur_b[1].z, cur_b[1].w};
         const float cc[8] = {cur_c[0].x, cur_c[0].y, cur_c[0].z, cur_c[0].w, cur_c[1].x, cur_c[1].y, cur_c[1].z, cur_c[1].w};
-        f16* crow = (f16*)Cout + (size_t)(m0 + wm * 128 + 4 * q4) * ldc + ncol;
+        const unsigned loff = ((unsigned)(4 * q4) * (unsigned)ldc + (unsigned)(r15 * 8)) * 2u;
+        const char* cbase = (const char*)((f16*)Cout + (size_t)urow * ldc + n0 + wn * 128);
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
             w4_for<4>([&](auto ec) {
@@ -1634,49 +1642,51 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                     if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
                     h8[ni] = (f16)x;
                 });
-                *(f16x8*)(crow + (size_t)(mi * 16 + e) * ldc) = h8;
+                *(f16x8*)(const_cast<char*>(cbase) + (size_t)(mi * 16 + e) * ldc * 2 + loff) = h8;
             });
         });
     } else {
         // fp32: lane holds features 64 g + 4 r + j (ni = 4 g + j) of the wave's 128: two float4 per (mi, e)
-        const int ncol = n0 + wn * 128 + r15 * 4;
         const float4 b4[2] = {cur_b[0], cur_b[1]};          // (zero unless EPI_BIAS_RESID)
-        const size_t row0 = (size_t)(m0 + wm * 128 + 4 * q4);
-        float* base = (EPI == EPI_BIAS_RESID ? resid : (float*)Cout) + row0 * ldc + ncol;
-        float4 xr[4][2];                            // residual rows: eight loads in flight; row (mi + 1, e) is requested right behind the store of (mi, e)
-        if (EPI == EPI_BIAS_RESID) {
+        const unsigned loff = ((unsigned)(4 * q4) * (unsigned)ldc + (unsigned)(r15 * 4)) * 4u, loffh = loff >> 1;
+        char* fbase = (char*)((EPI == EPI_BIAS_RESID ? resid : (float*)Cout) + (size_t)urow * ldc + n0 + wn * 128);
+        // residual rows: the 128 fragment registers of the K loop are free now -- the residual of FOUR mi blocks (32 float4) is requested
+        // at once, twice; a row's store follows its own loads only
+        float4 xr[4][4][2];
+        auto load_group = [&](int mg) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                xr[e][0] = *(const float4*)(base + (size_t)e * ldc);
-                xr[e][1] = *(const float4*)(base + (size_t)e * ldc + 64);
-            }
-        }
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const char* rp = fbase + (size_t)((mg * 4 + mm) * 16 + e) * ldc * 4 + loff;
+                    xr[mm][e][0] = *(const float4*)rp;
+                    xr[mm][e][1] = *(const float4*)(rp + 256);
+                }
+        };
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
+            if (EPI == EPI_BIAS_RESID && (mi & 3) == 0) load_group(mi >> 2);
             w4_for<4>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 float4 v[2];
+                char* rp = fbase + (size_t)(mi * 16 + e) * ldc * 4 + loff;
                 w4_for<2>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
                     v[g] = make_float4(w4_acc<(4 * g + 0) * 8 + mi, e>() + b4[g].x, w4_acc<(4 * g + 1) * 8 + mi, e>() + b4[g].y,
                                        w4_acc<(4 * g + 2) * 8 + mi, e>() + b4[g].z, w4_acc<(4 * g + 3) * 8 + mi, e>() + b4[g].w);
-                    if (EPI == EPI_BIAS_RESID) { v[g].x += xr[e][g].x; v[g].y += xr[e][g].y; v[g].z += xr[e][g].z; v[g].w += xr[e][g].w; }
-                    *(float4*)(base + (size_t)(mi * 16 + e) * ldc + 64 * g) = v[g];
+                    if (EPI == EPI_BIAS_RESID) { const float4 x = xr[mi & 3][e][g]; v[g].x += x.x; v[g].y += x.y; v[g].z += x.z; v[g].w += x.w; }
+                    *(float4*)(rp + 256 * g) = v[g];
                 });
-                if (EPI == EPI_BIAS_RESID && mi < 7) {
-                    xr[e][0] = *(const float4*)(base + (size_t)((mi + 1) * 16 + e) * ldc);
-                    xr[e][1] = *(const float4*)(base + (size_t)((mi + 1) * 16 + e) * ldc + 64);
-                }
                 if (EPI == EPI_BIAS_RESID && LN == 2) {
                     // fp16 copy for the next GEMM + this row's statistics over the wave's 128 columns
-                    f16* x16r = ln_x16 + (row0 + mi * 16 + e) * ldc + ncol;
+                    char* hp = (char*)(ln_x16 + (size_t)(urow + mi * 16 + e) * ldc + n0 + wn * 128) + loffh;
                     const f16x4 h0 = {(f16)v[0].x, (f16)v[0].y, (f16)v[0].z, (f16)v[0].w}, h1 = {(f16)v[1].x, (f16)v[1].y, (f16)v[1].z, (f16)v[1].w};
-                    *(f16x4*)x16r = h0; *(f16x4*)(x16r + 64) = h1;
+                    *(f16x4*)hp = h0; *(f16x4*)(hp + 128) = h1;
                     const float mean = w4_row16_sum(((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w))) * (1.0f / 128.0f);
                     const float a0 = v[0].x - mean, a1 = v[0].y - mean, a2 = v[0].z - mean, a3 = v[0].w - mean;
                     const float a4 = v[1].x - mean, a5 = v[1].y - mean, a6 = v[1].z - mean, a7 = v[1].w - mean;
                     const float m2 = w4_row16_sum(((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7)));
-                    if (r15 == 0) ln_stats[(row0 + mi * 16 + e) * (size_t)(N >> 7) + 2 * tn + wn] = LnPartial{mean, m2};
+                    if (r15 == 0) ln_stats[(size_t)(urow + mi * 16 + 4 * q4 + e) * (size_t)(N >> 7) + 2 * tn + wn] = LnPartial{mean, m2};
                 }
             });
         });
