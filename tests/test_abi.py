@@ -47,3 +47,34 @@ def test_vit_kernels_do_not_spill():
     since; the guard covered k_gemm_f16_pp64 only and the TR attention instantiation spilled a 64-bit row index unnoticed)."""
     from vilgod_amd import build
     assert build.check_scratch('vit.hip', '') == []
+
+
+def test_w4_loop_is_what_its_generator_writes():
+    """csrc/gemm_w4_loop.inc (the K loop of k_gemm_f16_w4: ~1 260 scheduled instructions per block) is generated; the committed file
+    is what csrc/gen_gemm_w4.py emits."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'vilgod_amd', 'csrc', 'gen_gemm_w4.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_w4_epilogues_match_the_wait_counts_of_the_assembly_block():
+    """The assembly block of k_gemm_f16_w4 waits for the NEXT tile's first DMA pieces with `vmcnt(24 + S)` / `vmcnt(8 + S)`, S = the
+    stores the compiler-generated epilogue issues behind them (in-order retirement; gen_gemm_w4.py ST).  A smaller S in the binary than
+    the generator assumed would let a fragment read run ahead of its piece.  Checked per instantiation, with: no scratch, and no
+    compiler-inserted `vmcnt(0)` inside the tile loop (one that waits for a spill reload or a branched load drains the previous tile's
+    stores: the first-tile set-up in front of the loop and the final drain behind it are the only ones)."""
+    from vilgod_amd import build
+    src = open(os.path.join(ROOT, 'vilgod_amd', 'csrc', 'gemm_w4_loop.inc')).read()
+    st_h = int(re.search(r'#define VG_W4_STORES_H (\d+)', src).group(1))
+    st_f = int(re.search(r'#define VG_W4_STORES_F (\d+)', src).group(1))
+    res = build.check_w4_epilogues()
+    assert set(res) == {(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 2), (3, 0)}, sorted(res)
+    for (epi, ln), r in res.items():
+        assert r['scratch'] == 0, (epi, ln, r)
+        if epi in (0, 1):
+            assert r['stores'] == st_h, (epi, ln, r)        # exact: the allowance is 24 + S <= 63
+        else:
+            assert r['stores'] >= st_f, (epi, ln, r)        # the allowance is capped at the counter's 63
+        zeros = [i for i, w in enumerate(r['compiler_vmcnt']) if w == 0]
+        assert len(zeros) <= 2 and (not zeros or zeros[-1] == len(r['compiler_vmcnt']) - 1), (epi, ln, r['compiler_vmcnt'])

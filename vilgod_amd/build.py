@@ -94,25 +94,54 @@ def build(force=False, verbose=True, dev=False):
     return LIB
 
 
+_ASM_CACHE = {}
+
+
+def _device_asm(source):
+    """device-side assembly text of csrc/<source> with the product flags (one compile per process: the checks below share it)"""
+    import tempfile
+    if source not in _ASM_CACHE:
+        hipcc = _hipcc()
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, source + '.s')
+            cmd = [hipcc] + [c for c in COMMON if c != '-fPIC'] + SOURCES[source] + ['-S', '--cuda-device-only', os.path.join(CSRC, source), '-o', out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f'hipcc -S failed for {source}:\n{r.stderr}')
+            _ASM_CACHE[source] = open(out).read()
+    return _ASM_CACHE[source]
+
+
 def check_scratch(source='vit.hip', name_part='k_gemm_f16_pp64'):
     """Kernels of `source` whose mangled name contains `name_part` and that use scratch memory (register spills) -> [(kernel, bytes)].
     The projection GEMM runs with 128 accumulator registers per wave and a 256-register budget: an instantiation that spills keeps
     its spill slots busy inside the tile loop, and one that did (round 3) returned wrong values."""
     import re
-    import tempfile
-    hipcc = _hipcc()
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, source + '.s')
-        cmd = [hipcc] + [c for c in COMMON if c != '-fPIC'] + SOURCES[source] + ['-S', '--cuda-device-only', os.path.join(CSRC, source), '-o', out]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f'hipcc -S failed for {source}:\n{r.stderr}')
-        text = open(out).read()
+    text = _device_asm(source)
     found = []
     for m in re.finditer(r'\.set (\S+)\.private_seg_size, (\d+)', text):
         if name_part in m.group(1) and int(m.group(2)) > 0:
             found.append((m.group(1), int(m.group(2))))
     return found
+
+
+def check_w4_epilogues():
+    """k_gemm_f16_w4 (csrc/vit.hip) leaves the next tile's DMA pieces in flight when its K loop's assembly block ends and lets the next
+    block wait for them with counts that allow for the epilogue's stores (csrc/gen_gemm_w4.py ST: vector memory operations retire in
+    order).  Those counts are only right if the compiler emits the stores the generator assumes.  Per product instantiation (VAR = 0)
+    -> {kernel: (stores behind the assembly block, scratch bytes, `s_waitcnt vmcnt(0)` inside the tile loop)}."""
+    import re
+    text = _device_asm('vit.hip')
+    res = {}
+    for m in re.finditer(r'^(_Z13k_gemm_f16_w4ILi(\d)ELi(\d)ELi0E\S*):\s', text, flags=re.M):
+        name, epi, ln = m.group(1), int(m.group(2)), int(m.group(3))
+        body = text[m.end():text.index('s_endpgm', m.end())]
+        tail = body[body.rindex('s_nop 15'):]                      # behind the K loop's assembly block (the loop's top is laid out in front of it)
+        scratch = int(re.search(r'\.set ' + re.escape(name) + r'\.private_seg_size, (\d+)', text).group(1))
+        # compiler waits inside the tile loop: everything between the first-tile set-up and the final drain
+        waits = re.findall(r'^\ts_waitcnt vmcnt\((\d+)\)', body, flags=re.M)       # (the assembly block's own waits are not tab-indented)
+        res[(epi, ln)] = {'stores': len(re.findall(r'\bglobal_store_', tail)), 'scratch': scratch, 'compiler_vmcnt': [int(w) for w in waits]}
+    return res
 
 
 def check_isa(sources=None, verbose=False):

@@ -1666,12 +1666,10 @@ static int cl_sit_min(int n) {
 #endif
     return std::max(2, n / 8);
 }
+// (sit_min, xcd_order: read ONCE per MST by the caller and handed to every launch of every round -- a development switch that a tool flips
+// between a round's search and pick launches would let pick accept candidates of a component that did not search)
 template <int DIM>
-static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
-    int xcd_order = 1;
-#ifdef VG_DEV
-    if (getenv("VG_CLUSTER_XCD_ORDER")) xcd_order = atoi(getenv("VG_CLUSTER_XCD_ORDER"));      // A/B aid (development build), read per call
-#endif
+static void cl_launch_search(vg_cluster* h, int n, hipStream_t st, int sit_min, int xcd_order) {
 #ifdef VG_DEV
     // VG_CLUSTER_SEARCH_NT (A/B aid, development build): threads per workgroup of the walk, 256 or 512 (see k_cl_b_search)
     const char* nt_env = getenv("VG_CLUSTER_SEARCH_NT");          // (read per launch: the A/B tool switches it inside one process)
@@ -1693,18 +1691,18 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st) {
         hipLaunchKernelGGL((k_cl_b_search<DIM, 256, true>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
-                           mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr, h->d_giant, cl_sit_min(n), 0);
+                           mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr, h->d_giant, sit_min, 0);
         return;
     }
 #endif
     if (nt == 512)
         hipLaunchKernelGGL((k_cl_b_search<DIM, 512>), dim3(vg_div_up(n, 512)), dim3(512), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, cl_sit_min(n), xcd_order);
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, sit_min, xcd_order);
     else
         hipLaunchKernelGGL((k_cl_b_search<DIM, 256>), dim3(vg_div_up(n, 256)), dim3(256), 0, st, h->d_spts, h->d_st, n, h->d_grid,
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
-                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, cl_sit_min(n), xcd_order);
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, sit_min, xcd_order);
 }
 
 extern "C" {
@@ -1798,13 +1796,18 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
 #ifdef VG_DEV
     if (getenv("VG_CLUSTER_FIRST_BATCH")) first_batch = std::max(1, std::min(12, atoi(getenv("VG_CLUSTER_FIRST_BATCH"))));
 #endif
+    const int sit_min = cl_sit_min(n);             // development switches: one reading per MST
+    int xcd_order = 1;
+#ifdef VG_DEV
+    if (getenv("VG_CLUSTER_XCD_ORDER")) xcd_order = atoi(getenv("VG_CLUSTER_XCD_ORDER"));
+#endif
     auto one_round = [&](int r) {
         hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
         if (r > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);
-        if (dim == 3) cl_launch_search<3>(h, n, st);
-        else if (dim == 4) cl_launch_search<4>(h, n, st);
-        else cl_launch_search<5>(h, n, st);
+        if (dim == 3) cl_launch_search<3>(h, n, st, sit_min, xcd_order);
+        else if (dim == 4) cl_launch_search<4>(h, n, st, sit_min, xcd_order);
+        else cl_launch_search<5>(h, n, st, sit_min, xcd_order);
 #ifdef VG_DEV
         if (r == 1 && getenv("VG_CLUSTER_SEEDSIM")) {
             (void)hipMemsetAsync(h->d_counter + 5, 0, 4, st);
@@ -1812,9 +1815,9 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
             hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
             hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
             hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);   // (round_init rewrote the pure values)
-            if (dim == 3) cl_launch_search<3>(h, n, st);          // walks only the points that were not seedable
-            else if (dim == 4) cl_launch_search<4>(h, n, st);
-            else cl_launch_search<5>(h, n, st);
+            if (dim == 3) cl_launch_search<3>(h, n, st, sit_min, xcd_order);          // walks only the points that were not seedable
+            else if (dim == 4) cl_launch_search<4>(h, n, st, sit_min, xcd_order);
+            else cl_launch_search<5>(h, n, st, sit_min, xcd_order);
             int left = 0;
             (void)hipMemcpyAsync(&left, h->d_counter + 5, 4, hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
@@ -1825,7 +1828,7 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         hipLaunchKernelGGL(k_cl_b_select, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_best_e, flags);
         hipLaunchKernelGGL(k_cl_b_pick, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_pt_w,
-                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b, flags, h->d_giant, cl_sit_min(n));
+                           h->d_pt_d, h->d_pt_key, h->d_pt_b, h->d_sel_a, h->d_sel_b, flags, h->d_giant, sit_min);
         hipLaunchKernelGGL(k_cl_b_emit, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_sel_a, h->d_sel_b, h->d_best_w,
                            h->d_perm, h->d_parent2, h->d_counter, h->d_mst_a, h->d_mst_b, h->d_mst_w, flags);
         hipLaunchKernelGGL(k_cl_b_compress, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_parent2, flags, h->d_aux, h->d_csize, h->d_giant);

@@ -231,6 +231,8 @@ __global__ __launch_bounds__(RT) void k_render(RenderArgs a) {
     __shared__ int s_cluster;
     {
         const int C = a.n_clusters, want = (int)blockIdx.x / V;
+        if (C > 1024) { if (tid == 0) s_cluster = want; }          // thousands of clusters (valid_only off, dense scenes): label order, not C^2 compares per workgroup
+        else
         for (int t = tid; t < C; t += RT) {
             const int sz = a.seg_off[t + 1] - a.seg_off[t];
             int rank = 0;

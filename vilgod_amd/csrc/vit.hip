@@ -1840,6 +1840,9 @@ static int launch_gemm_w4(const void* X, const void* Wt, const float* bias, void
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu < 8) n_cu = 256; n_cu_.store(n_cu); }
     int grid = (M / 256) * ntn;
     if (grid > n_cu) grid = n_cu;
+#ifdef VG_DEV
+    { static const int cap = getenv("VG_GEMM_W4_GRID") ? atoi(getenv("VG_GEMM_W4_GRID")) : 0; if (cap >= 8 && grid > cap) grid = cap; }   // experiment: two encodes on disjoint CU halves
+#endif
     grid = (grid + 7) / 8 * 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
                        ldc, gemm_chunk_tiles_256(ntn), ln_c1, ln_stats, ln_x16, trace);

@@ -23,6 +23,9 @@ def pack_clusters(labels, probs, threshold):
     was 2 ms of a frame's 12.6 ms front-stage latency (round 5)."""
     import ctypes
     from ._lib import lib, check
+    labels = np.asarray(labels)
+    if labels.size and (int(labels.max()) > np.iinfo(np.int32).max or int(labels.min()) < np.iinfo(np.int32).min):
+        return pack_clusters_numpy(labels, probs, threshold)        # (labels beyond int32 would wrap in the cast below; ADVICE r5)
     labels = np.ascontiguousarray(labels, dtype=np.int32)
     n = len(labels)
     pr = None if probs is None else np.ascontiguousarray(probs, dtype=np.float64)

@@ -118,7 +118,7 @@ def wait_state_writes(path=None):
     if fut is not None:
         try:
             fut.result()
-        except BaseException as e:      # noqa: BLE001  (name the file: the error surfaces in whichever thread waits next)
+        except Exception as e:          # noqa: BLE001  (name the file: the error surfaces in whichever thread waits next; KeyboardInterrupt / SystemExit pass through)
             raise RuntimeError(f'background write of the sequence state {written} failed: {e}') from e
 
 
@@ -136,14 +136,18 @@ def shutdown_state_writer():
 
 def _submit_state_write(path, compacts):
     from concurrent.futures import ThreadPoolExecutor
-    wait_state_writes()
-    with _STATE_LOCK:
-        if _STATE_WRITER['pool'] is None:
-            import atexit
-            _STATE_WRITER['pool'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vilgod-state-writer')
-            atexit.register(shutdown_state_writer)
-        _STATE_WRITER['path'] = str(path)
-        _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_via_helper, path, compacts)
+    while True:
+        wait_state_writes()                 # takes the pending future out under the lock and waits for it outside
+        with _STATE_LOCK:
+            if _STATE_WRITER['pending'] is not None:
+                continue                    # another thread submitted meanwhile: wait for that one too, so no future is ever dropped unawaited
+            if _STATE_WRITER['pool'] is None:
+                import atexit
+                _STATE_WRITER['pool'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='vilgod-state-writer')
+                atexit.register(shutdown_state_writer)
+            _STATE_WRITER['path'] = str(path)
+            _STATE_WRITER['pending'] = _STATE_WRITER['pool'].submit(_write_state_via_helper, path, compacts)
+            return
 
 
 class ZeroShotDetector:
