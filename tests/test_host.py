@@ -299,7 +299,8 @@ def test_pack_clusters_host_equals_numpy_form():
             assert g.dtype == w.dtype and np.array_equal(g, w)
 
 
-def test_profile_summary_splits_the_projection_gemm_per_kind(tmp_path):
+@pytest.mark.parametrize('family', ['pp64', 'w4'])
+def test_profile_summary_splits_the_projection_gemm_per_kind(tmp_path, family):
     """tools/summarize_profiles.py (VERDICT r4 task 2: FETCH / WRITE / SQ counters per GEMM KIND): a fabricated rocprofv3 run -- two frames of two
     blocks each, the instantiations' mangled names as the product library emits them, out_proj and c_proj sharing one instantiation and
     alternating in dispatch order, plus the small class-token launches of the last block -- must come out with each kind's own time, bytes
@@ -309,16 +310,23 @@ def test_profile_summary_splits_the_projection_gemm_per_kind(tmp_path):
     src, dst = tmp_path / 'prof', tmp_path / 'out'
     for d in ('trace', 'fetch', 'write', 'sq'):
         (src / d).mkdir(parents=True)
-    name = lambda epi, ln: f'_Z15k_gemm_f16_pp64ILi{epi}ELb0ELb0ELi{ln}ELb0EEvPKDF16_S1_PKfPvPfiiiiiPxS3_P9LnPartialPDF16_i'
+    # (round 6: k_gemm_f16_w4 launches a persistent grid of one workgroup per CU -- the rows of a launch come from the encode's
+    # k_embed_lnpre dispatch in front of it)
+    if family == 'pp64':
+        name = lambda epi, ln: f'_Z15k_gemm_f16_pp64ILi{epi}ELb0ELb0ELi{ln}ELb0EEvPKDF16_S1_PKfPvPfiiiiiPxS3_P9LnPartialPDF16_i'
+    else:
+        name = lambda epi, ln: f'_Z13k_gemm_f16_w4ILi{epi}ELi{ln}ELi0EEvPKDF16_S1_PKfPvPfiiiiiS3_P9LnPartialPDF16_Px'
+    dom = 'k_gemm_f16_pp64' if family == 'pp64' else 'k_gemm_f16_w4'
     rows_m = 65536                                            # 256 row tiles
     kinds = {'in_proj': (name(0, 1), 9, 270_000, 100.0, 300.0, 0.45), 'out_proj': (name(2, 2), 3, 160_000, 330.0, 300.0, 0.22),
              'c_fc': (name(1, 1), 12, 400_000, 110.0, 400.0, 0.42), 'c_proj': (name(2, 2), 3, 350_000, 740.0, 301.0, 0.46)}
     disp = []
     for frame in range(2):
+        disp.append(('lnpre', '_Z13k_embed_lnpreIDF16_EvPKfS1_S1_S1_S1_PT_iiiiS1_S1_PDF16_', rows_m // 4 * 256))
         for block in range(2):
             for k in ('in_proj', 'out_proj', 'c_fc', 'c_proj'):
-                disp.append((k, kinds[k][0], (rows_m // 256) * kinds[k][1] * 512))
-        disp += [('small', name(2, 2), 2 * 3 * 512), ('small', name(1, 1), 2 * 12 * 512)]      # class-token rows of the last block
+                disp.append((k, kinds[k][0], (rows_m // 256) * kinds[k][1] * 512 if family == 'pp64' else 256 * 256))
+        disp += [('small', name(2, 2), 2 * 3 * 512 if family == 'pp64' else 8 * 256), ('small', name(1, 1), 2 * 12 * 512 if family == 'pp64' else 24 * 256)]      # class-token rows of the last block
     trace, fetch, write, sq = [], [], [], []
     t = 1_000_000
     for did, (k, nm, grid) in enumerate(disp, start=1):
@@ -352,7 +360,7 @@ def test_profile_summary_splits_the_projection_gemm_per_kind(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'summarize_profiles.py'), 'tst'], capture_output=True, text=True,
                        env=dict(os.environ, VG_PROFILE_SRC=str(src), VG_PROFILE_OUT=str(dst)))
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.load(open(dst / 'tst_pmc_summary.json'))['k_gemm_f16_pp64_by_kind']
+    out = json.load(open(dst / 'tst_pmc_summary.json'))[dom + '_by_kind']
     assert set(out) == set(kinds)
     for k, (_, ntn, dur, f_mb, w_mb, util) in kinds.items():
         o = out[k]

@@ -16,7 +16,11 @@ applied afterwards, c1 summed over the ROUNDED weights), runs it on crops the re
     only one on, for each           (the step's error alone)
 
 as max |p - p_fp32| over all crops x 24 prompts, and the relative L2 error of the features.  Measurement aid (torch matmuls on the GPU);
-nothing here is product code.      python tools/fp16_ablation.py [n_frames=3] [max_crops_per_frame=400]"""
+nothing here is product code.      python tools/fp16_ablation.py [n_frames=3] [max_crops_per_frame=400] [layers]
+
+With the third argument `layers` (VERDICT r5 task 3b) the table is per LAYER instead of per step: all six roundings on in every block
+EXCEPT block l (and: only in block l), and with the last k = 1..4 blocks unrounded -- which blocks' roundings carry the error, i.e. what
+a higher-precision treatment of a few late blocks could buy."""
 import os
 import sys
 
@@ -32,9 +36,11 @@ def r16(t, on):
     return t.half().float() if on else t
 
 
-def tower(wd, x, heads, on):
-    """x: [n,3,224,224] fp32 normalised crops.  on: set of STEPS whose rounding is applied.  fp32 math otherwise."""
-    W_ = 'W' in on
+def tower(wd, x, heads, on, blocks=None):
+    """x: [n,3,224,224] fp32 normalised crops.  on: set of STEPS whose rounding is applied.  fp32 math otherwise.
+    blocks: the residual blocks in which `on` applies (None = all, and the patch embedding; a set = those blocks only, embedding unrounded)."""
+    on_all = set(on)
+    W_ = 'W' in on and blocks is None
     width = wd['conv1.weight'].shape[0]
     patch = wd['conv1.weight'].shape[-1]
     layers = len([k for k in wd if k.endswith('attn.in_proj_weight')])
@@ -58,6 +64,8 @@ def tower(wd, x, heads, on):
 
     for l in range(layers):
         p = f'transformer.resblocks.{l}.'
+        on = on_all if (blocks is None or l in blocks) else set()
+        W_ = 'W' in on
         if l == 0:      # block 0: ln_1 is computed by the embedding kernel and stored as fp16 (an 'x16'-kind rounding), plain weights
             h = r16(F.layer_norm(x, (width,), wd[p + 'ln_1.weight'], wd[p + 'ln_1.bias'], 1e-5), 'x16' in on)
             qkv = h @ r16(wd[p + 'attn.in_proj_weight'], W_).t() + wd[p + 'attn.in_proj_bias']
@@ -88,6 +96,7 @@ def probs_of(f, text):
 def main():
     n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     cap = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    per_layer = len(sys.argv) > 3 and sys.argv[3] == 'layers'
     from vilgod_amd import synthetic, clip_weights as cw
     from vilgod_amd.pipeline import PseudoLabelPipeline
     from vilgod_amd.clip_wrapper import VitEncoder, clip_scores
@@ -125,8 +134,8 @@ def main():
         n = crops.shape[0]
         n_crops += n
         with torch.no_grad():
-            def run(on):
-                return torch.cat([tower(wdd, c, 12, on) for c in torch.split(crops, 64)])
+            def run(on, blocks=None):
+                return torch.cat([tower(wdd, c, 12, on, blocks) for c in torch.split(crops, 64)])
             f32 = run(set())
             p32 = probs_of(f32, text)
             f_real = enc16.encode_patches(patches, n).float()
@@ -134,17 +143,34 @@ def main():
             f_all = run(set(STEPS))
             note('emulation, all six roundings', f_all, probs_of(f_all, text), f32, p32)
             note('  (real tower vs emulation)', f_real, probs_of(f_real, text), f_all, probs_of(f_all, text))
-            for s in STEPS:
-                f = run(set(STEPS) - {s})
-                note(f'all but {s}', f, probs_of(f, text), f32, p32)
-            for s in STEPS:
-                f = run({s})
-                note(f'only {s}', f, probs_of(f, text), f32, p32)
+            if per_layer:
+                allb = set(range(12))
+                for l in range(12):
+                    f = run(set(STEPS), allb - {l})
+                    note(f'all blocks but {l} (embedding unrounded)', f, probs_of(f, text), f32, p32)
+                for l in range(12):
+                    f = run(set(STEPS), {l})
+                    note(f'only block {l}', f, probs_of(f, text), f32, p32)
+                for k in (1, 2, 3, 4, 6):
+                    f = run(set(STEPS), set(range(12 - k)))
+                    note(f'last {k} blocks unrounded', f, probs_of(f, text), f32, p32)
+                for k in (1, 2, 3, 4):
+                    f = run(set(STEPS), set(range(k, 12)))
+                    note(f'first {k} blocks unrounded', f, probs_of(f, text), f32, p32)
+                f = run(set(STEPS), allb)
+                note('all blocks, embedding unrounded', f, probs_of(f, text), f32, p32)
+            else:
+                for s in STEPS:
+                    f = run(set(STEPS) - {s})
+                    note(f'all but {s}', f, probs_of(f, text), f32, p32)
+                for s in STEPS:
+                    f = run({s})
+                    note(f'only {s}', f, probs_of(f, text), f32, p32)
         print(f'frame {fi}: {n} crops', flush=True)
     print(f'\n{n_crops} crops of {n_frames} synthetic 150k-point frames, 24 prompts; reference = the same tower with no rounding (fp32)')
-    print(f'{"variant":36s} {"max |dp|":>10s} {"features rel L2":>16s}')
+    print(f'{"variant":44s} {"max |dp|":>10s} {"features rel L2":>16s}')
     for name, (mp, num, den) in rows.items():
-        print(f'{name:36s} {mp:10.2e} {np.sqrt(num / den):16.2e}')
+        print(f'{name:44s} {mp:10.2e} {np.sqrt(num / den):16.2e}')
 
 
 if __name__ == '__main__':

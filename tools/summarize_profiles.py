@@ -45,14 +45,18 @@ for k in sorted(set(fetch) | set(write)):
     st = stats.get(k)
     out['kernels'][k[:80]] = {'launches': f[0], 'fetch_kb_per_launch_raw': f[1] / max(f[0], 1), 'write_kb_per_launch': w[1] / max(w[0], 1),
                               'avg_ns': float(st['AverageNs']) if st else None}
-out['k_gemm_f16_pp64'] = group(lambda k: 'k_gemm_f16_pp64' in k)                       # the dominant kernel (bench.py roofline)
-out['k_gemm_f16'] = group(lambda k: 'k_gemm_f16' in k and 'k_gemm_f16_pp' not in k)    # fallback kernel (unused by ViT-B/16)
+# the dominant kernel (bench.py roofline): k_gemm_f16_w4 (round 6, the default) or k_gemm_f16_pp64 (VG_GEMM_W4=0) -- whichever the run used
+DOM = 'k_gemm_f16_w4' if any('k_gemm_f16_w4' in k for k in list(stats) + list(fetch)) else 'k_gemm_f16_pp64'
+is_dom = lambda k: DOM in k
+out['dominant_kernel'] = DOM
+out[DOM] = group(is_dom)
+out['k_gemm_f16'] = group(lambda k: 'k_gemm_f16' in k and 'k_gemm_f16_pp' not in k and 'k_gemm_f16_w4' not in k)    # fallback kernel (unused by ViT-B/16)
 sq_path = os.path.join(src, 'sq', 'bench_counter_collection.csv')
 if os.path.exists(sq_path):
     # SQ / GRBM pass: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of every SIMD's matrix pipe (16 per v_mfma_f32_16x16x32_f16),
     # GRBM_GUI_ACTIVE the active cycles of the 8 XCDs; MFMA utilisation = busy / (GUI_ACTIVE / 8 * 1024 SIMDs)
     names = ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE')
-    for label, match in (('k_gemm_f16_pp64', lambda k: 'k_gemm_f16_pp64' in k), ('k_attention_f16', lambda k: 'k_attention_f16' in k)):
+    for label, match in ((DOM, is_dom), ('k_attention_f16', lambda k: 'k_attention_f16' in k)):
         tot = {n: per_kernel(sq_path, n) for n in names}
         agg = {n: sum(v[1] for k, v in tot[n].items() if match(k)) for n in names}
         launches = sum(v[0] for k, v in tot['GRBM_GUI_ACTIVE'].items() if match(k))
@@ -71,11 +75,17 @@ def dispatch_rows(path, counters=None):
     rows = {}
     if not os.path.exists(path):
         return rows
-    for r in csv.DictReader(open(path)):
+    # k_gemm_f16_w4 launches a persistent grid (one workgroup per CU): its rows come from the encode's k_embed_lnpre launch in front of it
+    # (one wave per padded token row: grid = rows / 4 workgroups of 256 threads), in dispatch order
+    all_rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Dispatch_Id']))
+    m_rows = 0
+    for r in all_rows:
         name = r.get('Kernel_Name', '')
-        if 'k_gemm_f16_pp64' not in name:
+        if 'k_embed_lnpre' in name:
+            m_rows = int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0) // 64
+        if DOM not in name:
             continue
-        d = rows.setdefault(int(r['Dispatch_Id']), {'name': name, 'grid': int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0)})
+        d = rows.setdefault(int(r['Dispatch_Id']), {'name': name, 'grid': int(r.get('Grid_Size') or r.get('Grid_Size_X') or 0), 'm_rows': m_rows})
         if 'Counter_Name' in r:
             d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
         if r.get('Start_Timestamp') and r.get('End_Timestamp'):
@@ -83,7 +93,8 @@ def dispatch_rows(path, counters=None):
     return rows
 def template_args(name):
     import re
-    m = re.search(r'k_gemm_f16_pp64ILi(\d)ELb\dELb\dELi(\d)ELb(\d)E', name) or re.search(r'k_gemm_f16_pp64<(\d), \w+, \w+, (\d), (\w+)>', name)
+    m = (re.search(r'k_gemm_f16_pp64ILi(\d)ELb\dELb\dELi(\d)ELb(\d)E', name) or re.search(r'k_gemm_f16_pp64<(\d), \w+, \w+, (\d), (\w+)>', name) or
+         re.search(r'k_gemm_f16_w4ILi(\d)ELi(\d)ELi\d+E', name) or re.search(r'k_gemm_f16_w4<(\d), (\d), \d+>', name))
     return (int(m.group(1)), int(m.group(2))) if m else (None, None)
 def kinds_of(rows):
     """dispatch id -> kind for the full-size launches (grid = the frame's largest for that instantiation)."""
@@ -109,8 +120,8 @@ def algorithmic_bytes(kind, M):
     ldc = 2368 if kind == 'in_proj' else N
     rd = M * K * 2 + N * K * 2
     if kind in ('in_proj', 'c_fc'):
-        return rd + M * 8 * (K // 256), M * N * 2                      # + the row statistics; fp16 output
-    return rd + M * N * 4, M * N * 4 + M * N * 2 + M * 8                # fp32 residual read; residual + fp16 copy + statistics written
+        return rd + M * 8 * (K // (128 if DOM == 'k_gemm_f16_w4' else 256)), M * N * 2                      # + the row statistics; fp16 output
+    return rd + M * N * 4, M * N * 4 + M * N * 2 + M * 8 * (2 if DOM == 'k_gemm_f16_w4' else 1)                # fp32 residual read; residual + fp16 copy + statistics written
 trace_rows = dispatch_rows(os.path.join(src, 'trace', 'bench_kernel_trace.csv'))
 fetch_rows = dispatch_rows(os.path.join(src, 'fetch', 'bench_counter_collection.csv'))
 write_rows = dispatch_rows(os.path.join(src, 'write', 'bench_counter_collection.csv'))
@@ -131,7 +142,7 @@ for kind, g in kinds.items():
     t, f, w, q = g.get('trace', {'n': 0}), g.get('fetch', {'n': 0}), g.get('write', {'n': 0}), g.get('sq', {'n': 0})
     if not t['n']:
         continue
-    M = t['grid'] / t['n'] / 512 / (N // 256) * 256                    # average rows per launch (Grid_Size = work-items)
+    M = (t['m_rows'] / t['n']) if DOM == 'k_gemm_f16_w4' else t['grid'] / t['n'] / 512 / (N // 256) * 256      # average rows per launch (pp64: Grid_Size = work-items of one 512-thread workgroup per tile)
     us = t['dur_ns'] / t['n'] / 1e3
     alg_r, alg_w = algorithmic_bytes(kind, M)
     d = {'launches': t['n'], 'avg_rows': round(M), 'avg_launch_us': round(us, 1), 'tflops': round(2 * M * N * K / (us * 1e-6) / 1e12, 1),
@@ -150,7 +161,7 @@ for kind, g in kinds.items():
         d['wave_cycles_issue_stalled'] = round(q['SQ_WAIT_INST_ANY'] / q['SQ_WAVE_CYCLES'], 3)
         d['sustained_ghz'] = round(q['GRBM_GUI_ACTIVE'] / 8 / q['n'] / (q['dur_ns'] / q['n']), 3) if q.get('dur_ns') else None
     gemm_kinds[kind] = d
-out['k_gemm_f16_pp64_by_kind'] = gemm_kinds
+out[DOM + '_by_kind'] = gemm_kinds
 # ---- stage kernels next to the GEMM (north_star: "rocprof HBM GB/s (clustering, renderer)"): bench.py's `roofline_stages` block reads this ----
 def bench_line(logname):
     try:
@@ -198,7 +209,7 @@ stages = {
 }
 json.dump(stages, open(os.path.join(dst, 'stage_roofline.json'), 'w'), indent=1)
 json.dump(out, open(os.path.join(dst, f'{tag}_pmc_summary.json'), 'w'), indent=1)
-json.dump(dict(out['k_gemm_f16_pp64'], kernel='k_gemm_f16_pp64', tag=tag, by_kind=out.get('k_gemm_f16_pp64_by_kind', {}),
-               mfma_utilisation=out.get('k_gemm_f16_pp64_sq', {}).get('mfma_utilisation')),
+json.dump(dict(out[DOM], kernel=DOM, tag=tag, by_kind=out.get(DOM + '_by_kind', {}),
+               mfma_utilisation=out.get(DOM + '_sq', {}).get('mfma_utilisation')),
           open(os.path.join(dst, 'gemm_traffic.json'), 'w'), indent=1)
-print(json.dumps({'k_gemm_f16_pp64': out['k_gemm_f16_pp64'], 'k_gemm_f16': out['k_gemm_f16']}, indent=1))
+print(json.dumps({DOM: out[DOM], 'k_gemm_f16': out['k_gemm_f16']}, indent=1))
