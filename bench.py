@@ -185,7 +185,7 @@ def main():
     ap.add_argument('--views', type=int, default=4)
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
     ap.add_argument('--box-mode', default='reference', choices=['reference', 'fast'])
-    ap.add_argument('--ground-handoff', default='replicate', choices=['replicate', 'chain', 'replay'],
+    ap.add_argument('--ground-handoff', default='replicate', choices=['replicate', 'relay', 'chain', 'replay'],
                     help='N > 1: how a rank obtains the Patchwork++ state its frames need (inside the timed region).  replicate (default): '
                          'frames dealt round-robin, every rank runs the ground pass over the whole sequence itself, nothing is exchanged; '
                          'chain / replay: contiguous blocks, state handed down the rank chain / ground passes of the earlier blocks replayed')
@@ -280,7 +280,24 @@ def main():
         t0 = time.perf_counter()
         p.new_sequence()
         out = []
-        if world > 1 and args.ground_handoff == 'replicate':
+        if world > 1 and args.ground_handoff == 'relay':
+            # frames dealt round-robin as in `replicate`, but every rank runs ONLY its own ground passes: the Patchwork++ state is relayed
+            # frame by frame (rank g % N takes it from rank (g - 1) % N before frame g, hands it on behind it; vilgod_amd/dist.py)
+            seq = [frames[off + g // world] for g in range(world * K)]
+            seq_poses = [poses[W + g] for g in range(world * K)]
+            mine = [g for g in range(world * K) if g % world == rank]
+            rl = (lambda g: vdist.relay_recv_state(p.ground_model, g, dev), lambda g: vdist.relay_send_state(p.ground_model, g, world * K, dev))
+            if inflight == 1:
+                for g in mine:
+                    rl[0](g)
+                    d_pts = p.upload(seq[g])
+                    mask_g = p.ground(d_pts)
+                    rl[1](g)                      # the state goes on before this frame's heavy stages start
+                    fs, res = p.process_frame(d_pts, seq_poses[g], poses[0], fnr=g, timing=args.stage_times, mask=mask_g)
+                    out.append((fs, res, p.last_probs))
+            else:
+                out = p.process_frames(seq, seq_poses, poses[0], n_workers=inflight, first_fnr=0, own=mine, relay=rl)
+        elif world > 1 and args.ground_handoff == 'replicate':
             # frames dealt round-robin: frame g of the N * K frame sequence belongs to rank g % N.  Every rank queues the upload + ground
             # pass of ALL frames, in order, on its high-priority ground stream (0.36 ms per scan: N * K passes against K * ~15 ms of own
             # work) and processes its own frames in full; rank r's first frame waits for r ground passes, no state is exchanged.
@@ -343,12 +360,19 @@ def main():
             return
         from vilgod_amd._lib import lib as _l
         cdev = 'cpu' if dist.get_backend() == 'gloo' else dev
-        if args.ground_handoff == 'chain':               # (the other modes exchange no state: no point-to-point communicator is built)
+        if args.ground_handoff == 'chain':               # (replicate / replay exchange no state: no point-to-point communicator is built)
             buf = torch.zeros(int(_l.vg_ground_state_bytes()), dtype=torch.uint8, device=cdev)
             if rank > 0:
                 dist.recv(buf, src=rank - 1)
             if rank < world - 1:
                 dist.send(buf, dst=rank + 1)
+        if args.ground_handoff == 'relay':               # the ring rank -> rank + 1 (-> 0): the same order of operations as the timed region's first round
+            buf = torch.zeros(int(_l.vg_ground_state_bytes()), dtype=torch.uint8, device=cdev)
+            if rank > 0:
+                dist.recv(buf, src=rank - 1)
+            dist.send(buf, dst=(rank + 1) % world)
+            if rank == 0:
+                dist.recv(buf, src=world - 1)
         one = torch.ones(1, dtype=torch.int64, device=cdev)
         dist.all_gather([torch.zeros_like(one) for _ in range(world)], one)
         if dist.get_backend() != 'gloo':
@@ -508,6 +532,7 @@ def main():
                              f'{args.objects} objects (BASELINE config 3 shape' + (' as written' if args.views == 6 else f', but {args.views} views as in the reference\'s waymo.yaml; the 6-view '
                              'form is the views6 block') + f'), ONE sequence of {frames_total} frames sharded '
                              f'{world}-way ' + (('round-robin, ground pass replicated on every rank (no state exchange)' if args.ground_handoff == 'replicate'
+                                                else 'round-robin, ground state relayed frame by frame (every rank runs its own ground passes only)' if args.ground_handoff == 'relay'
                                                 else f'in contiguous blocks, ground state by {args.ground_handoff}') if world > 1 else '(one rank)') +
                              ', one all-gather of the score matrices'),
                 'points_per_frame': args.points, 'views': args.views, 'frames_per_gpu': K,

@@ -274,7 +274,7 @@ def test_cli_two_processes_per_gpu(cuda, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('handoff', ['replicate', 'chain'])
+@pytest.mark.parametrize('handoff', ['replicate', 'relay', 'chain'])
 def test_bench_two_ranks_on_one_gpu(cuda, handoff):
     """bench.py's N > 1 path (barriers, padded all-gather of the score matrices, max-over-ranks timing, one JSON line from
     rank 0) with two processes sharing the single GPU of the test box over gloo; the driver's multi-GPU runs use RCCL.

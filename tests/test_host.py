@@ -124,6 +124,54 @@ def test_two_rank_gather_gloo(tmp_path):
         assert f'rank {r} ok' in o
 
 
+RELAY_WORKER = """
+import os, sys
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from vilgod_amd import dist as vdist
+from vilgod_amd._lib import lib
+vdist.init_from_env('gloo')
+rank, ws = vdist.world()
+nbytes = int(lib.vg_ground_state_bytes())
+
+class FakeGround:                      # the state is the list of frames whose "ground pass" has run, in order
+    def __init__(self): self.seen = []
+    def export_state(self):
+        b = bytearray(nbytes); b[0] = len(self.seen)
+        for i, g in enumerate(self.seen): b[1 + i] = g
+        return bytes(b)
+    def set_state(self, blob): self.seen = list(blob[1:1 + blob[0]])
+
+gm = FakeGround()
+n_total = 7
+for g in range(n_total):
+    if g %% ws != rank:
+        continue
+    vdist.relay_recv_state(gm, g)
+    assert gm.seen == list(range(g)), (rank, g, gm.seen)       # every pass before frame g, in order, whoever ran it
+    gm.seen.append(g)                                            # this rank's ground pass of frame g
+    vdist.relay_send_state(gm, g, n_total)
+dist.barrier()
+print(f'rank {rank} ok', flush=True)
+"""
+
+
+def test_two_rank_ground_state_relay_gloo(tmp_path):
+    """bench.py --ground-handoff relay (round 6): frames dealt round-robin, the Patchwork++ state relayed frame by frame -- rank g % N
+    takes it from the owner of frame g - 1 before its ground pass of frame g and hands it on behind it.  Two gloo ranks, seven frames,
+    a stand-in ground model whose state is the list of passes run so far: every pass sees exactly the passes before it, in order."""
+    script = tmp_path / 'relay_worker.py'
+    script.write_text(RELAY_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=_free_port(), WORLD_SIZE='2', OMP_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f'rank {r} ok' in o
+
+
 def test_pseudo_label_exporter_roundtrip(tmp_path):
     """N3 exporter: result dicts -> OpenPCDet infos-style pickle + NPZ and back (empty frames included)."""
     import pickle

@@ -124,3 +124,29 @@ def chain_ground_state(ground_model, run_my_block, device=None):
     out = run_my_block()
     send_ground_state(ground_model, device)
     return out
+
+
+def relay_recv_state(ground_model, g, device=None):
+    """Round-robin frames with the ground state RELAYED frame by frame (bench.py --ground-handoff relay; SURVEY 8e exception 1): frame
+    g belongs to rank g % N, and before its ground pass that rank takes the Patchwork++ state behind frame g - 1 from rank (g - 1) % N
+    (point to point, ~131 KB).  Every rank runs ONLY its own ground passes -- against `replicate`, where every rank runs all N K of them:
+    measured by one rank on one GPU (bench.py multi_gpu_model.measured_single_rank_emulation) that costs 1.3 / 2.7 / 6.2 % at N = 2 / 4 /
+    8 -- at the price of a chain of N hand-offs per round of frames (0.46 ms pass + transfer each, far below a 14 ms frame)."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1 or g == 0:
+        return
+    from ._lib import lib
+    buf = torch.empty(int(lib.vg_ground_state_bytes()), dtype=torch.uint8, device=_state_device(device))
+    dist.recv(buf, src=(g - 1) % ws)
+    ground_model.set_state(buf.cpu().numpy().tobytes())
+
+
+def relay_send_state(ground_model, g, n_total, device=None):
+    """... and behind its ground pass of frame g (synchronises the caller's stream) it sends the state on to the owner of frame g + 1."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1 or g >= n_total - 1:
+        return
+    blob = torch.frombuffer(bytearray(ground_model.export_state()), dtype=torch.uint8).to(_state_device(device))
+    dist.send(blob, dst=(g + 1) % ws)

@@ -181,7 +181,7 @@ class PseudoLabelPipeline:
         parts = [f.result() for f in futs]
         return [parts[i % n_workers][i // n_workers] for i in range(len(items))]
 
-    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0, after_ground=None, own=None):
+    def process_frames(self, frames, poses, ref_pose, n_workers=3, first_fnr=0, after_ground=None, own=None, relay=None):
         """Throughput mode: frames (list of CUDA/numpy point arrays) are processed with `n_workers` frames in flight,
         each on its own HIP stream with its own handles.  Ground segmentation is stateful across frames and runs in
         frame order on the caller's stream; everything else of a frame runs on a worker stream after an event wait.
@@ -191,6 +191,9 @@ class PseudoLabelPipeline:
         sequence itself (0.36 ms per 150k-point scan on a high-priority stream, under its own frames' ViT work) and the frames are
         dealt round-robin, so rank r's first frame waits for r ground passes instead of r whole blocks and no state travels
         (bench.py --ground-handoff replicate).
+        relay: (recv(i), send(i)) with `own`: the other ranks' frames are NOT touched at all; recv(i) is called before the ground pass of own
+        frame i (it installs the ground state behind frame i - 1, taken from that frame's owner) and send(i) behind it (it hands the state
+        on to the owner of frame i + 1) -- vilgod_amd/dist.py relay_recv_state / relay_send_state.
         Returns [(FrameState, result dict, probs tensor)] of the own frames, in frame order."""
         own_set = None if own is None else set(int(i) for i in own)
         own_idx = list(range(len(frames))) if own_set is None else sorted(own_set)
@@ -276,9 +279,16 @@ class PseudoLabelPipeline:
         try:
             with torch.cuda.stream(main):
                 for i, pts in enumerate(frames):
+                    mine = own_set is None or i in own_set
+                    if relay is not None and not mine:
+                        continue                 # another rank's frame: its owner runs the ground pass and relays the state
+                    if relay is not None:
+                        relay[0](i)
                     d_pts = self.upload(pts)
                     mask = self.ground(d_pts)
-                    if own_set is not None and i not in own_set:
+                    if relay is not None:
+                        relay[1](i)
+                    if not mine:
                         continue                 # another rank's frame: only the ground state moves on
                     ev = torch.cuda.Event()
                     ev.record(main)
