@@ -2,14 +2,17 @@
 # on the GPU box: per-launch durations of k_cl_b_search for ONE MST of a 150k-point frame, development library, in dispatch order:
 #   VG_CLUSTER_SEEDSIM=1 -> round 1 is searched twice, the second launch walks only the points a k-NN seed could not serve
 #   VG_CLUSTER_SITOUT=0 / default -> the rounds with and without the largest component searching
+#   VG_CLUSTER_BOUNDSIM=1 (round 6) -> every round is searched twice, the second launch with every component's TRUE minimum published from the
+#     start: the floor of any search that shares a component bound better (printed in pairs: real launch, perfect-bound launch)
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/seedsim
 cd /tmp && export TMPDIR=/tmp
 export VILGOD_HIP_LIB=$GRAFT_REPO_ROOT/vilgod_amd/libvilgod_hip_dev.so
 for mode in ${MODES:-seedsim sitout_on sitout_off}; do
   case $mode in
-    seedsim) export VG_CLUSTER_SEEDSIM=1; unset VG_CLUSTER_SITOUT;;
-    sitout_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT;;
+    seedsim) export VG_CLUSTER_SEEDSIM=1; unset VG_CLUSTER_SITOUT; unset VG_CLUSTER_BOUNDSIM;;
+    boundsim) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_BOUNDSIM=1;;
+    sitout_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; unset VG_CLUSTER_BOUNDSIM;;
     sitout_off) unset VG_CLUSTER_SEEDSIM; export VG_CLUSTER_SITOUT=0;;
     xcd_on) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_XCD_ORDER=1;;
     xcd_off) unset VG_CLUSTER_SEEDSIM; unset VG_CLUSTER_SITOUT; export VG_CLUSTER_XCD_ORDER=0;;

@@ -205,6 +205,13 @@ stages = {
     'clustering_boruvka_search': stage(lambda k: 'k_cl_b_search' in k, M * 16 + (M - 1) * 16, 'points read once per round + the n - 1 MST edges (16 B) over all rounds; latency-bound tree walks, not a bandwidth kernel',
                                        {'pairs_evaluated_over_needed_core_distances': {'value': 29.9, 'source': 'profiles/r03a: VG_CLUSTER_DEBUG counters of the development build (cooperative k-NN kernel; the per-point walk: 9.5)'}}),
     'clustering_grid_tables': stage(lambda k: 'k_cl_fill_int' in k or 'k_cl_levels' in k, M * 4, 'the dense cell-start table (64 MB) is refilled and its level tables rebuilt per frame for M x 4 B of codes'),
+    # the attention is nearer its HBM roof than its MFMA roof (VERDICT r5 task 4): q, k, v rows read once and the output rows written once per
+    # (crop, head) item -- 4 x 197 x 64 x 2 B -- in 12 layers; an unfused attention cannot move less
+    'attention': stage(lambda k: 'k_attention_f16' in k, crops * 12 * 12 * 197 * 64 * 2 * 4, 'q, k, v rows read + output rows written once per (crop, head) and layer: crops x 12 heads x 12 layers x 4 x 197 x 64 x 2 B',
+                       {'bound': 'hbm', 'floor_us_per_launch_at_6_3_tb_per_s_copy_rate': round(crops * 12 * 197 * 64 * 2 * 4 / 6.3e12 * 1e6, 1),
+                        'note': 'per item the kernel is a chain of phases on seven waves (staging, load issue, S^T MFMAs, softmax on the vector ALU, P V, output) with ONE 97 KB workgroup per CU: '
+                                'nothing overlaps the phases of an item except the next item\'s loads in flight.  Tried and measured (LAB_NOTES): K / V by LDS-DMA into a double buffer '
+                                '(round 4: 111.5 vs 114 us, item time unchanged), two 4-wave workgroups per CU (round 3: +6 %), SIMD partners staggered (round 5: -3.5 %, kept)'}),
     'ground': stage(lambda k: k.startswith('k_pw_'), N * 16 + N * 1, 'N x 16 B of points read + N x 1 B mask written; one workgroup per patch, bound by its densest patch\'s dependent chain'),
 }
 json.dump(stages, open(os.path.join(dst, 'stage_roofline.json'), 'w'), indent=1)

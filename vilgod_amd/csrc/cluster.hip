@@ -1805,6 +1805,27 @@ int vg_cluster_mst_nd(vg_cluster* h, const float* d_points, int n, int stride, i
         hipLaunchKernelGGL(k_cl_b_round_init, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_best_w, h->d_best_d, h->d_best_e, h->d_sel_a, flags, h->d_csize, h->d_giant, h->d_code_s, h->d_cell_comp);
         if (r > 1) hipLaunchKernelGGL(k_cl_b_seed, dim3(nb), dim3(256), 0, st, n, h->d_comp, h->d_pt_b, h->d_pt_w, h->d_best_w, flags);
         hipLaunchKernelGGL(k_cl_b_purity, dim3(nb), dim3(256), 0, st, n, h->d_code_s, h->d_comp, h->d_cell_comp, flags);
+#ifdef VG_DEV
+        // VG_CLUSTER_BOUNDSIM (round 6, VERDICT r5 task 6: would a component-level search pay?).  What a workgroup-per-component search adds
+        // to this walk is a component bound every point sees AT ONCE (here: published through best_w by atomicMin, read at the start and every
+        // 8th node).  Simulated before being built: every round's search is launched a SECOND time with best_w already holding each
+        // component's final minimum (candidates and lower bounds restored to their state in front of the first launch) -- no shared bound
+        // can prune more than the true one from the first node on.  The second launches' durations are the floor of that family.
+        static const bool boundsim = getenv("VG_CLUSTER_BOUNDSIM") != nullptr;
+        static int* sim_b = nullptr; static double* sim_lb = nullptr; static int sim_n = 0;
+        if (boundsim) {
+            if (sim_n < n) { (void)hipFree(sim_b); (void)hipFree(sim_lb); (void)hipMalloc(&sim_b, (size_t)n * 4); (void)hipMalloc(&sim_lb, (size_t)n * 8); sim_n = n; }
+            (void)hipMemcpyAsync(sim_b, h->d_pt_b, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(sim_lb, h->d_pt_lb, (size_t)n * 8, hipMemcpyDeviceToDevice, st);
+            if (dim == 3) cl_launch_search<3>(h, n, st, sit_min, xcd_order);
+            else if (dim == 4) cl_launch_search<4>(h, n, st, sit_min, xcd_order);
+            else cl_launch_search<5>(h, n, st, sit_min, xcd_order);
+            // best_w now holds every component's minimum: search again from the same candidates / lower bounds (this launch's outputs are the
+            // ones the round goes on with: the same edges -- tests still pass with the switch on)
+            (void)hipMemcpyAsync(h->d_pt_b, sim_b, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+            (void)hipMemcpyAsync(h->d_pt_lb, sim_lb, (size_t)n * 8, hipMemcpyDeviceToDevice, st);
+        }
+#endif
         if (dim == 3) cl_launch_search<3>(h, n, st, sit_min, xcd_order);
         else if (dim == 4) cl_launch_search<4>(h, n, st, sit_min, xcd_order);
         else cl_launch_search<5>(h, n, st, sit_min, xcd_order);
