@@ -1438,11 +1438,21 @@ __global__ __launch_bounds__(512, 1) void k_gemm_f16_pp64(const f16* __restrict_
 //   Folded LayerNorm: the producer (LN = 2) writes one (mean, M2) partial per row and 128-COLUMN half (this wave's), the consumer
 //   (LN = 1) merges K / 128 of them; k_gemm_f16_pp64 keeps one per 256 columns -- a tower uses one kernel family throughout.
 #include "gemm_w4_loop.inc"
-template <int IDX, int E>
-__device__ __forceinline__ float w4_acc() {          // register E of accumulator tile IDX = 8 ni + mi, out of the AGPR the K loop left it in
-    float r;
-    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(4 * IDX + E));
-    return r;
+// register E of the eight accumulator tiles (ni = 0..7, mi = MI), out of the AGPRs the K loop left them in: a[4 (8 ni + MI) + E].  ONE asm
+// statement per eight values, and a whole mi block's four statements in a row: inline asm is a scheduling boundary for hipcc, and with one
+// statement per value every element's exp -> add -> rcp chain (QuickGELU) or DPP chain (row statistics) sat alone in its region, padded
+// with s_nop (469 per tile in the c_fc epilogue).
+template <int MI, int E>
+__device__ __forceinline__ void w4_acc8(float (&r)[8]) {
+    asm volatile("v_accvgpr_read_b32 %0, a[%8]\n\tv_accvgpr_read_b32 %1, a[%9]\n\tv_accvgpr_read_b32 %2, a[%10]\n\tv_accvgpr_read_b32 %3, a[%11]\n\t"
+                 "v_accvgpr_read_b32 %4, a[%12]\n\tv_accvgpr_read_b32 %5, a[%13]\n\tv_accvgpr_read_b32 %6, a[%14]\n\tv_accvgpr_read_b32 %7, a[%15]"
+                 : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]), "=v"(r[4]), "=v"(r[5]), "=v"(r[6]), "=v"(r[7])
+                 : "n"(4 * (0 * 8 + MI) + E), "n"(4 * (1 * 8 + MI) + E), "n"(4 * (2 * 8 + MI) + E), "n"(4 * (3 * 8 + MI) + E),
+                   "n"(4 * (4 * 8 + MI) + E), "n"(4 * (5 * 8 + MI) + E), "n"(4 * (6 * 8 + MI) + E), "n"(4 * (7 * 8 + MI) + E));
+}
+template <int MI>
+__device__ __forceinline__ void w4_acc_block(float (&r)[4][8]) {       // the 4 x 8 values of an mi block (token 4 q + e, eight features)
+    w4_acc8<MI, 0>(r[0]); w4_acc8<MI, 1>(r[1]); w4_acc8<MI, 2>(r[2]); w4_acc8<MI, 3>(r[3]);
 }
 template <int I> struct w4_ic { static constexpr int value = I; };
 template <int... Is, typename F>
@@ -1558,8 +1568,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     for (; ti < xcnt; ti += tstride) {
     int m0n = m0, n0n = n0, tnn = tn;               // the next tile, whose first pieces this tile's last K iterations request (none left: this tile again -- the
     if (ti + tstride < xcnt) tile_mn(xbase + ti + tstride, m0n, n0n, tnn);       // pieces land in slots nobody reads and are drained before the workgroup ends)
-    int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(lane_t));
+    int lane_t;                                    // the lane id, produced INSIDE the loop (v_mbcnt on an opaque zero): a loop-invariant lane id is hoisted, kept live
+    { unsigned z_; asm volatile("v_mov_b32 %0, 0" : "=v"(z_)); lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z_)); }      // across the whole loop and spilled
     issue_raw(m0n, n0n, lane_t);                    // the NEXT tile's bias / LayerNorm operands: older than this tile's stores (see issue_raw)
     {
     // per-lane operands of the K loop, re-derived per tile from the lane id (a dozen integer instructions): kept live across the tile
@@ -1614,8 +1624,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     // Addresses are a wave-uniform row pointer (SGPR pair) plus ONE per-lane byte offset: 32 row pointers per lane would not leave room
     // for the residual rows in flight.  The lane id is re-derived per tile (mbcnt) behind an opaque asm: nothing of the epilogue's
     // address arithmetic is hoisted out of the tile loop, across the K loop's assembly block.
-    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(lane_e));
+    int lane_e;
+    { unsigned z_; asm volatile("v_mov_b32 %0, 0" : "=v"(z_)); lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z_)); }
     const int r15 = lane_e & 15, q4 = lane_e >> 4;
     const int urow = m0 + wm * 128;                         // wave-uniform first row of the quadrant
     if constexpr (F16OUT) {
@@ -1625,6 +1635,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
         const char* cbase = (const char*)((f16*)Cout + (size_t)urow * ldc + n0 + wn * 128);
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
+            float acc[4][8];
+            w4_acc_block<mi>(acc);
             w4_for<4>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 float mean = 0.f, rstd = 1.f;
@@ -1634,14 +1646,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                     rstd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_rstd2[mi >> 2])));
                 }
                 f16x8 h8;
-                w4_for<8>([&](auto nic) {
-                    constexpr int ni = decltype(nic)::value;
-                    const float a = w4_acc<ni * 8 + mi, e>();
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni) {
+                    const float a = acc[e][ni];
                     float x = a + bb[ni];
                     if (LN == 1) x = rstd * (a - mean * cc[ni]) + bb[ni];
                     if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
                     h8[ni] = (f16)x;
-                });
+                }
                 *(f16x8*)(const_cast<char*>(cbase) + (size_t)(mi * 16 + e) * ldc * 2 + loff) = h8;
             });
         });
@@ -1666,29 +1678,39 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
             if (EPI == EPI_BIAS_RESID && (mi & 3) == 0) load_group(mi >> 2);
+            [[maybe_unused]] float st_mean[4], st_m2[4];
+            float acc[4][8];
+            w4_acc_block<mi>(acc);
             w4_for<4>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 float4 v[2];
                 char* rp = fbase + (size_t)(mi * 16 + e) * ldc * 4 + loff;
                 w4_for<2>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
-                    v[g] = make_float4(w4_acc<(4 * g + 0) * 8 + mi, e>() + b4[g].x, w4_acc<(4 * g + 1) * 8 + mi, e>() + b4[g].y,
-                                       w4_acc<(4 * g + 2) * 8 + mi, e>() + b4[g].z, w4_acc<(4 * g + 3) * 8 + mi, e>() + b4[g].w);
+                    v[g] = make_float4(acc[e][4 * g + 0] + b4[g].x, acc[e][4 * g + 1] + b4[g].y, acc[e][4 * g + 2] + b4[g].z, acc[e][4 * g + 3] + b4[g].w);
                     if (EPI == EPI_BIAS_RESID) { const float4 x = xr[mi & 3][e][g]; v[g].x += x.x; v[g].y += x.y; v[g].z += x.z; v[g].w += x.w; }
                     *(float4*)(rp + 256 * g) = v[g];
                 });
                 if (EPI == EPI_BIAS_RESID && LN == 2) {
-                    // fp16 copy for the next GEMM + this row's statistics over the wave's 128 columns
+                    // fp16 copy for the next GEMM + this row's statistics over the wave's 128 columns (every lane of the row's 16 holds them)
                     char* hp = (char*)(ln_x16 + (size_t)(urow + mi * 16 + e) * ldc + n0 + wn * 128) + loffh;
                     const f16x4 h0 = {(f16)v[0].x, (f16)v[0].y, (f16)v[0].z, (f16)v[0].w}, h1 = {(f16)v[1].x, (f16)v[1].y, (f16)v[1].z, (f16)v[1].w};
                     *(f16x4*)hp = h0; *(f16x4*)(hp + 128) = h1;
                     const float mean = w4_row16_sum(((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w))) * (1.0f / 128.0f);
                     const float a0 = v[0].x - mean, a1 = v[0].y - mean, a2 = v[0].z - mean, a3 = v[0].w - mean;
                     const float a4 = v[1].x - mean, a5 = v[1].y - mean, a6 = v[1].z - mean, a7 = v[1].w - mean;
-                    const float m2 = w4_row16_sum(((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7)));
-                    if (r15 == 0) ln_stats[(size_t)(urow + mi * 16 + 4 * q4 + e) * (size_t)(N >> 7) + 2 * tn + wn] = LnPartial{mean, m2};
+                    st_mean[e] = mean;
+                    st_m2[e] = w4_row16_sum(((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7)));
                 }
             });
+            if (EPI == EPI_BIAS_RESID && LN == 2) {
+                // ONE predicated store per mi block, behind the four rows' arithmetic (a branch per row cut the block into four scheduling
+                // regions and left every row's DPP chain alone with its s_nops): lane r = e of each 16 writes row e's pair
+                const float mean = r15 == 0 ? st_mean[0] : r15 == 1 ? st_mean[1] : r15 == 2 ? st_mean[2] : st_mean[3];
+                const float m2 = r15 == 0 ? st_m2[0] : r15 == 1 ? st_m2[1] : r15 == 2 ? st_m2[2] : st_m2[3];
+                if (r15 < 4)
+                    *(LnPartial*)((char*)(ln_stats + (size_t)(urow + mi * 16) * (size_t)(N >> 7) + 2 * tn + wn) + (unsigned)((4 * q4 + r15) * (N >> 7)) * 8u) = LnPartial{mean, m2};
+            }
         });
     }
 #ifdef VG_DEV
