@@ -480,3 +480,40 @@ def test_hip_tower_kernel_families_agree(cuda, monkeypatch):
     rel = ((f_w4 - f_pp).norm() / f_pp.norm()).item()
     print(f'k_gemm_f16_w4 vs k_gemm_f16_pp64 tower: relative L2 {rel:.2e}')
     assert rel < 5e-4           # (measured 1.7e-4: a last-bit difference of a row's rstd moves fp16 roundings downstream; the fp16 tower sits 3.4e-4 from the fp32 tower)
+
+
+@pytest.mark.gpu
+def test_hip_tower_is_deterministic_with_two_encodes_in_flight(cuda):
+    """Race screen for k_gemm_f16_w4 under the pipeline's conditions: two encodes in flight on two streams (persistent workgroups of one
+    launch start on CUs as the other launch's workgroups leave them; DMA pieces of a tile are waited for with counts that assume in-order
+    retirement behind the previous tile's stores).  A fragment read that ran ahead of its piece would return stale LDS bytes without any
+    fault: 2 x 12 encodes of 120 crops, every result bit-identical to the first."""
+    import threading
+    from vilgod_amd.clip_wrapper import VitEncoder
+    wd = cw.synthetic_vit_weights(1, **cw.VIT_B16)
+    enc = VitEncoder(wd, dtype='f16', device=cuda)
+    n = 120
+    rows = (n * 196 + 255) // 256 * 256
+    g = torch.Generator().manual_seed(7)
+    pats = [(torch.randint(0, 256, (rows, 256), generator=g).float() / 256).half().to(cuda) for _ in range(2)]
+    views = [enc.view(), enc.view()]
+    streams = [torch.cuda.Stream(device=cuda) for _ in range(2)]
+    ref = []
+    for k in range(2):
+        with torch.cuda.stream(streams[k]):
+            ref.append(views[k].encode_patches(pats[k], n).clone())
+        streams[k].synchronize()
+    assert torch.isfinite(ref[0]).all() and not torch.equal(ref[0], ref[1])
+    bad = []
+
+    def loop(k):
+        with torch.cuda.stream(streams[k]):
+            for it in range(12):
+                f = views[k].encode_patches(pats[k], n)
+                streams[k].synchronize()
+                if not torch.equal(f, ref[k]):
+                    bad.append((k, it, (f - ref[k]).abs().max().item()))
+    th = [threading.Thread(target=loop, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad, bad
