@@ -327,6 +327,8 @@ def test_cu_mask_words_partition_the_device():
         cu_mask_words(256, 32, 'front')
     with pytest.raises(ValueError):
         cu_mask_words(256, 0, 'tower')
+    with pytest.raises(ValueError):
+        cu_mask_words(100, 2, 'front')          # not a multiple of 8 XCDs: another partition mode, the mask layout is unknown
 
 
 def test_pack_clusters_host_equals_numpy_form():

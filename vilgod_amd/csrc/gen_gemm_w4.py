@@ -55,6 +55,7 @@ S_CNT = 74
 S_WDST = 75              # this wave's byte offset inside a slot (64 rows x 128 B x wave)
 SRD = {'x': 76, 'w': 80}       # s[76:79], s[80:83]
 S_END = 91               # lds0 + 5 slots (ring wrap)
+S_OFF0 = {'x': 58, 'w': 59}    # IOFF: source offset of piece 0 (3 072: the descriptor bases sit that much low)
 
 # vmcnt allowances by output kind: how many of the epilogue's vector-memory operations (its stores) may still be in flight when the
 # next block waits for its first pieces.  'h': fp16 outputs, exactly 32 16-byte stores per lane; 'f': fp32 outputs, >= 64 (the count is
@@ -85,11 +86,22 @@ def dst(slot):
     return 's_add_u32 s%d, s%d, s%d' % (S_DST, slot, S_WDST)
 
 
+IOFF = True     # pieces p & 3 != 0 reach their LDS rows through the instruction's 12-bit offset (added to the LDS address AND to the source address:
+                # the descriptors' bases sit 3 072 bytes low and every piece's source offset carries 3 072 - 1 024 (p & 3)): M0 is written twice per
+                # eight pieces instead of eight times
+
+
 def m0(p):
+    if IOFF:
+        return None if p & 3 else ('s_mov_b32 m0, s%d' % S_DST if p == 0 else 's_add_u32 m0, s%d, 4096' % S_DST)
     return 's_mov_b32 m0, s%d' % S_DST if p == 0 else 's_add_u32 m0, s%d, %d' % (S_DST, 1024 * p)
 
 
 def piece(op, p):
+    if IOFF:
+        so = 's%d' % (S_OFF0[op] if p == 0 else S_OFF[op] + p - 1)
+        io = ' offset:%d' % (1024 * (p & 3)) if p & 3 else ''
+        return 'buffer_load_dwordx4 %%[d%s%d], s[%d:%d], %s offen%s lds' % ('v' if op == 'x' else 'w', p & 1, SRD[op], SRD[op] + 3, so, io)
     so = '0' if p == 0 else 's%d' % (S_OFF[op] + p - 1)
     return 'buffer_load_dwordx4 %%[d%s%d], s[%d:%d], %s offen lds' % ('v' if op == 'x' else 'w', p & 1, SRD[op], SRD[op] + 3, so)
 
@@ -100,6 +112,8 @@ def advance(op, n=1):
 
 def srd_base(op, nxt=False):
     lo, hi = ('n' if nxt else '') + op + 'lo', ('n' if nxt else '') + op + 'hi'
+    if IOFF:
+        return ['s_sub_u32 s%d, %%[%s], 3072' % (SRD[op], lo), 's_subb_u32 s%d, %%[%s], 0' % (SRD[op] + 1, hi)]
     return ['s_mov_b32 s%d, %%[%s]' % (SRD[op], lo), 's_mov_b32 s%d, %%[%s]' % (SRD[op] + 1, hi)]
 
 
@@ -166,7 +180,7 @@ def body(dma_w, dma_x, vm_at_m, read_next, c0=False, loop_label=None, sched=SCHE
         gaps[first - 1] += (srd_base(op, nxt=True) if what == 'next0' else []) + [dst(slot), m0(0)]
         for p in range(8):
             gaps[first + s['dma_step'] * p].append(piece(op, p))
-            if p < 7:
+            if p < 7 and m0(p + 1):
                 gaps[first + s['dma_step'] * p + 1].append(m0(p + 1))
         gaps[first + s['dma_step'] * 7 + 1] += advance(op)
     # ---- first sub-step's fragments of tile i + 1 (slots c = X(i+1), d = W(i+1)); their registers are free behind MFMA 63
@@ -216,6 +230,11 @@ def setup():
     out.append('s_mov_b32 s%d, %%[rowb]' % (ow + 1))
     for p in range(3, 8):
         out.append('s_add_u32 s%d, s%d, %%[rowb]' % (ow + p - 1, ow + p - 3))
+    if IOFF:                                                              # every piece's source offset += 3 072 - 1 024 (p & 3)
+        for op in ('x', 'w'):
+            out.append('s_mov_b32 s%d, 3072' % S_OFF0[op])
+            for p in range(1, 8):
+                out.append('s_add_u32 s%d, s%d, %d' % (S_OFF[op] + p - 1, S_OFF[op] + p - 1, 3072 - 1024 * (p & 3)))
     out.append('s_add_u32 s%d, %%[lds0], %d' % (S_END, 5 * 32768))
     out.append('s_add_u32 s%d, %%[lds0], %%[ring]' % S_SLOT[0])
     for i in range(1, 5):                                                 # next slot = + 32 KB, wrapping at the end of the ring
@@ -242,7 +261,7 @@ def program(sched=SCHED, st='h'):
     for op, slot in (('x', a), ('w', b), ('x', c), ('w', d), ('x', e)):
         out += [dst(slot)]
         for p in range(8):
-            out += [m0(p), 's_nop 0', piece(op, p)]
+            out += ([m0(p), 's_nop 0'] if m0(p) else []) + [piece(op, p)]
         out += advance(op)
     out += ['s_waitcnt vmcnt(8)', 's_branch .Lw4_go_%=']           # (X(1), W(1) too: the first M's allowance is the prefetched case's)
     # ---- the previous block has issued them: the descriptors continue behind them
@@ -272,7 +291,7 @@ def clobbers():
     c = ['"memory"', '"scc"', '"m0"']
     c += ['"v%d"' % i for i in range(120, 256)]
     c += ['"a%d"' % i for i in range(256)]
-    c += ['"s%d"' % i for i in range(60, 102)]
+    c += ['"s%d"' % i for i in range(58, 102)]
     return c
 
 

@@ -30,7 +30,7 @@ def device_cu_count(device=None):
 def cu_mask_words(n_cu, reserve_per_xcd, role):
     """-> uint32 words of the CU mask.  role 'front': the reserved CUs (the low 8 r bits); 'tower': every other CU."""
     r = int(reserve_per_xcd)
-    if n_cu % N_XCD or n_cu // N_XCD < 16:
+    if n_cu % N_XCD or n_cu < 8 * N_XCD:
         raise ValueError(f'CU masks assume {N_XCD} XCDs in SPX mode (MI300X / MI355X: 256 or 304 CUs); this device reports {n_cu} CUs -- '
                          'on another partition mode bit i of the mask is not CU slot i // 8 of XCD i % 8 (ADVICE r5)')
     if not 0 < r * N_XCD < n_cu:
