@@ -1633,18 +1633,34 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
         const float cc[8] = {cur_c[0].x, cur_c[0].y, cur_c[0].z, cur_c[0].w, cur_c[1].x, cur_c[1].y, cur_c[1].z, cur_c[1].w};
         const unsigned loff = ((unsigned)(4 * q4) * (unsigned)ldc + (unsigned)(r15 * 8)) * 2u;
         const char* cbase = (const char*)((f16*)Cout + (size_t)urow * ldc + n0 + wn * 128);
+        // folded LayerNorm: the rows' (mean, rstd) are fetched for FOUR mi blocks at a time, 32 ds_bpermute back to back and pinned behind
+        // them (fetched row by row inside the loop every pair sat behind its own lgkmcnt wait -- 32 exposed LDS round trips per tile -- and
+        // left alone the compiler sinks every pair back in front of its use).  Row mi 16 + 4 q + e of the wave's half sits in lane
+        // (row & 63), register set mi >> 2.
+        float rmean[4][4], rrstd[4][4];
+        auto fetch_rows = [&](int mg) {
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int src = (((mg * 4 + mm) * 16 + 4 * q4 + e) & 63) << 2;
+                    rmean[mm][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_mean2[mg])));
+                    rrstd[mm][e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_rstd2[mg])));
+                }
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(rmean[mm][e]), "+v"(rrstd[mm][e]));
+        };
         w4_for<8>([&](auto mic) {
             constexpr int mi = decltype(mic)::value;
+            if (LN == 1 && (mi & 3) == 0) fetch_rows(mi >> 2);
             float acc[4][8];
             w4_acc_block<mi>(acc);
             w4_for<4>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 float mean = 0.f, rstd = 1.f;
-                if (LN == 1) {           // row mi 16 + 4 q + e of the wave's half sits in lane (row & 63), register set mi >> 2
-                    const int src = ((mi * 16 + 4 * q4 + e) & 63) << 2;
-                    mean = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_mean2[mi >> 2])));
-                    rstd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, ln_rstd2[mi >> 2])));
-                }
+                if (LN == 1) { mean = rmean[mi & 3][e]; rstd = rrstd[mi & 3][e]; }
                 f16x8 h8;
 #pragma unroll
                 for (int ni = 0; ni < 8; ++ni) {
