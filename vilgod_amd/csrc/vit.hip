@@ -1493,9 +1493,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     const int xcnt = xq + (xcd < xr_ ? 1 : 0);
     const int tstride = (int)(gridDim.x >> 3);
     const int per_chunk = ntm * cw;
-    auto tile_mn = [&](int t, int& m0_, int& n0_, int& tn_) {
-        const int chunk = t / per_chunk, tc = t - chunk * per_chunk;
-        const int tm = tc / cw;
+    // tile t of the launch -> (row tile, column tile): column tiles in chunks of cw that share their row tile's activations in L2.  One
+    // division per tile by the launch constant cw, as a multiplication (exact for t < 2^20, cw <= 2^10); the chunk advances incrementally.
+    const unsigned inv_cw = (unsigned)((0x100000000ull + (unsigned)cw - 1u) / (unsigned)cw);
+    auto tile_of = [&](int chunk, int tc, int& m0_, int& n0_, int& tn_) {
+        const int tm = cw == 1 ? tc : (int)(((unsigned long long)(unsigned)tc * inv_cw) >> 32);      // (cw = 1: the reciprocal 2^32 does not fit)
         tn_ = chunk * cw + (tc - tm * cw);
         m0_ = tm * BM; n0_ = tn_ * BN;
     };
@@ -1508,7 +1510,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     int ti = (int)(blockIdx.x >> 3);
     if (ti >= xcnt) return;
     int m0, n0, tn;
-    tile_mn(xbase + ti, m0, n0, tn);
+    int t_chunk = (xbase + ti) / per_chunk, t_tc = (xbase + ti) - t_chunk * per_chunk;      // (the one real division: before the tile loop)
+    tile_of(t_chunk, t_tc, m0, n0, tn);
     // Per-tile operands of the epilogue (bias, and for the folded LayerNorm's consumer c1 and the K / 128 partial statistics of the
     // rows wm 128 + lane, wm 128 + 64 + lane).  Vector memory operations retire IN ORDER and the compiler cannot see the K loop's DMA
     // pieces: a load it waits for behind the assembly block would wait for every prefetched piece, and one issued behind the epilogue's
@@ -1567,7 +1570,11 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     take_raw();
     for (; ti < xcnt; ti += tstride) {
     int m0n = m0, n0n = n0, tnn = tn;               // the next tile, whose first pieces this tile's last K iterations request (none left: this tile again -- the
-    if (ti + tstride < xcnt) tile_mn(xbase + ti + tstride, m0n, n0n, tnn);       // pieces land in slots nobody reads and are drained before the workgroup ends)
+    if (ti + tstride < xcnt) {                                                   // pieces land in slots nobody reads and are drained before the workgroup ends)
+        t_tc += tstride;
+        while (t_tc >= per_chunk) { t_tc -= per_chunk; ++t_chunk; }
+        tile_of(t_chunk, t_tc, m0n, n0n, tnn);
+    }
     int lane_t;                                    // the lane id, produced INSIDE the loop (v_mbcnt on an opaque zero): a loop-invariant lane id is hoisted, kept live
     { unsigned z_; asm volatile("v_mov_b32 %0, 0" : "=v"(z_)); lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z_)); }      // across the whole loop and spilled
     issue_raw(m0n, n0n, lane_t);                    // the NEXT tile's bias / LayerNorm operands: older than this tile's stores (see issue_raw)
@@ -1663,12 +1670,20 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                 if (LN == 1) { mean = rmean[mi & 3][e]; rstd = rrstd[mi & 3][e]; }
                 f16x8 h8;
 #pragma unroll
-                for (int ni = 0; ni < 8; ++ni) {
-                    const float a = acc[e][ni];
-                    float x = a + bb[ni];
-                    if (LN == 1) x = rstd * (a - mean * cc[ni]) + bb[ni];
-                    if (EPI == EPI_BIAS_GELU) x = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * QGELU_C));
-                    h8[ni] = (f16)x;
+                for (int np2 = 0; np2 < 4; ++np2) {      // feature pairs: the non-transcendental steps as packed fp32 operations (same IEEE operations per element)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 a = {acc[e][2 * np2], acc[e][2 * np2 + 1]}, b2 = {bb[2 * np2], bb[2 * np2 + 1]};
+                    f32x2 x = a + b2;
+                    if (LN == 1) {
+                        const f32x2 c2 = {cc[2 * np2], cc[2 * np2 + 1]};
+                        x = rstd * (a - mean * c2) + b2;
+                    }
+                    if (EPI == EPI_BIAS_GELU) {
+                        const f32x2 t = x * QGELU_C;
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+                        x = x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                    }
+                    h8[2 * np2] = (f16)x.x; h8[2 * np2 + 1] = (f16)x.y;
                 }
                 *(f16x8*)(const_cast<char*>(cbase) + (size_t)(mi * 16 + e) * ldc * 2 + loff) = h8;
             });
