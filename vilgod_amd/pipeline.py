@@ -107,7 +107,7 @@ class PseudoLabelPipeline:
         self._ground_stream = None
         # frames in flight: the ViT passes of the workers take turns in arrival order (see classify); shared by the worker clones
         import threading
-        self._vit_turn = {'lock': threading.Lock(), 'events': [], 'depth': int(os.environ.get('VILGOD_VIT_CONCURRENCY', '2'))}
+        self._vit_turn = {'lock': threading.Lock(), 'events': [], 'depth': int(os.environ.get('VILGOD_VIT_CONCURRENCY', '3'))}
         self.box_workers = int(box_workers)      # helper processes for the host part of the reference box mode (0 = in the frame's thread)
         if self.box_mode == 'reference' and self.box_workers > 0:
             from . import boxes as _boxes
@@ -480,14 +480,16 @@ class PseudoLabelPipeline:
 
     @contextlib.contextmanager
     def _vit_in_turn(self):
-        """Frames in flight: at most `depth` (2; env VILGOD_VIT_CONCURRENCY, 0 = unlimited) ViT passes of the worker streams run at
+        """Frames in flight: at most `depth` (3; env VILGOD_VIT_CONCURRENCY, 0 = unlimited) ViT passes of the worker streams run at
         a time, in arrival order (a pass waits for the event recorded after the pass `depth` before it).  Left alone, the GPU
         interleaves the GEMM tiles of all queued passes: every pass takes n_workers times as long, all finish together, and the
         workers then move in lock step (all clustering, then all encoding; kernel trace: tools/analyze_fill.py) instead of one
         frame's clustering and rendering running underneath another frame's GEMMs.  Strictly one pass at a time staggers the
         workers but leaves the tails of a pass (LayerNorm, attention, head: few workgroups) uncovered; two cover each other.
         Measured, 20-frame blocks: unlimited 18.55, one 18.5, two 17.9, four 18.3 ms per frame; 96-frame blocks: 16.8 for all but
-        one (17.65)."""
+        one (17.65) -- round 2, one GEMM tile per workgroup.  Round 6 (persistent GEMM workgroups: a launch holds its CUs until its tiles
+        are done, queued launches no longer interleave tile by tile): one 63.3, two 72.2-72.6, THREE 72.6-74.1, four 72.9-73.6,
+        unlimited 72.8-73.8 frames/s (20- and 48-frame blocks, two rounds, one process each on one box): three since."""
         turn = self._vit_turn
         st = torch.cuda.current_stream(self.device)
         depth = turn['depth']
