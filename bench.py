@@ -503,7 +503,7 @@ def main():
                   'achieved': round(VIT_FLOP_PER_CROP * n_cr / t2 / 1e12, 1), 'unit': 'TFLOP/s',
                   'frac': round(VIT_FLOP_PER_CROP * n_cr / t2 / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                   'note': 'the whole ViT-B/16 tower (projection GEMMs, attention, embedding, head: 35.1 GFLOP per crop, SURVEY 8d) on random '
-                          'single-channel patch rows of the stream\'s mean crop count, two encodes in flight on two streams as in the pipeline; wall '
+                          'single-channel patch rows of the stream\'s mean crop count, two encodes in flight on two streams (the pipeline lets up to three ViT passes run at a time since round 6: VILGOD_VIT_CONCURRENCY); wall '
                           'time per encode.  Not the kernel roofline (that is `frac` above, one launch at a time): what the timed region gets'}
         del views2, pat2
 
@@ -548,7 +548,7 @@ def main():
                 'nonground_points_per_frame': round(sum(int(getattr(fs, 'n_nonground', 0) or 0) for fs, _, _ in outs) / max(K, 1)),
                 'crops_per_frame': round(crops / max(K, 1), 1),
                 'labelled_per_frame': round(labelled / max(K, 1), 1),
-                'weights': pipe.clip.weights_source, 'parallelism': f'frame-sharded x{world}', 'frames_in_flight_per_gpu': inflight,
+                'weights': pipe.clip.weights_source, 'parallelism': f'frame-sharded x{world}', 'frames_in_flight_per_gpu': inflight, 'vit_passes_at_a_time': int(os.environ.get('VILGOD_VIT_CONCURRENCY', '3')),
                 'box_mode': args.box_mode,
             },
             'roofline': {
