@@ -202,6 +202,58 @@ def test_round_robin_frames_with_replicated_ground_equal_one_rank(cuda):
 
 
 @pytest.mark.gpu
+def test_round_robin_frames_with_relayed_ground_state_equal_one_rank(cuda):
+    """bench.py --ground-handoff relay (round 6): two "ranks" (two pipeline objects on two threads, a pair of queues standing in for the
+    point-to-point link) take the frames of one sequence round-robin; each runs ONLY its own ground passes, taking the Patchwork++ state
+    behind frame g - 1 from that frame's owner before its pass of frame g and handing its own on behind it (process_frames(own=...,
+    relay=(recv, send)); vilgod_amd/dist.py relay_recv_state / relay_send_state do the same over torch.distributed).  Merged, the results
+    equal one pipeline processing the whole sequence -- ground sets, clusters, validity, boxes, names, scores."""
+    import queue
+    import threading
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    n = 7
+    poses = synthetic.make_poses(n + 2)
+    frames = [synthetic.make_frame(90 + f, 40_000, n_objects=16) for f in range(n)]
+    one = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=41_000, clip_model_path='/nonexistent')
+    one.new_sequence()
+    want = one.process_frames(frames, poses[1:n + 1], poses[0], n_workers=3)
+    link = [queue.Queue(), queue.Queue()]                 # link[r]: states addressed to rank r
+    merged, errors = {}, []
+
+    def rank(r):
+        try:
+            torch.cuda.set_device(cuda)
+            p = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=41_000, clip_model_path='/nonexistent')
+            p.new_sequence()
+            mine = [g for g in range(n) if g % 2 == r]
+
+            def recv(g):
+                if g > 0:
+                    p.ground_model.set_state(link[r].get(timeout=120))
+
+            def send(g):
+                if g < n - 1:
+                    link[(g + 1) % 2].put(p.ground_model.export_state())
+            got = p.process_frames(frames, poses[1:n + 1], poses[0], n_workers=2, own=mine, relay=(recv, send))
+            assert len(got) == len(mine)
+            merged.update(dict(zip(mine, got)))
+        except BaseException as e:     # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert sorted(merged) == list(range(n))
+    for g in range(n):
+        (fa, ra, pa), (fb, rb, pb) = want[g], merged[g]
+        assert fa.fnr == fb.fnr == g
+        assert np.array_equal(np.sort(fa.ground_point_indices), np.sort(fb.ground_point_indices)), g
+        assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off) and np.array_equal(fa.valid, fb.valid)
+        assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+        assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
+
+
+@pytest.mark.gpu
 def test_f16_pipeline_agrees_with_f32_pipeline_on_150k_frames(cuda):
     """The benchmarked fp16 pipeline against the fp32 (oracle-pinned, test_pipeline_matches_oracle_20k) pipeline on three synthetic
     150k-point frames: everything before the ViT is the same code -> ground set, clusters, valid flags and boxes EQUAL; per-crop
