@@ -105,7 +105,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
  * vg_vit_profile_read synchronises and returns launches, summed ms and algorithmic FLOPs (2*M*N*K each). */
 int vg_vit_profile(vg_vit* v, int on);
 int vg_vit_profile_read(vg_vit* v, int32_t* h_launches, double* h_ms, double* h_flops);
-/* the same, restricted to one kernel: kind 1 = k_gemm_f16_pp64 (every ViT-B/16 shape), 0 = k_gemm_f16 / k_gemm_f32, -1 = all */
+/* the same, restricted to one kernel: kind 1 = the 256 x 256 projection GEMM (k_gemm_f16_w4, or k_gemm_f16_pp64 with VG_GEMM_W4=0: every ViT-B/16
+ * shape), 0 = k_gemm_f16 / k_gemm_f32, -1 = all */
 int vg_vit_profile_read_kind(vg_vit* v, int kind, int32_t* h_launches, double* h_ms, double* h_flops);
 
 /* One projection GEMM of the tower, C = X @ Wt^T with the fused epilogue the block uses

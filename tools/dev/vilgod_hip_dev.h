@@ -10,14 +10,16 @@ extern "C" {
 
 /* development aid: the f16 GEMM kernels by number, bias epilogue (k_gemm_f16: 0, ablations 1 no in-loop DMA, 2 DMA only,
  * 3 no epilogue; k_gemm_f16_pp (32x32x16, K-step 32): 22, 20 two phases per K-step, 21/23 five stages; k_gemm_f16_pp16: 30;
- * k_gemm_f16_pp64, the production kernel: 32) */
+ * k_gemm_f16_pp64, the production kernel of rounds 2-5: 32) */
 int vg_gemm_variant(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int M, int N, int K, int ldc,
                     void* stream);
 
 /* development aid: k_gemm_f16_pp (var 20..23) and k_gemm_f16_pp64 (var 32 +bias, 33 +bias QuickGELU, 34 fp32 residual with d_C = the
  * float [M,N] stream, 35 fp16 residual with d_C = the half [M,N] stream) with per-wave cycle stamps.  d_trace receives, per
  * (workgroup, wave), eight int64: main-loop cycles, cycles in the counted vmcnt wait, cycles at barriers, prologue + epilogue
- * cycles, LOAD-segment cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks.  Variants 32..35 append, after those
+ * cycles, LOAD-segment cycles, MFMA-segment cycles, wave id, elapsed 100-MHz ticks.  var 50 (round 6): k_gemm_f16_w4's trace variant, twelve int64
+ * per (tile, wave): entry -> block, block entry, K loop, M-wait / barrier / end-wait cycle sums, one stamp pair, epilogue, whole block, first, wave,
+ * 100-MHz ticks (tools/dev/w4_trace.py; size d_trace for 48 * tiles).  Variants 32..35 append, after those
  * 64 * n_workgroups values, eight int64 per workgroup: entry and exit time (100-MHz ticks), XCC id << 32 | HW_ID, prologue
  * cycles, epilogue cycles, 1 -- size d_trace for 72 * (M/256) * (N/256) values (tools/bench_gemm_tiles.py). */
 int vg_gemm_trace(int var, const void* d_X, const void* d_Wt, const float* d_bias, void* d_C, int64_t* d_trace, int M, int N,
