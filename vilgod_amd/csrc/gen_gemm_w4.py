@@ -28,7 +28,9 @@ one 256 x 256 output tile of a PERSISTENT workgroup, including the first DMA pie
     (`vmcnt(24 + S)`, `vmcnt(8 + S)` at the first M; S = the epilogue's stores, a property of the kernel instantiation: ST below).
     The first iteration's MFMAs take 0 as their C operand: no zeroing pass over the accumulators.
   * every LDS read, DMA piece, address update and wait sits at a fixed distance between the MFMAs (the table SCHED below): nothing is
-    left to the compiler's scheduler.
+    left to the compiler's scheduler.  A DMA piece costs the CU's address path 16 cycles (1 KB per wave, 64 B per cycle) and the four waves
+    issue theirs together: pieces closer than every third gap stall the issuing waves (measured), and X's pieces, which have two
+    iterations to land, are spread to every sixth (in_proj -3 %, c_proj -5 % against every third).
 
 Registers: v128..v255 fragments (W half 0, X half 0, W half 1, X half 1: 32 each), v120..v123 read addresses, s60..s91 (piece offsets,
 slot ring, buffer descriptors, loop counter; s92..s101 cycle stamps of the trace variant).  Everything else comes in through named
@@ -139,9 +141,9 @@ def stamp_take(acc):
 SCHED = dict(
     rd1_first=1, rd1_pattern=(0, 1),     # second sub-step's fragments: two reads in every three gaps from gap rd1_first on
     wait_m=31, bar_m=32,                 # s_waitcnt vmcnt(..) lgkmcnt(0) behind MFMA 31, s_barrier behind MFMA 32
-    dma_w_first=34, dma_x_first=58, dma_step=3,
+    dma_w_first=34, dma_x_first=58, dma_step=3, dma_x_step=6,     # W(i+2) a piece every 3rd gap (one iteration to land), X(i+3) every 6th (two)
     rd0_first=67, rd0_pattern=(0, 1),
-    rotate_at=100, loop_at=127, wait_end=126,
+    rotate_at=104, loop_at=127, wait_end=126,
 )
 
 
@@ -164,8 +166,8 @@ def body(dma_w, dma_x, vm_at_m, read_next, c0=False, loop_label=None, sched=SCHE
         for o in s['rd1_pattern']:
             if n < 16:
                 gaps[g + o].append(reads[n]); n += 1
-        g += 3
-    assert g - 3 + max(s['rd1_pattern']) < s['wait_m']
+        g += s.get('rd1_stride', 3)
+    assert g - s.get('rd1_stride', 3) + max(s['rd1_pattern']) < s['wait_m']
     if s.get('trace'):
         gaps[s['wait_m'] - 1] += stamp_first()       # executes one MFMA in front of the wait; the wait retires it with everything else
         gaps[s['wait_m']] += [wait_m] + stamp_take(94) + ['s_mov_b32 s97, s92']
@@ -177,12 +179,13 @@ def body(dma_w, dma_x, vm_at_m, read_next, c0=False, loop_label=None, sched=SCHE
     for what, op, slot, first in ((dma_w, 'w', a, s['dma_w_first']), (dma_x, 'x', b, s['dma_x_first'])):
         if not what:
             continue
+        step = s.get('dma_%s_step' % op, s['dma_step'])
         gaps[first - 1] += (srd_base(op, nxt=True) if what == 'next0' else []) + [dst(slot), m0(0)]
         for p in range(8):
-            gaps[first + s['dma_step'] * p].append(piece(op, p))
+            gaps[first + step * p].append(piece(op, p))
             if p < 7 and m0(p + 1):
-                gaps[first + s['dma_step'] * p + 1].append(m0(p + 1))
-        gaps[first + s['dma_step'] * 7 + 1] += advance(op)
+                gaps[first + step * p + 1].append(m0(p + 1))
+        gaps[first + step * 7 + 1] += advance(op)
     # ---- first sub-step's fragments of tile i + 1 (slots c = X(i+1), d = W(i+1)); their registers are free behind MFMA 63
     if read_next:
         g = s['rd0_first']
@@ -194,7 +197,7 @@ def body(dma_w, dma_x, vm_at_m, read_next, c0=False, loop_label=None, sched=SCHE
             for o in s['rd0_pattern']:
                 if n < 16:
                     gaps[g + o].append(reads[n]); n += 1
-            g += 3
+            g += s.get('rd0_stride', 3)
         assert g < s['rotate_at']
         if s.get('trace'):
             gaps[s['wait_end'] - 1] += stamp_first()
@@ -306,6 +309,18 @@ VARIANTS = [
     dict(dma_step=2, dma_x_first=50),                    # 5: the first schedule (a piece every second gap)
     dict(dma_step=4, dma_x_first=66),                    # 6
     dict(trace=True),                                    # 7: the product schedule with cycle stamps (vg_gemm_trace var 50)
+    dict(dma_x_step=3, rotate_at=100),                   # 8: the schedule until the end of round 6's first pass: X pieces every 3rd gap too
+    dict(dma_x_step=8, dma_x_first=60, rotate_at=120, rd0_first=67),   # 9: ... every eighth
+    dict(dma_x_step=3, rd0_first=97, rotate_at=124),     # 10: next tile's first fragments read late (behind the pieces)
+    dict(dma_x_first=92, dma_x_step=4, rotate_at=122),   # 11: X pieces behind the next tile's first fragments
+    dict(dma_w_step=4, dma_x_first=64, dma_x_step=6, rotate_at=110),          # 12
+    dict(dma_x_step=5, rotate_at=104),                                        # 13
+    dict(dma_x_step=7, dma_x_first=57, rotate_at=110),                        # 14
+    dict(rd1_pattern=(0,), rd1_stride=2, wait_m=39, bar_m=40, dma_w_first=42, dma_x_first=66, rd0_first=68, rotate_at=112),   # 15: a read every 2nd gap, M at 40
+    dict(dma_w_step=2, dma_x_first=52),                                       # 16: W pieces every 2nd gap
+    dict(dma_x_first=62, rotate_at=108),                                      # 17
+    dict(rd0_pattern=(0,), rd0_stride=2, rd0_first=67, rotate_at=104),        # 18: next tile's first fragments one read per 2 gaps (67..97)
+    dict(rd1_pattern=(0,), rd1_stride=1, rd1_first=1),                        # 19: second sub-step's fragments one read per gap (1..16)
 ]
 
 
