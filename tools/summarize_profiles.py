@@ -30,15 +30,16 @@ def group(match):
             continue
         f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
         st = stats.get(k)
-        g['launches'] += f[0]; g['fetch_kb'] += f[1]; g['write_kb'] += w[1]
+        g['launches'] += f[0]; g['fetch_kb'] += f[1]; g['write_kb'] += w[1]; g['launches_w'] = g.get('launches_w', 0) + w[0]
         if st:
             g['dur_ns'] += float(st['TotalDurationNs']); g['calls_trace'] += int(st['Calls'])
     n = max(g['launches'], 1)
+    nw = max(g.get('launches_w', 0), 1)        # (the FETCH and WRITE passes are separate runs of the command: their adaptive set-up may repeat a different number of times)
     return {
         'launches_pmc': g['launches'], 'avg_launch_us_trace': g['dur_ns'] / max(g['calls_trace'], 1) / 1e3,
         'fetch_bytes_per_launch_raw': 1024 * g['fetch_kb'] / n, 'fetch_bytes_per_launch_corrected_x2': 2048 * g['fetch_kb'] / n,
-        'write_bytes_per_launch': 1024 * g['write_kb'] / n,
-        'hbm_bytes_per_launch': (2048 * g['fetch_kb'] + 1024 * g['write_kb']) / n,
+        'write_bytes_per_launch': 1024 * g['write_kb'] / nw,
+        'hbm_bytes_per_launch': 2048 * g['fetch_kb'] / n + 1024 * g['write_kb'] / nw,
     }
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
