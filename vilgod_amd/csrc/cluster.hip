@@ -1671,7 +1671,7 @@ static int cl_sit_min(int n) {
 template <int DIM>
 static void cl_launch_search(vg_cluster* h, int n, hipStream_t st, int sit_min, int xcd_order) {
 #ifdef VG_DEV
-    // VG_CLUSTER_SEARCH_NT (A/B aid, development build): threads per workgroup of the walk, 256 or 512 (see k_cl_b_search)
+    // VG_CLUSTER_SEARCH_NT (A/B aid, development build): threads per workgroup of the walk, 256, 512 or 768 (see k_cl_b_search)
     const char* nt_env = getenv("VG_CLUSTER_SEARCH_NT");          // (read per launch: the A/B tool switches it inside one process)
     const int nt = nt_env ? atoi(nt_env) : 512;
 #else
@@ -1692,6 +1692,14 @@ static void cl_launch_search(vg_cluster* h, int n, hipStream_t st, int sit_min, 
                            h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
                            h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, mode == 1 ? (const int*)h->d_far : (const int*)nullptr,
                            mode == 2 ? (const int*)h->d_far_flag : (const int*)nullptr, h->d_giant, sit_min, 0);
+        return;
+    }
+#endif
+#ifdef VG_DEV
+    if (nt == 768) {      // three waves per SIMD (<= 168 registers, 132 KB of stack): 103 instead of 155 workgroups for 79k points (A/B, round 6)
+        hipLaunchKernelGGL((k_cl_b_search<DIM, 768>), dim3(vg_div_up(n, 768)), dim3(768), 0, st, h->d_spts, h->d_st, n, h->d_grid,
+                           h->d_cell_start, h->d_cell_comp, h->d_cell_e, h->d_perm, h->d_core2, h->d_comp, h->d_aux, h->d_best_w, h->d_pt_w, h->d_pt_d,
+                           h->d_pt_key, h->d_pt_b, h->d_pt_lb, h->d_dbg, h->d_counter, (const int*)nullptr, (const int*)nullptr, h->d_giant, sit_min, xcd_order);
         return;
     }
 #endif
