@@ -224,6 +224,17 @@ int vg_hdbscan_tree_host(const int32_t* h_lo, const int32_t* h_hi, const double*
                          int min_cluster_size, double eps, int32_t* h_labels, double* h_probs,
                          int32_t* h_n_clusters);
 
+/* The same hierarchy stage ON THE DEVICE (csrc/hdbscan_device.hip): d_lo / d_hi / d_w2 = the tree as vg_cluster_mst_nd leaves it
+ * (sorted by weight, ties in any order), d_labels [n] / d_probs [n] / d_n_clusters [1] device outputs equal, bit for bit, to what
+ * vg_hdbscan_tree_host returns for the same tree.  No host work between the tree and the labels: the stage is a sequence of kernels on
+ * `stream`.  A handle holds the stage's buffers for trees of up to max_points (<= 2^20) points; min_cluster_size in [2, 32]
+ * (VG_ERR_ARG beyond: the host stage has no such bound), n > max_points: VG_ERR_CAPACITY.  One call at a time per handle. */
+typedef struct vg_hier vg_hier;
+int vg_hier_create(vg_hier** out, int max_points);
+int vg_hier_destroy(vg_hier* h);
+int vg_hdbscan_tree_device(vg_hier* h, const int32_t* d_lo, const int32_t* d_hi, const double* d_w2, int n, int min_cluster_size,
+                           double eps, int32_t* d_labels, double* d_probs, int32_t* d_n_clusters, void* stream);
+
 /* LidarFrame.generate_detections' grouping (src/vilgod/lidar_frame.py:163-167, 230-237; Detection objects :42-58 of
  * src/dataclass/objects.py) on the host: points whose membership probability is < threshold become noise (h_probs may be NULL),
  * clusters in ascending label order, each cluster's point indices ascending.  h_ids [capacity n]: the labels that own a point;

@@ -4,7 +4,6 @@
 // of the data-parallel formulation are checked without a GPU; the kernels themselves are checked on the GPU against both.
 // Test infrastructure only -- nothing in vilgod_amd/ loads this.
 #include <algorithm>
-#include <numeric>
 #include <vector>
 
 #include "hdbscan_device.inc"
@@ -18,17 +17,13 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
     if (mcs < 2 || mcs > HD_MAX_MCS) return 1;
     if (n <= mcs) return 0;
     const int m = n - 1;
-    // total order (w2, lo, hi)
-    std::vector<int> ord(m);
-    std::iota(ord.begin(), ord.end(), 0);
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-        if (w2_in[a] != w2_in[b]) return w2_in[a] < w2_in[b];
-        if (lo_in[a] != lo_in[b]) return lo_in[a] < lo_in[b];
-        return hi_in[a] < hi_in[b];
-    });
+    // total order (w2, lo, hi) from the weight order the device is handed: every edge moves inside its run of equal weights
     std::vector<int> lo(m), hi(m);
     std::vector<double> w2(m);
-    for (int r = 0; r < m; ++r) { lo[r] = lo_in[ord[r]]; hi[r] = hi_in[ord[r]]; w2[r] = w2_in[ord[r]]; }
+    for (int i = 0; i < m; ++i) {
+        const int pos = hd_tie_position(lo_in, hi_in, w2_in, m, i);
+        lo[pos] = lo_in[i]; hi[pos] = hi_in[i]; w2[pos] = w2_in[i];
+    }
     // adjacency, ascending rank per vertex
     std::vector<int> adj_off(n + 1, 0);
     for (int r = 0; r < m; ++r) { adj_off[lo[r] + 1]++; adj_off[hi[r] + 1]++; }
@@ -47,7 +42,7 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
         cl_of_edge(m, 0), chainlen(ncl_cap, 0), npts(ncl_cap, 0), kw_parent(2 * ncap), kw_top(2 * ncap), nsub(ncap), tot(ncap), csize(ncl_cap),
         depth(ncap), pre(ncap), q(ncap), done(ncl_cap), sel_by_final(ncl_cap + 1), out_label(ncl_cap), ncl_out(1, 0);
     std::vector<unsigned> first(n);
-    std::vector<unsigned long long> death(ncl_cap, 0), chain(m);
+    std::vector<unsigned long long> death(ncl_cap, 0);
     std::vector<double> stab(ncl_cap), stab2(ncl_cap), out_death(ncl_cap);
     HdView v{};
     v.n = n; v.m = m; v.mcs = mcs; v.ncap = ncap; v.eps = eps;
@@ -55,7 +50,7 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
     v.side = side.data(); v.eflag = eflag.data(); v.kcnt = kcnt.data(); v.a = a.data(); v.uf = uf.data(); v.split_pos = split_pos.data();
     v.S = S.data(); v.ns = nsv.data(); v.first = first.data(); v.node = node.data(); v.sp_parent = sp_parent.data(); v.sp_side = sp_side.data();
     v.kid = kid.data(); v.cl_of_edge = cl_of_edge.data(); v.chainlen = chainlen.data(); v.npts = npts.data(); v.death = death.data();
-    v.chain = chain.data(); v.kw_parent = kw_parent.data(); v.kw_top = kw_top.data(); v.nsub = nsub.data(); v.tot = tot.data();
+    v.kw_parent = kw_parent.data(); v.kw_top = kw_top.data(); v.nsub = nsub.data(); v.tot = tot.data();
     v.csize = csize.data(); v.depth = depth.data(); v.pre = pre.data(); v.q = q.data(); v.done = done.data(); v.stab = stab.data();
     v.stab2 = stab2.data(); v.wins = wins.data(); v.selected = selected.data(); v.cand = cand.data(); v.sel_by_final = sel_by_final.data();
     v.out_label = out_label.data(); v.out_death = out_death.data(); v.n_clusters = ncl_out.data(); v.labels = labels; v.probs = probs;
@@ -73,12 +68,11 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
     if (n_splits) *n_splits = ns;
     for (int i = 0; i < 2 * ns; ++i) hd_split_nodes(v, i);
     hd_kruskal_splits(v, ns, kw_parent.data(), kw_top.data());
-    for (int r = 0; r < m; ++r) hd_chain_cluster(v, r);
-    std::vector<unsigned long long> keys(m);
-    for (int r = 0; r < m; ++r) keys[r] = hd_chain_key(v, r);
-    std::sort(keys.begin(), keys.end());
-    chain = keys;
-    v.chain = chain.data();
+    for (int r = 0; r < m; ++r) {
+        const int c = hd_chain_find(v, r);
+        cl_of_edge[r] = c;
+        if (c >= 0) hd_chain_count(v, r, c);
+    }
     const int ncl = 2 * ns + 1;
     int total_sweeps = 0;
     auto relax = [&](int count, auto&& body) {
@@ -99,7 +93,13 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
         for (int j = 0; j < ns; ++j) cnt += hd_bfs_before(depth[j], pre[j], depth[k], pre[k]) ? 1 : 0;
         q[k] = cnt;
     }
-    for (int c = 1; c < ncl; ++c) hd_stability(v, c, ns);
+    for (int c = 1; c < ncl; ++c) {
+        const double birth = hd_birth(v, c);
+        double sum = 0.0;
+        for (int r = hd_chain_hi(v, c), r0 = hd_chain_lo(v, c, ns); r >= r0; --r)
+            if (cl_of_edge[r] == c) sum = hd_stab_terms(sum, (hd_lambda(w2[r]) - birth) * 1.0, kcnt[r]);
+        hd_stability_finish(v, c, ns, sum);
+    }
     std::fill(done.begin(), done.end(), 0);
     relax(ncl - 1, [&](int i) { return hd_up_eom(v, i + 1, ns); });
     for (int c = 1; c < ncl; ++c) hd_select_eom(v, c);

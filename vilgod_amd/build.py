@@ -30,6 +30,7 @@ SOURCES = {
     'ground.hip': ['-ffp-contract=off'],
     'cluster.hip': ['-ffp-contract=off'],
     'hdbscan_tree.cpp': ['-ffp-contract=off'],
+    'hdbscan_device.hip': ['-ffp-contract=off'],
     'segment.hip': ['-ffp-contract=off'],
     'vit.hip': [],
 }

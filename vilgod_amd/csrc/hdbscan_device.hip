@@ -1,0 +1,358 @@
+// HDBSCAN hierarchy stage ON THE DEVICE (round 6; SURVEY §8a row B2, kernel list K2d): from the minimum spanning tree of the
+// mutual-reachability graph, as csrc/cluster.hip leaves it in device memory (edges sorted by weight), to flat labels and membership
+// probabilities -- no copy of the tree to the host, no host thread between the tree and the clusters' first kernel.
+//
+// Replaces the tail of `cluster_model.fit(points_ref_wo_ground)` (src/vilgod/zero_shot_detector.py:248; hdbscan.HDBSCAN(
+// min_cluster_size=15, cluster_selection_epsilon=0.15), tools/configs/preprocessor/waymo.yaml:10-15) and produces, bit for bit, what
+// the host stage csrc/hdbscan_tree.cpp produces (tests/test_hierarchy.py).  The host stage is a sequential union-find over all n - 1
+// edges; here every step is a rule with bounded local work per edge / point / cluster (hdbscan_device.inc: R1..R6, each checked against
+// the host stage on the CPU by the test-suite's emulation of the same bodies):
+//
+//   k_hd_order                         the strict (w2, lo, hi) order the host stage uses: every edge to its place inside its run of
+//                                      equal weights; the 2 (n - 1) half-edges
+//   radix sort + k_hd_offsets          the half-edges by vertex (stable: by ascending rank inside a vertex)
+//   k_hd_side<count / assign>          per (edge, side): vertices reached over lower-rank edges, at most min_cluster_size   (R1, R2)
+//   k_hd_union / k_hd_flatten          lock-free union-find over the non-split edges: segments                             (R3)
+//   scan + k_hd_scatter                the split edges, a few hundred, in rank order
+//   k_hd_tree_a                        ONE lane, union-find in LDS: Kruskal over the splits on the segments = the cluster tree
+//   k_hd_chain                         every chain node's cluster: a walk up the cluster tree                              (R4)
+//   k_hd_tree_b                        ONE workgroup: cluster sizes, dendrogram depths, the library's BFS numbering        (R5)
+//   k_hd_stability                     a wave per cluster: its chain by descending rank, summed in the library's order     (R6)
+//   k_hd_tree_c                        ONE workgroup: excess of mass, epsilon, flat labels
+//   k_hd_points                        label and probability of every point
+// The one-workgroup kernels sweep the cluster tree level by level (as many sweeps as it is high).  float64 throughout; compiled with
+// -ffp-contract=off (the stability sums are the host stage's expressions, unfused).
+#include <string.h>
+#include <algorithm>
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+
+#include "vilgod_hip.h"
+#define HD_DEVICE
+#include "hdbscan_device.inc"
+
+#define HD_NT 256                 // threads per workgroup of the per-element kernels
+#define HD_TREE_LDS_INTS 30720    // dynamic LDS of k_hd_tree_a (120 KB): ten ints per split -> up to 3072 splits, else global memory
+
+struct vg_hier {
+    int max_points;
+    char* slab;
+    void* d_temp;
+    size_t temp_bytes;
+    int *lo, *hi;                  // the tree in (w2, lo, hi) order
+    double* w2;
+    unsigned *he_key, *he_key_s;   // half-edges: vertex, (rank << 32 | other endpoint)
+    unsigned long long *he_val, *adj;
+    int* adj_off;
+    unsigned long long* bfs_key;
+    HdView v;                      // the arrays of the stage (n, m, mcs, eps, inputs filled per call)
+};
+
+namespace {
+
+struct HdSplitFlag {
+    __device__ int operator()(unsigned char f) const { return (int)(f & HD_SPLIT); }
+};
+
+__global__ __launch_bounds__(HD_NT) void k_hd_order(int m, const int* __restrict__ lo_in, const int* __restrict__ hi_in, const double* __restrict__ w2_in,
+                                                    int* __restrict__ lo, int* __restrict__ hi, double* __restrict__ w2,
+                                                    unsigned* __restrict__ he_key, unsigned long long* __restrict__ he_val) {
+    const int i = blockIdx.x * HD_NT + threadIdx.x;
+    if (i >= m) return;
+    const int r = hd_tie_position(lo_in, hi_in, w2_in, m, i);
+    const int a = lo_in[i], b = hi_in[i];
+    lo[r] = a; hi[r] = b; w2[r] = w2_in[i];
+    he_key[2 * r] = (unsigned)a;     he_val[2 * r] = ((unsigned long long)r << 32) | (unsigned)b;
+    he_key[2 * r + 1] = (unsigned)b; he_val[2 * r + 1] = ((unsigned long long)r << 32) | (unsigned)a;
+}
+
+__global__ __launch_bounds__(HD_NT) void k_hd_offsets(int n2, int n, const unsigned* __restrict__ key_s, int* __restrict__ adj_off) {
+    const int i = blockIdx.x * HD_NT + threadIdx.x;
+    if (i == 0) adj_off[n] = n2;
+    if (i >= n2) return;
+    if (i == 0 || key_s[i] != key_s[i - 1]) adj_off[key_s[i]] = i;          // (a tree: every vertex has an edge)
+}
+
+__global__ __launch_bounds__(HD_NT) void k_hd_init(HdView v) {
+    const int i = blockIdx.x * HD_NT + threadIdx.x;
+    if (i < v.n) v.uf[i] = i;
+    if (i < 2 * v.ncap + 1) { v.chainlen[i] = 0; v.npts[i] = 0; v.death[i] = 0ull; }
+    if (i == 0) { *v.ns = 0; *v.n_clusters = 0; }
+}
+
+template <bool ASSIGN>
+__global__ __launch_bounds__(HD_NT) void k_hd_side(HdView v) {
+    extern __shared__ int hd_stack[];                          // [2][mcs][HD_NT]
+    const int i = blockIdx.x * HD_NT + threadIdx.x;
+    if (i >= 2 * v.m) return;
+    int* st_x = hd_stack + threadIdx.x;
+    int* st_i = hd_stack + v.mcs * HD_NT + threadIdx.x;
+    if (ASSIGN) hd_side_assign(v, i, st_x, st_i, HD_NT);
+    else hd_side_count(v, i, st_x, st_i, HD_NT);
+}
+
+__global__ __launch_bounds__(HD_NT) void k_hd_union(HdView v) {
+    const int r = blockIdx.x * HD_NT + threadIdx.x;
+    if (r < v.m) hd_segment_union(v, r);
+}
+__global__ __launch_bounds__(HD_NT) void k_hd_flatten(HdView v) {
+    const int x = blockIdx.x * HD_NT + threadIdx.x;
+    if (x < v.n) hd_segment_flatten(v, x);
+}
+__global__ __launch_bounds__(HD_NT) void k_hd_scatter(HdView v) {
+    const int r = blockIdx.x * HD_NT + threadIdx.x;
+    if (r < v.m) hd_split_scatter(v, r);
+}
+
+// ONE workgroup: the union-find nodes of the splits' endpoints, then Kruskal over the splits by ONE lane -- every array it touches in
+// LDS (a dependent global-memory access per step would cost a microsecond each), written out afterwards
+__global__ __launch_bounds__(1024) void k_hd_tree_a(HdView v) {
+    extern __shared__ int lds[];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int ns = *v.ns;
+    if (ns == 0) return;
+    HdView w = v;
+    int *par = v.kw_parent, *top = v.kw_top;
+    const bool in_lds = 10 * ns <= HD_TREE_LDS_INTS;
+    if (in_lds) {
+        w.node = lds; par = lds + 2 * ns; top = lds + 4 * ns; w.kid = lds + 6 * ns; w.sp_parent = lds + 8 * ns; w.sp_side = lds + 9 * ns;
+    }
+    for (int i = t; i < 2 * ns; i += T) hd_split_nodes(w, i);
+    __syncthreads();
+    if (t == 0) hd_kruskal_splits(w, ns, par, top);
+    __syncthreads();
+    if (in_lds) {
+        for (int i = t; i < 2 * ns; i += T) v.kid[i] = w.kid[i];
+        for (int i = t; i < ns; i += T) { v.sp_parent[i] = w.sp_parent[i]; v.sp_side[i] = w.sp_side[i]; }
+    }
+}
+
+__global__ __launch_bounds__(HD_NT) void k_hd_chain(HdView v) {
+    const int r = blockIdx.x * HD_NT + threadIdx.x;
+    const int c = r < v.m ? hd_chain_find(v, r) : -1;
+    if (r < v.m) v.cl_of_edge[r] = c;
+    // most chain nodes belong to the root (the points no cluster holds), and of the root only the chain length is read: one atomic per wave
+    const unsigned long long roots = __ballot(c == 0);
+    if (c == 0) { if ((int)(threadIdx.x & 63) == __ffsll((long long)roots) - 1) atomicAdd(&v.chainlen[0], __popcll(roots)); }
+    else if (c > 0) hd_chain_count(v, r, c);
+}
+
+#define HD_RELAX(COUNT, BODY)                                                              \
+    for (int i = t; i < ncl; i += T) v.done[i] = 0;                                        \
+    __syncthreads();                                                                       \
+    for (;;) {                                                                             \
+        if (t == 0) s_changed = 0;                                                         \
+        __syncthreads();                                                                   \
+        int ch = 0;                                                                        \
+        for (int i = t; i < (COUNT); i += T) ch |= (BODY);                                 \
+        if (ch) s_changed = 1;                                                             \
+        __syncthreads();                                                                   \
+        for (int i = t; i < ncl; i += T) hd_mark_done(v, i);                               \
+        const int again = s_changed;                                                       \
+        __syncthreads();                                                                   \
+        if (!again) break;                                                                 \
+    }
+
+// ONE workgroup: sizes bottom-up, dendrogram depths and preorder top-down, BFS positions
+__global__ __launch_bounds__(1024) void k_hd_tree_b(HdView v, unsigned long long* __restrict__ bfs_key) {
+    const int t = threadIdx.x, T = blockDim.x;
+    const int ns = *v.ns, ncl = 2 * ns + 1;
+    __shared__ int s_changed;
+    HD_RELAX(ns, hd_up_sizes(v, i))
+    HD_RELAX(ns, hd_down_order(v, i))
+    for (int k = t; k < ns; k += T) bfs_key[k] = ((unsigned long long)(unsigned)v.depth[k] << 32) | (unsigned)v.pre[k];
+    __syncthreads();
+    for (int k = t; k < ns; k += T) {                      // BFS position = the splits in front in (depth, preorder) order
+        const unsigned long long mine = bfs_key[k];
+        int cnt = 0;
+        for (int j = 0; j < ns; ++j) cnt += bfs_key[j] < mine ? 1 : 0;
+        v.q[k] = cnt;
+    }
+}
+
+// a wave per cluster (the root's stability is never read): 64 ranks per step from the cluster's creating split down to its terminating
+// one, the chain nodes among them summed in descending rank -- the loads in parallel, the additions in the library's order
+__global__ __launch_bounds__(HD_NT) void k_hd_stability(HdView v) {
+    const int ns = *v.ns, ncl = 2 * ns + 1;
+    const int lane = threadIdx.x & 63, nw = gridDim.x * (HD_NT / 64);
+    for (int c = 1 + (int)((blockIdx.x * HD_NT + threadIdx.x) >> 6); c < ncl; c += nw) {
+        const double birth = hd_birth(v, c);
+        const int r_hi = hd_chain_hi(v, c), r_lo = hd_chain_lo(v, c, ns);
+        double s = 0.0;
+        for (int base = r_hi; base >= r_lo; base -= 64) {
+            const int r = base - lane;                       // lane 0: the highest rank of the step
+            const bool mine = r >= r_lo && v.cl_of_edge[r] == c;
+            double tv = 0.0;
+            int kc = 0;
+            if (mine) { tv = (hd_lambda(v.w2[r]) - birth) * 1.0; kc = v.kcnt[r]; }
+            unsigned long long mask = __ballot(mine);
+            while (mask) {
+                const int j = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                s = hd_stab_terms(s, __shfl(tv, j), __shfl(kc, j));
+            }
+        }
+        if (lane == 0) hd_stability_finish(v, c, ns, s);
+    }
+}
+
+// ONE workgroup: excess of mass bottom-up, the selection, cluster_selection_epsilon, flat labels in the order of the library's ids
+__global__ __launch_bounds__(1024) void k_hd_tree_c(HdView v) {
+    const int t = threadIdx.x, T = blockDim.x;
+    const int ns = *v.ns, ncl = 2 * ns + 1;
+    __shared__ int s_changed;
+    __shared__ int s_part[1024];
+    HD_RELAX(ncl - 1, hd_up_eom(v, i + 1, ns))
+    for (int c = 1 + t; c < ncl; c += T) hd_select_eom(v, c);
+    __syncthreads();
+    const bool use_eps = v.eps != 0.0 && ncl > 1;
+    if (use_eps) {
+        for (int c = 1 + t; c < ncl; c += T) hd_eps_candidates(v, c);
+        __syncthreads();
+        for (int c = 1 + t; c < ncl; c += T) hd_eps_select(v, c);
+        __syncthreads();
+    }
+    for (int c = t; c < ncl; c += T) hd_selected_by_final(v, c, use_eps);
+    __syncthreads();
+    // exclusive scan of sel_by_final[0 .. ncl): a chunk per thread
+    const int per = (ncl + T - 1) / T, b0 = t * per < ncl ? t * per : ncl, b1 = b0 + per < ncl ? b0 + per : ncl;
+    int sum = 0;
+    for (int f = b0; f < b1; ++f) sum += v.sel_by_final[f];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1) {
+        const int add = t >= off ? s_part[t - off] : 0;
+        __syncthreads();
+        s_part[t] += add;
+        __syncthreads();
+    }
+    int run = s_part[t] - sum;
+    for (int f = b0; f < b1; ++f) { const int sf = v.sel_by_final[f]; v.sel_by_final[f] = run; run += sf; }
+    if (t == T - 1) *v.n_clusters = s_part[T - 1];
+    __syncthreads();
+    for (int c = t; c < ncl; c += T) hd_owner(v, c);
+}
+#undef HD_RELAX
+
+__global__ __launch_bounds__(HD_NT) void k_hd_points(HdView v) {
+    const int p = blockIdx.x * HD_NT + threadIdx.x;
+    if (p < v.n) hd_point(v, p);
+}
+__global__ __launch_bounds__(HD_NT) void k_hd_noise(int n, int* __restrict__ labels, double* __restrict__ probs, int* __restrict__ ncl) {
+    const int p = blockIdx.x * HD_NT + threadIdx.x;
+    if (p < n) { labels[p] = -1; probs[p] = 0.0; }
+    if (p == 0 && ncl) *ncl = 0;
+}
+
+template <typename T>
+T* hd_take(char*& p, size_t count) {
+    T* r = (T*)p;
+    p += (count * sizeof(T) + 255) & ~(size_t)255;
+    return r;
+}
+
+VgPerDeviceOnce hd_tree_a_lds;
+
+}  // namespace
+
+extern "C" {
+
+int vg_hier_create(vg_hier** out, int max_points) {
+    if (!out || max_points < 2 || max_points > (1 << HD_RANK_BITS)) return VG_ERR_ARG;
+    vg_hier* h = new vg_hier();
+    h->max_points = max_points;
+    const size_t n = (size_t)max_points, m = n, ncap = n / 2 + 2, ncl = 2 * ncap + 2;       // (min_cluster_size >= 2)
+    // one slab: the first pass sizes it, the second hands the pieces out
+    for (int pass = 0; pass < 2; ++pass) {
+        char* p = pass ? h->slab : (char*)nullptr;
+        HdView& v = h->v;
+        h->lo = hd_take<int>(p, m); h->hi = hd_take<int>(p, m); h->w2 = hd_take<double>(p, m);
+        h->he_key = hd_take<unsigned>(p, 2 * m); h->he_key_s = hd_take<unsigned>(p, 2 * m);
+        h->he_val = hd_take<unsigned long long>(p, 2 * m); h->adj = hd_take<unsigned long long>(p, 2 * m);
+        h->adj_off = hd_take<int>(p, n + 1);
+        h->bfs_key = hd_take<unsigned long long>(p, ncap);
+        v.side = hd_take<unsigned char>(p, 2 * m); v.eflag = hd_take<unsigned char>(p, m);
+        v.kcnt = hd_take<int>(p, m); v.a = hd_take<int>(p, n); v.uf = hd_take<int>(p, n); v.split_pos = hd_take<int>(p, m);
+        v.S = hd_take<int>(p, ncap); v.ns = hd_take<int>(p, 1); v.first = hd_take<unsigned>(p, n);
+        v.node = hd_take<int>(p, 2 * ncap); v.sp_parent = hd_take<int>(p, ncap); v.sp_side = hd_take<int>(p, ncap);
+        v.kid = hd_take<int>(p, 2 * ncap); v.cl_of_edge = hd_take<int>(p, m);
+        v.chainlen = hd_take<int>(p, ncl); v.npts = hd_take<int>(p, ncl); v.death = hd_take<unsigned long long>(p, ncl);
+        v.kw_parent = hd_take<int>(p, 2 * ncap); v.kw_top = hd_take<int>(p, 2 * ncap);
+        v.nsub = hd_take<int>(p, ncap); v.tot = hd_take<int>(p, ncap); v.csize = hd_take<int>(p, ncl);
+        v.depth = hd_take<int>(p, ncap); v.pre = hd_take<int>(p, ncap); v.q = hd_take<int>(p, ncap); v.done = hd_take<int>(p, ncl);
+        v.stab = hd_take<double>(p, ncl); v.stab2 = hd_take<double>(p, ncl);
+        v.wins = hd_take<unsigned char>(p, ncl); v.selected = hd_take<unsigned char>(p, ncl); v.cand = hd_take<unsigned char>(p, ncl);
+        v.sel_by_final = hd_take<int>(p, ncl + 1); v.out_label = hd_take<int>(p, ncl); v.out_death = hd_take<double>(p, ncl);
+        v.n_clusters = hd_take<int>(p, 1);
+        if (!pass) {
+            const size_t bytes = (size_t)(p - (char*)nullptr);
+            if (hipMalloc((void**)&h->slab, bytes) != hipSuccess) { delete h; return VG_ERR_HIP; }
+        }
+    }
+    size_t t3 = 0, t4 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t3, h->he_key, h->he_key_s, h->he_val, h->adj, 2 * m, 0, HD_RANK_BITS);
+    (void)rocprim::exclusive_scan(nullptr, t4, rocprim::make_transform_iterator(h->v.eflag, HdSplitFlag()), h->v.split_pos, 0, m, rocprim::plus<int>());
+    h->temp_bytes = std::max(t3, t4) + 256;
+    if (hipMalloc(&h->d_temp, h->temp_bytes) != hipSuccess) { (void)hipFree(h->slab); delete h; return VG_ERR_HIP; }
+    *out = h;
+    return VG_OK;
+}
+
+int vg_hier_destroy(vg_hier* h) {
+    if (!h) return VG_ERR_ARG;
+    (void)hipFree(h->slab);
+    (void)hipFree(h->d_temp);
+    delete h;
+    return VG_OK;
+}
+
+int vg_hdbscan_tree_device(vg_hier* h, const int32_t* d_lo, const int32_t* d_hi, const double* d_w2, int n, int min_cluster_size, double eps,
+                           int32_t* d_labels, double* d_probs, int32_t* d_n_clusters, void* stream) {
+    if (!h || n < 0 || !d_labels || !d_probs || min_cluster_size < 2 || min_cluster_size > HD_MAX_MCS) return VG_ERR_ARG;
+    if (n > h->max_points) return VG_ERR_CAPACITY;
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= min_cluster_size) {
+        if (n > 0 || d_n_clusters) hipLaunchKernelGGL(k_hd_noise, dim3(vg_div_up(std::max(n, 1), HD_NT)), dim3(HD_NT), 0, st, n, d_labels, d_probs, d_n_clusters);
+        VG_LAUNCH_CHECK();
+        return VG_OK;
+    }
+    if (!d_lo || !d_hi || !d_w2) return VG_ERR_ARG;
+    const int m = n - 1;
+    HdView v = h->v;
+    v.n = n; v.m = m; v.mcs = min_cluster_size; v.ncap = n / min_cluster_size + 2; v.eps = eps;
+    v.lo = h->lo; v.hi = h->hi; v.w2 = h->w2; v.adj_off = h->adj_off; v.adj = h->adj;
+    v.labels = d_labels; v.probs = d_probs;
+    const dim3 B(HD_NT);
+    const int gm = vg_div_up(m, HD_NT), gn = vg_div_up(n, HD_NT), g2m = vg_div_up(2 * m, HD_NT);
+    size_t tb;
+    // ---- the (w2, lo, hi) order; adjacency by ascending rank ----
+    hipLaunchKernelGGL(k_hd_order, dim3(gm), B, 0, st, m, d_lo, d_hi, d_w2, h->lo, h->hi, h->w2, h->he_key, h->he_val);
+    tb = h->temp_bytes;
+    VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->he_key, h->he_key_s, h->he_val, h->adj, (size_t)(2 * m), 0, HD_RANK_BITS, st));
+    hipLaunchKernelGGL(k_hd_offsets, dim3(g2m), B, 0, st, 2 * m, n, h->he_key_s, h->adj_off);
+    hipLaunchKernelGGL(k_hd_init, dim3(vg_div_up(std::max(n, 2 * v.ncap + 1), HD_NT)), B, 0, st, v);
+    // ---- R1, R2 ----
+    const size_t stack_bytes = (size_t)2 * min_cluster_size * HD_NT * sizeof(int);
+    hipLaunchKernelGGL((k_hd_side<false>), dim3(g2m), B, stack_bytes, st, v);
+    hipLaunchKernelGGL((k_hd_side<true>), dim3(g2m), B, stack_bytes, st, v);
+    // ---- R3 ----
+    hipLaunchKernelGGL(k_hd_union, dim3(gm), B, 0, st, v);
+    hipLaunchKernelGGL(k_hd_flatten, dim3(gn), B, 0, st, v);
+    tb = h->temp_bytes;
+    VG_CHECK(rocprim::exclusive_scan(h->d_temp, tb, rocprim::make_transform_iterator(v.eflag, HdSplitFlag()), v.split_pos, 0, (size_t)m,
+                                     rocprim::plus<int>(), st));
+    hipLaunchKernelGGL(k_hd_scatter, dim3(gm), B, 0, st, v);
+    if (vg_max_dynamic_lds((const void*)k_hd_tree_a, HD_TREE_LDS_INTS * 4, hd_tree_a_lds) != VG_OK) return VG_ERR_HIP;
+    hipLaunchKernelGGL(k_hd_tree_a, dim3(1), dim3(1024), HD_TREE_LDS_INTS * 4, st, v);
+    // ---- R4 .. R6 ----
+    hipLaunchKernelGGL(k_hd_chain, dim3(gm), B, 0, st, v);
+    hipLaunchKernelGGL(k_hd_tree_b, dim3(1), dim3(1024), 0, st, v, h->bfs_key);
+    hipLaunchKernelGGL(k_hd_stability, dim3(256), B, 0, st, v);
+    hipLaunchKernelGGL(k_hd_tree_c, dim3(1), dim3(1024), 0, st, v);
+    hipLaunchKernelGGL(k_hd_points, dim3(gn), B, 0, st, v);
+    if (d_n_clusters) VG_CHECK(hipMemcpyAsync(d_n_clusters, v.n_clusters, sizeof(int), hipMemcpyDeviceToDevice, st));
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+}
+
+}  // extern "C"

@@ -4,7 +4,8 @@ min_cluster_size=15, metric='euclidean', core_dist_n_jobs=-1)`; `.fit(X)` then `
 `.probabilities_`, src/vilgod/zero_shot_detector.py:248-250), running on the GPU:
 
     core distances + exact mutual-reachability MST + edge sort   csrc/cluster.hip   (GPU)
-    single linkage / condense / EOM / epsilon / labels           csrc/hdbscan_tree.cpp (host, C++)
+    single linkage / condense / EOM / epsilon / labels           csrc/hdbscan_tree.cpp (host, C++), or -- `hierarchy='device'` --
+                                                                 csrc/hdbscan_device.hip (GPU, the same results bit for bit)
 
 `fit` accepts a numpy array (reference call) or a CUDA float32 tensor (fused pipeline).
 """
@@ -129,3 +130,37 @@ class HDBSCAN:
         self.labels_ = labels.astype(np.int64)
         self.probabilities_ = probs
         return self
+
+
+class DeviceHierarchy:
+    """The hierarchy stage on the device (csrc/hdbscan_device.hip): the tree `HDBSCAN.mst` returns -> labels int32 [n], probabilities
+    float64 [n] (CUDA tensors) and the cluster count, equal bit for bit to `HDBSCAN.tree` on the same tree.  Holds the stage's buffers
+    for trees of up to `max_points` points; one call at a time per object."""
+
+    def __init__(self, max_points=400_000, device='cuda'):
+        self.device = torch.device(device)
+        self.max_points = int(max_points)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.vg_hier_create(ctypes.byref(h), self.max_points), 'vg_hier_create')
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and lib is not None:
+            lib.vg_hier_destroy(h)
+            self._h = None
+
+    def tree_async(self, lo, hi, w2, n, min_cluster_size, eps, stream=None):
+        """-> (labels, probs, n_clusters) CUDA tensors, queued on `stream` (nothing waited for)."""
+        dev = self.device
+        labels = torch.empty(n, dtype=torch.int32, device=dev)
+        probs = torch.empty(n, dtype=torch.float64, device=dev)
+        nc = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.vg_hdbscan_tree_device(self._h, ptr(lo), ptr(hi), ptr(w2), int(n), int(min_cluster_size), float(eps), ptr(labels), ptr(probs),
+                                         ptr(nc), stream_ptr(stream)), 'vg_hdbscan_tree_device')
+        return labels, probs, nc
+
+    def tree(self, lo, hi, w2, n, min_cluster_size, eps, stream=None):
+        labels, probs, nc = self.tree_async(lo, hi, w2, n, min_cluster_size, eps, stream)
+        return labels, probs, int(nc.item())

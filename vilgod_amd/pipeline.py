@@ -25,7 +25,7 @@ from scipy.spatial.transform import Rotation
 from ._lib import lib, ptr, stream_ptr, check
 from .frame_state import FrameState, pack_clusters, vote, static_from_entropy
 from . import patchworkpp as gpw
-from .hdbscan import HDBSCAN
+from .hdbscan import HDBSCAN, DeviceHierarchy
 from .projection import RealisticProjection, VIEWS_4, VIEWS_6
 from .clip_wrapper import ClipWrapper
 
@@ -64,7 +64,8 @@ def _get(cfg, key, default=None):
 class PseudoLabelPipeline:
     def __init__(self, preprocessor_cfg=None, device='cuda:0', vit_dtype='f16', n_views=4, max_points=300_000,
                  clip_model_path='../models/clip/', min_range=1.5, z_offset=1.723, plane_seed=666, clip=None,
-                 box_mode='reference', box_workers=4, vit_graph=False, angle_mode='reference', cu_reserve=None, cu_tower=None):
+                 box_mode='reference', box_workers=4, vit_graph=False, angle_mode='reference', cu_reserve=None, cu_tower=None,
+                 hierarchy=None):
         cfg = preprocessor_cfg if preprocessor_cfg is not None else default_preprocessor_cfg()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -79,6 +80,13 @@ class PseudoLabelPipeline:
         mcfg = dict(_get(ccfg, 'model'))
         mcfg.pop('_target_', None)
         self.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **mcfg)
+        # hierarchy stage: 'host' (csrc/hdbscan_tree.cpp in the frame's thread, beside the other frames' GPU work) or 'device'
+        # (csrc/hdbscan_device.hip: no copy of the tree, no host stage -- the same labels and probabilities bit for bit; 2 ms less
+        # frame latency, a dozen small kernels more per frame: LAB_NOTES.md section 0)
+        self.hierarchy = str(os.environ.get('VILGOD_HIERARCHY', 'host') if hierarchy is None else hierarchy)
+        if self.hierarchy not in ('host', 'device'):
+            raise ValueError("hierarchy: 'host' or 'device'")
+        self._hier = DeviceHierarchy(max_points=self.max_points, device=self.device) if self.hierarchy == 'device' else None
         self.prob_threshold = float(_get(ccfg, 'propability_threshold', 0.3))
         self._filters = self._parse_filters(ccfg)
         self.angle_mode = angle_mode             # view direction angle: 'device' | 'reference' (this host's numpy; projection.py)
@@ -134,6 +142,7 @@ class PseudoLabelPipeline:
         import copy
         w = copy.copy(self)
         w.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **self._mcfg)
+        w._hier = DeviceHierarchy(max_points=self.max_points, device=self.device) if self.hierarchy == 'device' else None
         w.projection = RealisticProjection(_get(self.cfg, 'lidar_image_projection'), device=self.device,
                                            views=VIEWS_4 if self._n_views == 4 else VIEWS_6, angle_mode=self.angle_mode)
         w.clip = self.clip.view()                # shared read-only weights, own workspace
@@ -393,6 +402,13 @@ class PseudoLabelPipeline:
             return np.full(n, -1, np.int64), np.zeros(n)
         lo, hi, w2 = self.cluster_model.mst(d_X)
         self._mark('mst_kernels')
+        if self._hier is not None:
+            m = self.cluster_model
+            d_labels, d_probs, _ = self._hier.tree_async(lo, hi, w2, n, m.min_cluster_size, m.cluster_selection_epsilon)
+            self._mark('hierarchy_device')
+            labels, probs = d_labels.cpu().numpy(), d_probs.cpu().numpy()
+            self._mark('labels_d2h')
+            return labels, probs
         h_lo, h_hi, h_w2 = lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy()
         self._mark('mst_d2h')
         labels, probs, _ = self.cluster_model.tree(h_lo, h_hi, h_w2, n)
