@@ -39,17 +39,18 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
     const int ncap = n / mcs + 2, ncl_cap = 2 * ncap + 1;
     std::vector<unsigned char> side(2 * (size_t)m), eflag(m), wins(ncl_cap), selected(ncl_cap), cand(ncl_cap);
     std::vector<int> kcnt(m), a(n, -1), uf(n), split_pos(m), S(ncap), nsv(1, 0), node(2 * ncap), sp_parent(ncap), sp_side(ncap), kid(2 * ncap),
-        cl_of_edge(m, 0), chainlen(ncl_cap, 0), npts(ncl_cap, 0), kw_parent(2 * ncap), kw_top(2 * ncap), nsub(ncap), tot(ncap), csize(ncl_cap),
+        chainlen(ncl_cap, 0), npts(ncl_cap, 0), kw_parent(2 * ncap), kw_top(2 * ncap), nsub(ncap), tot(ncap), csize(ncl_cap),
         depth(ncap), pre(ncap), q(ncap), done(ncl_cap), sel_by_final(ncl_cap + 1), out_label(ncl_cap), ncl_out(1, 0);
     std::vector<unsigned> first(n);
-    std::vector<unsigned long long> death(ncl_cap, 0);
-    std::vector<double> stab(ncl_cap), stab2(ncl_cap), out_death(ncl_cap);
+    std::vector<double> death(ncl_cap, 0.0);
+    std::vector<double> stab(ncl_cap), stab2(ncl_cap), out_death(ncl_cap), lam_split(ncap);
+    std::vector<HdChainRec> crec(m);
     HdView v{};
     v.n = n; v.m = m; v.mcs = mcs; v.ncap = ncap; v.eps = eps;
     v.lo = lo.data(); v.hi = hi.data(); v.w2 = w2.data(); v.adj_off = adj_off.data(); v.adj = adj.data();
     v.side = side.data(); v.eflag = eflag.data(); v.kcnt = kcnt.data(); v.a = a.data(); v.uf = uf.data(); v.split_pos = split_pos.data();
     v.S = S.data(); v.ns = nsv.data(); v.first = first.data(); v.node = node.data(); v.sp_parent = sp_parent.data(); v.sp_side = sp_side.data();
-    v.kid = kid.data(); v.cl_of_edge = cl_of_edge.data(); v.chainlen = chainlen.data(); v.npts = npts.data(); v.death = death.data();
+    v.kid = kid.data(); v.crec = crec.data(); v.lam_split = lam_split.data(); v.chainlen = chainlen.data(); v.npts = npts.data(); v.death = death.data();
     v.kw_parent = kw_parent.data(); v.kw_top = kw_top.data(); v.nsub = nsub.data(); v.tot = tot.data();
     v.csize = csize.data(); v.depth = depth.data(); v.pre = pre.data(); v.q = q.data(); v.done = done.data(); v.stab = stab.data();
     v.stab2 = stab2.data(); v.wins = wins.data(); v.selected = selected.data(); v.cand = cand.data(); v.sel_by_final = sel_by_final.data();
@@ -68,40 +69,38 @@ extern "C" int hd_emul_tree(const int32_t* lo_in, const int32_t* hi_in, const do
     if (n_splits) *n_splits = ns;
     for (int i = 0; i < 2 * ns; ++i) hd_split_nodes(v, i);
     hd_kruskal_splits(v, ns, kw_parent.data(), kw_top.data());
-    for (int r = 0; r < m; ++r) {
-        const int c = hd_chain_find(v, r);
-        cl_of_edge[r] = c;
-        if (c >= 0) hd_chain_count(v, r, c);
-    }
     const int ncl = 2 * ns + 1;
+    std::vector<unsigned> ckey(m), crank(m);
+    for (int r = 0; r < m; ++r) {
+        crec[r] = hd_chain_rec(v, r, hd_chain_find(v, r));
+        if (crec[r].c == 0) chainlen[0]++;
+        ckey[r] = hd_chain_sortkey(crec[r]); crank[r] = (unsigned)r;
+    }
+    std::stable_sort(crank.begin(), crank.end(), [&](unsigned x, unsigned y) { return ckey[x] < ckey[y]; });
+    {
+        std::vector<unsigned> ks(m);
+        for (int i = 0; i < m; ++i) ks[i] = ckey[crank[i]];
+        ckey.swap(ks);
+    }
+    v.chain_key = ckey.data(); v.chain_rank = crank.data();
+    for (int c = 1; c < ncl; ++c) hd_chain_stats(v, c);
     int total_sweeps = 0;
-    auto relax = [&](int count, auto&& body) {
-        while (true) {
+    auto relax = [&](auto&& body) {
+        std::fill(done.begin(), done.end(), 0);
+        for (int sweep = 0;; ++sweep) {
             int changed = 0;
-            for (int i = 0; i < count; ++i) changed |= body(i);
-            for (int i = 0; i < ncl; ++i) hd_mark_done(v, i);
+            for (int k = 0; k < ns; ++k) changed |= body(k, sweep);
             ++total_sweeps;
             if (!changed) break;
         }
     };
-    std::fill(done.begin(), done.end(), 0);
-    relax(ns, [&](int k) { return hd_up_sizes(v, k); });
-    std::fill(done.begin(), done.end(), 0);
-    relax(ns, [&](int k) { return hd_down_order(v, k); });
+    relax([&](int k, int sweep) { return hd_up_all(v, k, sweep); });
+    relax([&](int k, int sweep) { return hd_down_order(v, k, sweep); });
     for (int k = 0; k < ns; ++k) {
         int cnt = 0;
         for (int j = 0; j < ns; ++j) cnt += hd_bfs_before(depth[j], pre[j], depth[k], pre[k]) ? 1 : 0;
         q[k] = cnt;
     }
-    for (int c = 1; c < ncl; ++c) {
-        const double birth = hd_birth(v, c);
-        double sum = 0.0;
-        for (int r = hd_chain_hi(v, c), r0 = hd_chain_lo(v, c, ns); r >= r0; --r)
-            if (cl_of_edge[r] == c) sum = hd_stab_terms(sum, (hd_lambda(w2[r]) - birth) * 1.0, kcnt[r]);
-        hd_stability_finish(v, c, ns, sum);
-    }
-    std::fill(done.begin(), done.end(), 0);
-    relax(ncl - 1, [&](int i) { return hd_up_eom(v, i + 1, ns); });
     for (int c = 1; c < ncl; ++c) hd_select_eom(v, c);
     const bool use_eps = eps != 0.0 && ncl > 1;
     if (use_eps) {

@@ -36,6 +36,11 @@ int vg_gemm_ln_consumer(int epi, const void* d_X, const void* d_Wt, const float*
 int vg_attention_trace(const void* d_qkv, void* d_out, int n_crops, int T, int W, int heads, int ld, int64_t* d_trace, void* stream);
 
 
+/* hierarchy stage on the device: 100 MHz time stamps of the last call's one-workgroup kernels (csrc/hdbscan_device.hip HD_STAMP):
+ * [0..2] k_hd_tree_a start / nodes staged / Kruskal done; [4..13] k_hd_tree_bc start, staged, up sweeps, down sweeps, BFS numbering,
+ * selection, epsilon, scan, owners, end */
+int vg_hier_stamps(void* h, int64_t* h_out16);
+
 #ifdef __cplusplus
 }
 #endif

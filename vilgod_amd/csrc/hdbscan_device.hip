@@ -15,12 +15,13 @@
 //   k_hd_union / k_hd_flatten          lock-free union-find over the non-split edges: segments                             (R3)
 //   scan + k_hd_scatter                the split edges, a few hundred, in rank order
 //   k_hd_tree_a                        ONE lane, union-find in LDS: Kruskal over the splits on the segments = the cluster tree
-//   k_hd_chain                         every chain node's cluster: a walk up the cluster tree                              (R4)
-//   k_hd_tree_b                        ONE workgroup: cluster sizes, dendrogram depths, the library's BFS numbering        (R5)
-//   k_hd_stability                     a wave per cluster: its chain by descending rank, summed in the library's order     (R6)
-//   k_hd_tree_c                        ONE workgroup: excess of mass, epsilon, flat labels
+//   k_hd_chain + radix sort            every chain node's cluster (a walk up the cluster tree); the chains grouped by cluster  (R4)
+//   k_hd_chain_stats                   a wave per cluster: its chain by descending rank, summed in the library's order     (R6)
+//   k_hd_tree_bc                       ONE workgroup: cluster sizes, the stabilities' last rows, excess of mass; dendrogram depths and
+//                                      the library's BFS numbering (R5); epsilon; flat labels
+// The cluster tree's arrays (a few hundred splits) are staged in LDS by every kernel that sweeps or walks the tree (HdCarve).
 //   k_hd_points                        label and probability of every point
-// The one-workgroup kernels sweep the cluster tree level by level (as many sweeps as it is high).  float64 throughout; compiled with
+// The one-workgroup kernel sweeps the cluster tree level by level (as many sweeps, one barrier each, as it is high).  float64 throughout; compiled with
 // -ffp-contract=off (the stability sums are the host stage's expressions, unfused).
 #include <string.h>
 #include <algorithm>
@@ -45,6 +46,8 @@ struct vg_hier {
     unsigned long long *he_val, *adj;
     int* adj_off;
     unsigned long long* bfs_key;
+    long long* stamps;              // development build: 100 MHz time stamps of the one-workgroup kernels' phases (NULL in the product)
+    unsigned *ckey, *ckey_s, *crank, *crank_s;   // chain nodes: sort key (cluster), rank
     HdView v;                      // the arrays of the stage (n, m, mcs, eps, inputs filled per call)
 };
 
@@ -76,8 +79,7 @@ __global__ __launch_bounds__(HD_NT) void k_hd_offsets(int n2, int n, const unsig
 __global__ __launch_bounds__(HD_NT) void k_hd_init(HdView v) {
     const int i = blockIdx.x * HD_NT + threadIdx.x;
     if (i < v.n) v.uf[i] = i;
-    if (i < 2 * v.ncap + 1) { v.chainlen[i] = 0; v.npts[i] = 0; v.death[i] = 0ull; }
-    if (i == 0) { *v.ns = 0; *v.n_clusters = 0; }
+    if (i == 0) { *v.ns = 0; *v.n_clusters = 0; v.chainlen[0] = 0; }
 }
 
 template <bool ASSIGN>
@@ -104,13 +106,15 @@ __global__ __launch_bounds__(HD_NT) void k_hd_scatter(HdView v) {
     if (r < v.m) hd_split_scatter(v, r);
 }
 
-// ONE workgroup: the union-find nodes of the splits' endpoints, then Kruskal over the splits by ONE lane -- every array it touches in
-// LDS (a dependent global-memory access per step would cost a microsecond each), written out afterwards
-__global__ __launch_bounds__(1024) void k_hd_tree_a(HdView v) {
+// ONE workgroup: the union-find nodes of the splits' endpoints, then Kruskal over the splits -- every array it touches in LDS (a
+// dependent global-memory access per step would cost a microsecond each), written out afterwards
+__global__ __launch_bounds__(1024) void k_hd_tree_a(HdView v, long long* __restrict__ stamps) {
     extern __shared__ int lds[];
     const int t = threadIdx.x, T = blockDim.x;
     const int ns = *v.ns;
     if (ns == 0) return;
+#define HD_STAMP(I) if (stamps && t == 0) stamps[I] = (long long)wall_clock64();
+    HD_STAMP(0)
     HdView w = v;
     int *par = v.kw_parent, *top = v.kw_top;
     const bool in_lds = 10 * ns <= HD_TREE_LDS_INTS;
@@ -119,92 +123,172 @@ __global__ __launch_bounds__(1024) void k_hd_tree_a(HdView v) {
     }
     for (int i = t; i < 2 * ns; i += T) hd_split_nodes(w, i);
     __syncthreads();
+    HD_STAMP(1)
+    // (ONE lane.  Measured and dropped, round 6: the same steps run wave-uniformly by 64 lanes -- node pairs of 64 splits prefetched into
+    // registers, union by size -- took 312 us instead of 265 for 682 splits: the scalarising readfirstlanes cost more than the loads saved)
     if (t == 0) hd_kruskal_splits(w, ns, par, top);
     __syncthreads();
+    HD_STAMP(2)
     if (in_lds) {
         for (int i = t; i < 2 * ns; i += T) v.kid[i] = w.kid[i];
         for (int i = t; i < ns; i += T) { v.sp_parent[i] = w.sp_parent[i]; v.sp_side[i] = w.sp_side[i]; }
     }
 }
 
-__global__ __launch_bounds__(HD_NT) void k_hd_chain(HdView v) {
-    const int r = blockIdx.x * HD_NT + threadIdx.x;
-    const int c = r < v.m ? hd_chain_find(v, r) : -1;
-    if (r < v.m) v.cl_of_edge[r] = c;
-    // most chain nodes belong to the root (the points no cluster holds), and of the root only the chain length is read: one atomic per wave
-    const unsigned long long roots = __ballot(c == 0);
-    if (c == 0) { if ((int)(threadIdx.x & 63) == __ffsll((long long)roots) - 1) atomicAdd(&v.chainlen[0], __popcll(roots)); }
-    else if (c > 0) hd_chain_count(v, r, c);
+// LDS staging of the cluster tree's small arrays (a few hundred splits): the sweeps and walks over the tree are chains of dependent
+// accesses -- ~100 ns each in LDS, a microsecond each in global memory.  A kernel carves its pieces out of its dynamic LDS, copies the
+// inputs in, points a local HdView at them (the bodies of hdbscan_device.inc do not care where an array lives) and copies results out.
+struct HdCarve {
+    int* base;
+    int used;
+};
+template <typename T>
+__device__ __forceinline__ T* hd_carve(HdCarve& cv, const T* g, int count, bool copy_in) {
+    cv.used = (cv.used + 1) & ~1;                                  // 8-byte alignment
+    T* p = (T*)(cv.base + cv.used);
+    cv.used += (int)(((size_t)count * sizeof(T) + 3) / 4);
+    if (copy_in) for (int i = threadIdx.x; i < count; i += blockDim.x) p[i] = g[i];
+    return p;
+}
+template <typename T>
+__device__ __forceinline__ void hd_copy_out(T* g, const T* l, int count) {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) g[i] = l[i];
 }
 
-#define HD_RELAX(COUNT, BODY)                                                              \
-    for (int i = t; i < ncl; i += T) v.done[i] = 0;                                        \
-    __syncthreads();                                                                       \
-    for (;;) {                                                                             \
-        if (t == 0) s_changed = 0;                                                         \
-        __syncthreads();                                                                   \
-        int ch = 0;                                                                        \
-        for (int i = t; i < (COUNT); i += T) ch |= (BODY);                                 \
-        if (ch) s_changed = 1;                                                             \
-        __syncthreads();                                                                   \
-        for (int i = t; i < ncl; i += T) hd_mark_done(v, i);                               \
-        const int again = s_changed;                                                       \
-        __syncthreads();                                                                   \
-        if (!again) break;                                                                 \
+#define HD_CHAIN_LDS_INTS 12288     // k_hd_chain: S, sp_parent, sp_side of up to 4096 splits per workgroup (48 KB)
+__global__ __launch_bounds__(HD_NT) void k_hd_chain(HdView v, unsigned* __restrict__ ckey, unsigned* __restrict__ crank) {
+    extern __shared__ int lds[];
+    const int ns = *v.ns;
+    HdView w = v;
+    if (3 * ns <= HD_CHAIN_LDS_INTS) {                             // the walk up the cluster tree: its three arrays in LDS
+        HdCarve cv{lds, 0};
+        w.S = hd_carve(cv, v.S, ns, true); w.sp_parent = hd_carve(cv, v.sp_parent, ns, true); w.sp_side = hd_carve(cv, v.sp_side, ns, true);
+        __syncthreads();
     }
+    const int r = blockIdx.x * HD_NT + threadIdx.x;
+    const int c = r < v.m ? hd_chain_find(w, r) : -1;
+    if (r < v.m) {
+        const HdChainRec rec = hd_chain_rec(v, r, c);
+        v.crec[r] = rec;
+        ckey[r] = hd_chain_sortkey(rec); crank[r] = (unsigned)r;
+    }
+    // of the root (the points no cluster holds: most chain nodes) only the chain length is read: one atomic per wave
+    const unsigned long long roots = __ballot(c == 0);
+    if (c == 0 && (int)(threadIdx.x & 63) == __ffsll((long long)roots) - 1) atomicAdd(&v.chainlen[0], __popcll(roots));
+}
 
-// ONE workgroup: sizes bottom-up, dendrogram depths and preorder top-down, BFS positions
-__global__ __launch_bounds__(1024) void k_hd_tree_b(HdView v, unsigned long long* __restrict__ bfs_key) {
-    const int t = threadIdx.x, T = blockDim.x;
+// a wave per cluster over its run of the sorted chain nodes: chain length, points, largest lambda, and the rows of its own chain summed
+// in the library's order (descending rank)
+__global__ __launch_bounds__(HD_NT) void k_hd_chain_stats(HdView v) {
     const int ns = *v.ns, ncl = 2 * ns + 1;
-    __shared__ int s_changed;
-    HD_RELAX(ns, hd_up_sizes(v, i))
-    HD_RELAX(ns, hd_down_order(v, i))
+    const int lane = threadIdx.x & 63, nw = gridDim.x * (HD_NT / 64);
+    for (int c = 1 + (int)((blockIdx.x * HD_NT + threadIdx.x) >> 6); c < ncl; c += nw) {
+        const int b = hd_lower_bound_u32(v.chain_key, v.m, (unsigned)c), e = hd_lower_bound_u32(v.chain_key, v.m, (unsigned)c + 1u);
+        const double birth = hd_birth(v, c);
+        double s = 0.0;
+        int np = 0;
+        // 64 records per step, the next step's records requested before this step's additions; the additions strictly in order, one
+        // chain node after the other out of the lanes (v_readlane with a constant lane: no loop counter, no LDS round trip per node)
+        auto fetch = [&](int top) {
+            const int i = top - lane;                              // lane 0: the highest rank of the step
+            return i >= b ? v.crec[v.chain_rank[i]] : HdChainRec{-1, 0, 0.0};
+        };
+        HdChainRec nxt = fetch(e - 1);
+        for (int top = e - 1; top >= b; top -= 64) {
+            const HdChainRec rec = nxt;
+            nxt = fetch(top - 64);
+            const int cnt = min(64, top - b + 1);
+            const double tv = (rec.lam - birth) * 1.0;
+            const int tlo = __double2loint(tv), thi = __double2hiint(tv);
+            np += rec.kc;
+            if (cnt == 64 && __ballot(rec.kc != 1) == 0ull) {      // the common step: 64 nodes of one point each -- 64 additions, no branch
+#pragma unroll
+                for (int j = 0; j < 64; ++j) s += __hiloint2double(__builtin_amdgcn_readlane(thi, j), __builtin_amdgcn_readlane(tlo, j));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    if (j < cnt) {
+                        const double tt = __hiloint2double(__builtin_amdgcn_readlane(thi, j), __builtin_amdgcn_readlane(tlo, j));
+                        const int kk = __builtin_amdgcn_readlane(rec.kc, j);
+                        if (kk == 1) s += tt;
+                        else s = hd_stab_terms(s, tt, kk);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) np += __shfl_xor(np, off);
+        if (lane == 0) {
+            v.chainlen[c] = e - b; v.npts[c] = np; v.stab[c] = s;
+            v.death[c] = e > b ? v.crec[v.chain_rank[b]].lam : 0.0;
+        }
+    }
+}
+
+// ONE workgroup over the cluster tree, its arrays in LDS: bottom-up (sizes, the stabilities' last rows, excess of mass), top-down (dendrogram
+// depths, preorder), the library's BFS numbering, the selection, cluster_selection_epsilon, flat labels.  A sweep = one barrier.
+#define HD_SWEEPS(BODY)                                                                    \
+    for (int i = t; i < ns; i += T) v.done[i] = 0;                                         \
+    if (t == 0) s_flag[0] = 0;                                                             \
+    __syncthreads();                                                                       \
+    for (int sweep = 0;; ++sweep) {                                                        \
+        if (t == 0) s_flag[(sweep + 1) % 3] = 0;                                           \
+        int ch = 0;                                                                        \
+        for (int i = t; i < ns; i += T) ch |= (BODY);                                      \
+        if (ch) s_flag[sweep % 3] = 1;                                                     \
+        __syncthreads();                                                                   \
+        if (!s_flag[sweep % 3]) break;                                                     \
+    }
+#define HD_TREE_BC_LDS_INTS 38912      // 152 KB of dynamic LDS (+ the scan's 4 KB): up to ~1100 splits, else global memory
+__global__ __launch_bounds__(512) void k_hd_tree_bc(HdView gv, unsigned long long* __restrict__ g_bfs_key, long long* __restrict__ stamps) {
+    extern __shared__ int lds[];
+    const int t = threadIdx.x, T = blockDim.x;
+    const int ns = *gv.ns, ncl = 2 * ns + 1;
+    __shared__ int s_flag[3];
+    __shared__ int s_part[512];
+    HdView v = gv;
+    unsigned long long* bfs_key = g_bfs_key;
+    HD_STAMP(4)
+    if (stamps && t == 0) stamps[14] = clock64();
+    const bool in_lds = 12 * ns + 11 * ncl + 64 <= HD_TREE_BC_LDS_INTS;
+    if (in_lds) {
+        HdCarve cv{lds, 0};
+        v.kid = hd_carve(cv, gv.kid, 2 * ns, true); v.sp_parent = hd_carve(cv, gv.sp_parent, ns, true); v.sp_side = hd_carve(cv, gv.sp_side, ns, true);
+        v.lam_split = hd_carve(cv, gv.lam_split, ns, true);
+        v.tot = hd_carve(cv, gv.tot, ns, false); v.nsub = hd_carve(cv, gv.nsub, ns, false); v.depth = hd_carve(cv, gv.depth, ns, false);
+        v.pre = hd_carve(cv, gv.pre, ns, false); v.done = hd_carve(cv, gv.done, ns, false); v.q = hd_carve(cv, gv.q, ns, false);
+        v.npts = hd_carve(cv, gv.npts, ncl, true); v.chainlen = hd_carve(cv, gv.chainlen, ncl, true);
+        v.csize = hd_carve(cv, gv.csize, ncl, false); v.stab = hd_carve(cv, gv.stab, ncl, true); v.stab2 = hd_carve(cv, gv.stab2, ncl, false);
+        v.death = hd_carve(cv, gv.death, ncl, true); v.sel_by_final = hd_carve(cv, gv.sel_by_final, ncl + 1, false);
+        v.wins = hd_carve(cv, gv.wins, ncl, false); v.selected = hd_carve(cv, gv.selected, ncl, false); v.cand = hd_carve(cv, gv.cand, ncl, false);
+        // (free once the bottom-up sweeps are over: stab2 -> the BFS keys, stab -> out_death, csize -> out_label)
+        bfs_key = (unsigned long long*)v.stab2; v.out_death = v.stab; v.out_label = v.csize;
+        __syncthreads();
+    }
+    HD_STAMP(5)
+    HD_SWEEPS(hd_up_all(v, i, sweep))
+    HD_STAMP(6)
+    HD_SWEEPS(hd_down_order(v, i, sweep))
+    HD_STAMP(7)
     for (int k = t; k < ns; k += T) bfs_key[k] = ((unsigned long long)(unsigned)v.depth[k] << 32) | (unsigned)v.pre[k];
     __syncthreads();
     for (int k = t; k < ns; k += T) {                      // BFS position = the splits in front in (depth, preorder) order
         const unsigned long long mine = bfs_key[k];
-        int cnt = 0;
-        for (int j = 0; j < ns; ++j) cnt += bfs_key[j] < mine ? 1 : 0;
+        int cnt = 0, j = 0;
+        for (; j + 32 <= ns; j += 32) {                    // (32 independent LDS reads per step: one at a time they cost a round trip each)
+            unsigned long long kk[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) kk[u] = bfs_key[j + u];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) cnt += kk[u] < mine ? 1 : 0;
+        }
+        for (; j < ns; ++j) cnt += bfs_key[j] < mine ? 1 : 0;
         v.q[k] = cnt;
     }
-}
-
-// a wave per cluster (the root's stability is never read): 64 ranks per step from the cluster's creating split down to its terminating
-// one, the chain nodes among them summed in descending rank -- the loads in parallel, the additions in the library's order
-__global__ __launch_bounds__(HD_NT) void k_hd_stability(HdView v) {
-    const int ns = *v.ns, ncl = 2 * ns + 1;
-    const int lane = threadIdx.x & 63, nw = gridDim.x * (HD_NT / 64);
-    for (int c = 1 + (int)((blockIdx.x * HD_NT + threadIdx.x) >> 6); c < ncl; c += nw) {
-        const double birth = hd_birth(v, c);
-        const int r_hi = hd_chain_hi(v, c), r_lo = hd_chain_lo(v, c, ns);
-        double s = 0.0;
-        for (int base = r_hi; base >= r_lo; base -= 64) {
-            const int r = base - lane;                       // lane 0: the highest rank of the step
-            const bool mine = r >= r_lo && v.cl_of_edge[r] == c;
-            double tv = 0.0;
-            int kc = 0;
-            if (mine) { tv = (hd_lambda(v.w2[r]) - birth) * 1.0; kc = v.kcnt[r]; }
-            unsigned long long mask = __ballot(mine);
-            while (mask) {
-                const int j = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                s = hd_stab_terms(s, __shfl(tv, j), __shfl(kc, j));
-            }
-        }
-        if (lane == 0) hd_stability_finish(v, c, ns, s);
-    }
-}
-
-// ONE workgroup: excess of mass bottom-up, the selection, cluster_selection_epsilon, flat labels in the order of the library's ids
-__global__ __launch_bounds__(1024) void k_hd_tree_c(HdView v) {
-    const int t = threadIdx.x, T = blockDim.x;
-    const int ns = *v.ns, ncl = 2 * ns + 1;
-    __shared__ int s_changed;
-    __shared__ int s_part[1024];
-    HD_RELAX(ncl - 1, hd_up_eom(v, i + 1, ns))
+    HD_STAMP(8)
     for (int c = 1 + t; c < ncl; c += T) hd_select_eom(v, c);
     __syncthreads();
+    HD_STAMP(9)
     const bool use_eps = v.eps != 0.0 && ncl > 1;
     if (use_eps) {
         for (int c = 1 + t; c < ncl; c += T) hd_eps_candidates(v, c);
@@ -212,6 +296,7 @@ __global__ __launch_bounds__(1024) void k_hd_tree_c(HdView v) {
         for (int c = 1 + t; c < ncl; c += T) hd_eps_select(v, c);
         __syncthreads();
     }
+    HD_STAMP(10)
     for (int c = t; c < ncl; c += T) hd_selected_by_final(v, c, use_eps);
     __syncthreads();
     // exclusive scan of sel_by_final[0 .. ncl): a chunk per thread
@@ -228,11 +313,21 @@ __global__ __launch_bounds__(1024) void k_hd_tree_c(HdView v) {
     }
     int run = s_part[t] - sum;
     for (int f = b0; f < b1; ++f) { const int sf = v.sel_by_final[f]; v.sel_by_final[f] = run; run += sf; }
-    if (t == T - 1) *v.n_clusters = s_part[T - 1];
+    if (t == T - 1) *gv.n_clusters = s_part[T - 1];
     __syncthreads();
+    HD_STAMP(11)
     for (int c = t; c < ncl; c += T) hd_owner(v, c);
+    if (in_lds) {
+        __syncthreads();
+        HD_STAMP(12)
+        hd_copy_out(gv.out_label, v.out_label, ncl); hd_copy_out(gv.out_death, v.out_death, ncl);
+    }
+    __syncthreads();
+    HD_STAMP(13)
+    if (stamps && t == 0) stamps[15] = clock64();
 }
-#undef HD_RELAX
+#undef HD_SWEEPS
+#undef HD_STAMP
 
 __global__ __launch_bounds__(HD_NT) void k_hd_points(HdView v) {
     const int p = blockIdx.x * HD_NT + threadIdx.x;
@@ -251,7 +346,7 @@ T* hd_take(char*& p, size_t count) {
     return r;
 }
 
-VgPerDeviceOnce hd_tree_a_lds;
+VgPerDeviceOnce hd_tree_a_lds, hd_tree_bc_lds;
 
 }  // namespace
 
@@ -271,12 +366,13 @@ int vg_hier_create(vg_hier** out, int max_points) {
         h->he_val = hd_take<unsigned long long>(p, 2 * m); h->adj = hd_take<unsigned long long>(p, 2 * m);
         h->adj_off = hd_take<int>(p, n + 1);
         h->bfs_key = hd_take<unsigned long long>(p, ncap);
+        h->ckey = hd_take<unsigned>(p, m); h->ckey_s = hd_take<unsigned>(p, m); h->crank = hd_take<unsigned>(p, m); h->crank_s = hd_take<unsigned>(p, m);
         v.side = hd_take<unsigned char>(p, 2 * m); v.eflag = hd_take<unsigned char>(p, m);
         v.kcnt = hd_take<int>(p, m); v.a = hd_take<int>(p, n); v.uf = hd_take<int>(p, n); v.split_pos = hd_take<int>(p, m);
         v.S = hd_take<int>(p, ncap); v.ns = hd_take<int>(p, 1); v.first = hd_take<unsigned>(p, n);
         v.node = hd_take<int>(p, 2 * ncap); v.sp_parent = hd_take<int>(p, ncap); v.sp_side = hd_take<int>(p, ncap);
-        v.kid = hd_take<int>(p, 2 * ncap); v.cl_of_edge = hd_take<int>(p, m);
-        v.chainlen = hd_take<int>(p, ncl); v.npts = hd_take<int>(p, ncl); v.death = hd_take<unsigned long long>(p, ncl);
+        v.kid = hd_take<int>(p, 2 * ncap); v.crec = hd_take<HdChainRec>(p, m); v.lam_split = hd_take<double>(p, ncap);
+        v.chainlen = hd_take<int>(p, ncl); v.npts = hd_take<int>(p, ncl); v.death = hd_take<double>(p, ncl);
         v.kw_parent = hd_take<int>(p, 2 * ncap); v.kw_top = hd_take<int>(p, 2 * ncap);
         v.nsub = hd_take<int>(p, ncap); v.tot = hd_take<int>(p, ncap); v.csize = hd_take<int>(p, ncl);
         v.depth = hd_take<int>(p, ncap); v.pre = hd_take<int>(p, ncap); v.q = hd_take<int>(p, ncap); v.done = hd_take<int>(p, ncl);
@@ -289,17 +385,32 @@ int vg_hier_create(vg_hier** out, int max_points) {
             if (hipMalloc((void**)&h->slab, bytes) != hipSuccess) { delete h; return VG_ERR_HIP; }
         }
     }
-    size_t t3 = 0, t4 = 0;
+    size_t t3 = 0, t4 = 0, t5 = 0;
     (void)rocprim::radix_sort_pairs(nullptr, t3, h->he_key, h->he_key_s, h->he_val, h->adj, 2 * m, 0, HD_RANK_BITS);
     (void)rocprim::exclusive_scan(nullptr, t4, rocprim::make_transform_iterator(h->v.eflag, HdSplitFlag()), h->v.split_pos, 0, m, rocprim::plus<int>());
-    h->temp_bytes = std::max(t3, t4) + 256;
+    (void)rocprim::radix_sort_pairs(nullptr, t5, h->ckey, h->ckey_s, h->crank, h->crank_s, m, 0, HD_CHAIN_KEY_BITS);
+    h->temp_bytes = std::max(std::max(t3, t4), t5) + 256;
     if (hipMalloc(&h->d_temp, h->temp_bytes) != hipSuccess) { (void)hipFree(h->slab); delete h; return VG_ERR_HIP; }
+    h->stamps = nullptr;
+#ifdef VG_DEV
+    if (hipMalloc((void**)&h->stamps, 16 * sizeof(long long)) != hipSuccess) h->stamps = nullptr;
+#endif
     *out = h;
     return VG_OK;
 }
 
+#ifdef VG_DEV
+/* development aid (tools/dev/vilgod_hip_dev.h): the phase stamps of the last call's one-workgroup kernels, 100 MHz ticks */
+int vg_hier_stamps(vg_hier* h, int64_t* h_out16) {
+    if (!h || !h->stamps || !h_out16) return VG_ERR_ARG;
+    VG_CHECK(hipMemcpy(h_out16, h->stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return VG_OK;
+}
+#endif
+
 int vg_hier_destroy(vg_hier* h) {
     if (!h) return VG_ERR_ARG;
+    if (h->stamps) (void)hipFree(h->stamps);
     (void)hipFree(h->slab);
     (void)hipFree(h->d_temp);
     delete h;
@@ -330,7 +441,7 @@ int vg_hdbscan_tree_device(vg_hier* h, const int32_t* d_lo, const int32_t* d_hi,
     tb = h->temp_bytes;
     VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->he_key, h->he_key_s, h->he_val, h->adj, (size_t)(2 * m), 0, HD_RANK_BITS, st));
     hipLaunchKernelGGL(k_hd_offsets, dim3(g2m), B, 0, st, 2 * m, n, h->he_key_s, h->adj_off);
-    hipLaunchKernelGGL(k_hd_init, dim3(vg_div_up(std::max(n, 2 * v.ncap + 1), HD_NT)), B, 0, st, v);
+    hipLaunchKernelGGL(k_hd_init, dim3(gn), B, 0, st, v);
     // ---- R1, R2 ----
     const size_t stack_bytes = (size_t)2 * min_cluster_size * HD_NT * sizeof(int);
     hipLaunchKernelGGL((k_hd_side<false>), dim3(g2m), B, stack_bytes, st, v);
@@ -343,12 +454,15 @@ int vg_hdbscan_tree_device(vg_hier* h, const int32_t* d_lo, const int32_t* d_hi,
                                      rocprim::plus<int>(), st));
     hipLaunchKernelGGL(k_hd_scatter, dim3(gm), B, 0, st, v);
     if (vg_max_dynamic_lds((const void*)k_hd_tree_a, HD_TREE_LDS_INTS * 4, hd_tree_a_lds) != VG_OK) return VG_ERR_HIP;
-    hipLaunchKernelGGL(k_hd_tree_a, dim3(1), dim3(1024), HD_TREE_LDS_INTS * 4, st, v);
+    hipLaunchKernelGGL(k_hd_tree_a, dim3(1), dim3(1024), HD_TREE_LDS_INTS * 4, st, v, h->stamps);
     // ---- R4 .. R6 ----
-    hipLaunchKernelGGL(k_hd_chain, dim3(gm), B, 0, st, v);
-    hipLaunchKernelGGL(k_hd_tree_b, dim3(1), dim3(1024), 0, st, v, h->bfs_key);
-    hipLaunchKernelGGL(k_hd_stability, dim3(256), B, 0, st, v);
-    hipLaunchKernelGGL(k_hd_tree_c, dim3(1), dim3(1024), 0, st, v);
+    hipLaunchKernelGGL(k_hd_chain, dim3(gm), B, HD_CHAIN_LDS_INTS * 4, st, v, h->ckey, h->crank);
+    tb = h->temp_bytes;
+    VG_CHECK(rocprim::radix_sort_pairs(h->d_temp, tb, h->ckey, h->ckey_s, h->crank, h->crank_s, (size_t)m, 0, HD_CHAIN_KEY_BITS, st));
+    v.chain_key = h->ckey_s; v.chain_rank = h->crank_s;
+    hipLaunchKernelGGL(k_hd_chain_stats, dim3(512), B, 0, st, v);
+    if (vg_max_dynamic_lds((const void*)k_hd_tree_bc, HD_TREE_BC_LDS_INTS * 4, hd_tree_bc_lds) != VG_OK) return VG_ERR_HIP;
+    hipLaunchKernelGGL(k_hd_tree_bc, dim3(1), dim3(512), HD_TREE_BC_LDS_INTS * 4, st, v, h->bfs_key, h->stamps);
     hipLaunchKernelGGL(k_hd_points, dim3(gn), B, 0, st, v);
     if (d_n_clusters) VG_CHECK(hipMemcpyAsync(d_n_clusters, v.n_clusters, sizeof(int), hipMemcpyDeviceToDevice, st));
     VG_LAUNCH_CHECK();
