@@ -171,6 +171,30 @@ def test_cu_masked_streams_change_no_output(cuda, tower):
 
 
 @pytest.mark.gpu
+def test_device_hierarchy_changes_no_output(cuda):
+    """hierarchy='device' (csrc/hdbscan_device.hip, the default) against hierarchy='host' (csrc/hdbscan_tree.cpp; zero_shot_detector.py:248):
+    labels and probabilities are bit-identical, so every state, score and box of frames in flight is."""
+    from vilgod_amd.pipeline import PseudoLabelPipeline
+    poses = synthetic.make_poses(6)
+    frames = [synthetic.make_frame(70 + f, 60_000, n_objects=30) for f in range(4)]
+    ref = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=61_000, clip_model_path='/nonexistent', hierarchy='host')
+    dev = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=61_000, clip_model_path='/nonexistent', clip=ref.clip, hierarchy='device')
+    assert ref._hier is None and dev._hier is not None
+    ref.new_sequence(); dev.new_sequence()
+    a = ref.process_frames([ref.upload(f) for f in frames], poses[1:5], poses[0], n_workers=3)
+    b = dev.process_frames([dev.upload(f) for f in frames], poses[1:5], poses[0], n_workers=3)
+    n_valid = 0
+    for (fa, ra, pa), (fb, rb, pb) in zip(a, b):
+        assert np.array_equal(fa.index, fb.index) and np.array_equal(fa.seg_off, fb.seg_off) and np.array_equal(fa.valid, fb.valid)
+        assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+        assert np.array_equal(ra['name'], rb['name']) and np.array_equal(ra['boxes_lidar'], rb['boxes_lidar'])
+        n_valid += int(fa.valid.sum())
+    assert n_valid > 20
+    with pytest.raises(ValueError):
+        PseudoLabelPipeline(device=cuda, max_points=1000, clip_model_path='/nonexistent', clip=ref.clip, hierarchy='gpu')
+
+
+@pytest.mark.gpu
 def test_round_robin_frames_with_replicated_ground_equal_one_rank(cuda):
     """SURVEY 8e, bench.py --ground-handoff replicate: two "ranks" (two pipeline objects here) take the frames of one sequence
     round-robin; each runs the stateful ground pass over ALL frames itself (process_frames(own=...)) and its own frames in full.

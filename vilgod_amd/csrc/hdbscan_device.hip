@@ -106,33 +106,36 @@ __global__ __launch_bounds__(HD_NT) void k_hd_scatter(HdView v) {
     if (r < v.m) hd_split_scatter(v, r);
 }
 
-// ONE workgroup: the union-find nodes of the splits' endpoints, then Kruskal over the splits -- every array it touches in LDS (a
-// dependent global-memory access per step would cost a microsecond each), written out afterwards
+// ONE workgroup: the union-find nodes of the splits' endpoints, then Kruskal over the splits by ONE lane -- every array it touches in
+// LDS (a dependent global-memory access per step would cost a microsecond each), written out afterwards.
+// The LDS form and the global-memory form are two instantiations of one body: with ONE body behind "pointer = LDS or global" every access
+// is a FLAT instruction (the address space decided per access at run time), and a flat access to LDS costs several times a ds_read
+// (round 6: 265 us of Kruskal for 682 splits at 2.4 GHz = 950 cycles per split).
+#define HD_STAMP(I) if (stamps && threadIdx.x == 0) stamps[I] = (long long)wall_clock64();
+__device__ __forceinline__ void hd_tree_a_body(const HdView& w, int ns, int* par, int* top, long long* stamps) {
+    for (int i = threadIdx.x; i < 2 * ns; i += blockDim.x) hd_split_nodes(w, i);
+    __syncthreads();
+    HD_STAMP(1)
+    // (ONE lane.  Measured and dropped, round 6: the same steps run wave-uniformly by 64 lanes -- node pairs of 64 splits prefetched into
+    // registers, union by size -- took 312 us instead of 265 for 682 splits: the scalarising readfirstlanes cost more than the loads saved)
+    if (threadIdx.x == 0) hd_kruskal_splits(w, ns, par, top);
+    __syncthreads();
+    HD_STAMP(2)
+}
 __global__ __launch_bounds__(1024) void k_hd_tree_a(HdView v, long long* __restrict__ stamps) {
     extern __shared__ int lds[];
     const int t = threadIdx.x, T = blockDim.x;
     const int ns = *v.ns;
     if (ns == 0) return;
-#define HD_STAMP(I) if (stamps && t == 0) stamps[I] = (long long)wall_clock64();
     HD_STAMP(0)
-    HdView w = v;
-    int *par = v.kw_parent, *top = v.kw_top;
-    const bool in_lds = 10 * ns <= HD_TREE_LDS_INTS;
-    if (in_lds) {
-        w.node = lds; par = lds + 2 * ns; top = lds + 4 * ns; w.kid = lds + 6 * ns; w.sp_parent = lds + 8 * ns; w.sp_side = lds + 9 * ns;
-    }
-    for (int i = t; i < 2 * ns; i += T) hd_split_nodes(w, i);
-    __syncthreads();
-    HD_STAMP(1)
-    // (ONE lane.  Measured and dropped, round 6: the same steps run wave-uniformly by 64 lanes -- node pairs of 64 splits prefetched into
-    // registers, union by size -- took 312 us instead of 265 for 682 splits: the scalarising readfirstlanes cost more than the loads saved)
-    if (t == 0) hd_kruskal_splits(w, ns, par, top);
-    __syncthreads();
-    HD_STAMP(2)
-    if (in_lds) {
-        for (int i = t; i < 2 * ns; i += T) v.kid[i] = w.kid[i];
-        for (int i = t; i < ns; i += T) { v.sp_parent[i] = w.sp_parent[i]; v.sp_side[i] = w.sp_side[i]; }
-    }
+    if (10 * ns <= HD_TREE_LDS_INTS) {
+        HdView w = v;
+        w.node = lds; w.kid = lds + 6 * ns; w.sp_parent = lds + 8 * ns; w.sp_side = lds + 9 * ns;
+        hd_tree_a_body(w, ns, lds + 2 * ns, lds + 4 * ns, stamps);
+        for (int i = t; i < 2 * ns; i += T) v.kid[i] = lds[6 * ns + i];
+        for (int i = t; i < ns; i += T) { v.sp_parent[i] = lds[8 * ns + i]; v.sp_side[i] = lds[9 * ns + i]; }
+    } else
+        hd_tree_a_body(v, ns, v.kw_parent, v.kw_top, stamps);
 }
 
 // LDS staging of the cluster tree's small arrays (a few hundred splits): the sweeps and walks over the tree are chains of dependent
@@ -156,15 +159,7 @@ __device__ __forceinline__ void hd_copy_out(T* g, const T* l, int count) {
 }
 
 #define HD_CHAIN_LDS_INTS 12288     // k_hd_chain: S, sp_parent, sp_side of up to 4096 splits per workgroup (48 KB)
-__global__ __launch_bounds__(HD_NT) void k_hd_chain(HdView v, unsigned* __restrict__ ckey, unsigned* __restrict__ crank) {
-    extern __shared__ int lds[];
-    const int ns = *v.ns;
-    HdView w = v;
-    if (3 * ns <= HD_CHAIN_LDS_INTS) {                             // the walk up the cluster tree: its three arrays in LDS
-        HdCarve cv{lds, 0};
-        w.S = hd_carve(cv, v.S, ns, true); w.sp_parent = hd_carve(cv, v.sp_parent, ns, true); w.sp_side = hd_carve(cv, v.sp_side, ns, true);
-        __syncthreads();
-    }
+__device__ __forceinline__ void hd_chain_body(const HdView& v, const HdView& w, unsigned* __restrict__ ckey, unsigned* __restrict__ crank) {
     const int r = blockIdx.x * HD_NT + threadIdx.x;
     const int c = r < v.m ? hd_chain_find(w, r) : -1;
     if (r < v.m) {
@@ -175,6 +170,18 @@ __global__ __launch_bounds__(HD_NT) void k_hd_chain(HdView v, unsigned* __restri
     // of the root (the points no cluster holds: most chain nodes) only the chain length is read: one atomic per wave
     const unsigned long long roots = __ballot(c == 0);
     if (c == 0 && (int)(threadIdx.x & 63) == __ffsll((long long)roots) - 1) atomicAdd(&v.chainlen[0], __popcll(roots));
+}
+__global__ __launch_bounds__(HD_NT) void k_hd_chain(HdView v, unsigned* __restrict__ ckey, unsigned* __restrict__ crank) {
+    extern __shared__ int lds[];
+    const int ns = *v.ns;
+    if (3 * ns <= HD_CHAIN_LDS_INTS) {                             // the walk up the cluster tree: its three arrays in LDS
+        for (int i = threadIdx.x; i < ns; i += HD_NT) { lds[i] = v.S[i]; lds[ns + i] = v.sp_parent[i]; lds[2 * ns + i] = v.sp_side[i]; }
+        __syncthreads();
+        HdView w = v;
+        w.S = lds; w.sp_parent = lds + ns; w.sp_side = lds + 2 * ns;
+        hd_chain_body(v, w, ckey, crank);
+    } else
+        hd_chain_body(v, v, ckey, crank);
 }
 
 // a wave per cluster over its run of the sorted chain nodes: chain length, points, largest lambda, and the rows of its own chain summed
@@ -239,52 +246,35 @@ __global__ __launch_bounds__(HD_NT) void k_hd_chain_stats(HdView v) {
         __syncthreads();                                                                   \
         if (!s_flag[sweep % 3]) break;                                                     \
     }
-#define HD_TREE_BC_LDS_INTS 38912      // 152 KB of dynamic LDS (+ the scan's 4 KB): up to ~1100 splits, else global memory
-__global__ __launch_bounds__(512) void k_hd_tree_bc(HdView gv, unsigned long long* __restrict__ g_bfs_key, long long* __restrict__ stamps) {
-    extern __shared__ int lds[];
-    const int t = threadIdx.x, T = blockDim.x;
-    const int ns = *gv.ns, ncl = 2 * ns + 1;
-    __shared__ int s_flag[3];
-    __shared__ int s_part[512];
-    HdView v = gv;
-    unsigned long long* bfs_key = g_bfs_key;
-    HD_STAMP(4)
-    if (stamps && t == 0) stamps[14] = clock64();
-    const bool in_lds = 12 * ns + 11 * ncl + 64 <= HD_TREE_BC_LDS_INTS;
-    if (in_lds) {
-        HdCarve cv{lds, 0};
-        v.kid = hd_carve(cv, gv.kid, 2 * ns, true); v.sp_parent = hd_carve(cv, gv.sp_parent, ns, true); v.sp_side = hd_carve(cv, gv.sp_side, ns, true);
-        v.lam_split = hd_carve(cv, gv.lam_split, ns, true);
-        v.tot = hd_carve(cv, gv.tot, ns, false); v.nsub = hd_carve(cv, gv.nsub, ns, false); v.depth = hd_carve(cv, gv.depth, ns, false);
-        v.pre = hd_carve(cv, gv.pre, ns, false); v.done = hd_carve(cv, gv.done, ns, false); v.q = hd_carve(cv, gv.q, ns, false);
-        v.npts = hd_carve(cv, gv.npts, ncl, true); v.chainlen = hd_carve(cv, gv.chainlen, ncl, true);
-        v.csize = hd_carve(cv, gv.csize, ncl, false); v.stab = hd_carve(cv, gv.stab, ncl, true); v.stab2 = hd_carve(cv, gv.stab2, ncl, false);
-        v.death = hd_carve(cv, gv.death, ncl, true); v.sel_by_final = hd_carve(cv, gv.sel_by_final, ncl + 1, false);
-        v.wins = hd_carve(cv, gv.wins, ncl, false); v.selected = hd_carve(cv, gv.selected, ncl, false); v.cand = hd_carve(cv, gv.cand, ncl, false);
-        // (free once the bottom-up sweeps are over: stab2 -> the BFS keys, stab -> out_death, csize -> out_label)
-        bfs_key = (unsigned long long*)v.stab2; v.out_death = v.stab; v.out_label = v.csize;
-        __syncthreads();
-    }
+#define HD_TREE_BC_LDS_INTS 38912      // 152 KB of dynamic LDS (+ the scan's 2 KB): up to ~1100 splits, else global memory
+__device__ __forceinline__ void hd_tree_bc_body(const HdView& v, unsigned long long* bfs_key, int* n_clusters, int ns, int* s_flag, int* s_part,
+                                                long long* stamps) {
+    const int t = threadIdx.x, T = blockDim.x, ncl = 2 * ns + 1;
     HD_STAMP(5)
     HD_SWEEPS(hd_up_all(v, i, sweep))
     HD_STAMP(6)
     HD_SWEEPS(hd_down_order(v, i, sweep))
     HD_STAMP(7)
-    for (int k = t; k < ns; k += T) bfs_key[k] = ((unsigned long long)(unsigned)v.depth[k] << 32) | (unsigned)v.pre[k];
+    // BFS position of a split = its place in (depth, preorder) order: a bitonic sort of depth << 40 | preorder << 20 | split over the next
+    // power of two (a step = one barrier; counting "who is in front of me" was ns^2 / T reads per thread: 60-180 us for 682 splits)
+    int P = 1;
+    while (P < ns) P <<= 1;
+    for (int i = t; i < P; i += T)
+        bfs_key[i] = i < ns ? ((unsigned long long)(unsigned)v.depth[i] << (2 * HD_RANK_BITS)) | ((unsigned long long)(unsigned)v.pre[i] << HD_RANK_BITS) | (unsigned)i : ~0ull;
     __syncthreads();
-    for (int k = t; k < ns; k += T) {                      // BFS position = the splits in front in (depth, preorder) order
-        const unsigned long long mine = bfs_key[k];
-        int cnt = 0, j = 0;
-        for (; j + 32 <= ns; j += 32) {                    // (32 independent LDS reads per step: one at a time they cost a round trip each)
-            unsigned long long kk[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) kk[u] = bfs_key[j + u];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) cnt += kk[u] < mine ? 1 : 0;
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P; i += T) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const unsigned long long a = bfs_key[i], b = bfs_key[x];
+                    if ((a > b) == ((i & k2) == 0)) { bfs_key[i] = b; bfs_key[x] = a; }
+                }
+            }
+            __syncthreads();
         }
-        for (; j < ns; ++j) cnt += bfs_key[j] < mine ? 1 : 0;
-        v.q[k] = cnt;
-    }
+    for (int i = t; i < ns; i += T) v.q[(int)(bfs_key[i] & ((1u << HD_RANK_BITS) - 1u))] = i;
+    __syncthreads();
     HD_STAMP(8)
     for (int c = 1 + t; c < ncl; c += T) hd_select_eom(v, c);
     __syncthreads();
@@ -313,18 +303,41 @@ __global__ __launch_bounds__(512) void k_hd_tree_bc(HdView gv, unsigned long lon
     }
     int run = s_part[t] - sum;
     for (int f = b0; f < b1; ++f) { const int sf = v.sel_by_final[f]; v.sel_by_final[f] = run; run += sf; }
-    if (t == T - 1) *gv.n_clusters = s_part[T - 1];
+    if (t == T - 1) *n_clusters = s_part[T - 1];
     __syncthreads();
     HD_STAMP(11)
     for (int c = t; c < ncl; c += T) hd_owner(v, c);
-    if (in_lds) {
+    __syncthreads();
+    HD_STAMP(12)
+}
+__global__ __launch_bounds__(512) void k_hd_tree_bc(HdView gv, unsigned long long* __restrict__ g_bfs_key, long long* __restrict__ stamps) {
+    extern __shared__ int lds[];
+    const int ns = *gv.ns, ncl = 2 * ns + 1;
+    __shared__ int s_flag[3];
+    __shared__ int s_part[512];
+    HD_STAMP(4)
+    if (stamps && threadIdx.x == 0) stamps[14] = clock64();
+    if (12 * ns + 11 * ncl + 64 <= HD_TREE_BC_LDS_INTS) {          // (two instantiations of the body: see k_hd_tree_a)
+        HdView v = gv;
+        HdCarve cv{lds, 0};
+        v.kid = hd_carve(cv, gv.kid, 2 * ns, true); v.sp_parent = hd_carve(cv, gv.sp_parent, ns, true); v.sp_side = hd_carve(cv, gv.sp_side, ns, true);
+        v.lam_split = hd_carve(cv, gv.lam_split, ns, true);
+        v.tot = hd_carve(cv, gv.tot, ns, false); v.nsub = hd_carve(cv, gv.nsub, ns, false); v.depth = hd_carve(cv, gv.depth, ns, false);
+        v.pre = hd_carve(cv, gv.pre, ns, false); v.done = hd_carve(cv, gv.done, ns, false); v.q = hd_carve(cv, gv.q, ns, false);
+        v.npts = hd_carve(cv, gv.npts, ncl, true); v.chainlen = hd_carve(cv, gv.chainlen, ncl, true);
+        v.csize = hd_carve(cv, gv.csize, ncl, false); v.stab = hd_carve(cv, gv.stab, ncl, true); v.stab2 = hd_carve(cv, gv.stab2, ncl, false);
+        v.death = hd_carve(cv, gv.death, ncl, true); v.sel_by_final = hd_carve(cv, gv.sel_by_final, ncl + 1, false);
+        v.wins = hd_carve(cv, gv.wins, ncl, false); v.selected = hd_carve(cv, gv.selected, ncl, false); v.cand = hd_carve(cv, gv.cand, ncl, false);
+        // (free once the bottom-up sweeps are over: stab2 -> the BFS keys, stab -> out_death, csize -> out_label)
+        v.out_death = v.stab; v.out_label = v.csize;
         __syncthreads();
-        HD_STAMP(12)
+        hd_tree_bc_body(v, (unsigned long long*)v.stab2, gv.n_clusters, ns, s_flag, s_part, stamps);
         hd_copy_out(gv.out_label, v.out_label, ncl); hd_copy_out(gv.out_death, v.out_death, ncl);
-    }
+    } else
+        hd_tree_bc_body(gv, g_bfs_key, gv.n_clusters, ns, s_flag, s_part, stamps);
     __syncthreads();
     HD_STAMP(13)
-    if (stamps && t == 0) stamps[15] = clock64();
+    if (stamps && threadIdx.x == 0) stamps[15] = clock64();
 }
 #undef HD_SWEEPS
 #undef HD_STAMP
@@ -365,7 +378,7 @@ int vg_hier_create(vg_hier** out, int max_points) {
         h->he_key = hd_take<unsigned>(p, 2 * m); h->he_key_s = hd_take<unsigned>(p, 2 * m);
         h->he_val = hd_take<unsigned long long>(p, 2 * m); h->adj = hd_take<unsigned long long>(p, 2 * m);
         h->adj_off = hd_take<int>(p, n + 1);
-        h->bfs_key = hd_take<unsigned long long>(p, ncap);
+        h->bfs_key = hd_take<unsigned long long>(p, 2 * ncap);
         h->ckey = hd_take<unsigned>(p, m); h->ckey_s = hd_take<unsigned>(p, m); h->crank = hd_take<unsigned>(p, m); h->crank_s = hd_take<unsigned>(p, m);
         v.side = hd_take<unsigned char>(p, 2 * m); v.eflag = hd_take<unsigned char>(p, m);
         v.kcnt = hd_take<int>(p, m); v.a = hd_take<int>(p, n); v.uf = hd_take<int>(p, n); v.split_pos = hd_take<int>(p, m);

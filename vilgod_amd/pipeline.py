@@ -80,12 +80,15 @@ class PseudoLabelPipeline:
         mcfg = dict(_get(ccfg, 'model'))
         mcfg.pop('_target_', None)
         self.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **mcfg)
-        # hierarchy stage: 'host' (csrc/hdbscan_tree.cpp in the frame's thread, beside the other frames' GPU work) or 'device'
-        # (csrc/hdbscan_device.hip: no copy of the tree, no host stage -- the same labels and probabilities bit for bit; 2 ms less
-        # frame latency, a dozen small kernels more per frame: LAB_NOTES.md section 0)
-        self.hierarchy = str(os.environ.get('VILGOD_HIERARCHY', 'host') if hierarchy is None else hierarchy)
+        # hierarchy stage: 'device' (csrc/hdbscan_device.hip: the tree never leaves the GPU; default) or 'host' (csrc/hdbscan_tree.cpp in
+        # the frame's thread) -- the same labels and probabilities bit for bit (tests/test_hierarchy.py); the device stage takes 0.9 ms of
+        # a 150k-point frame's latency instead of 2.2 and costs the stream of frames nothing (LAB_NOTES.md section 0).  The device stage
+        # holds min_cluster_size <= 32 and <= 2^20 points; beyond that the host stage runs.
+        self.hierarchy = str(os.environ.get('VILGOD_HIERARCHY', 'device') if hierarchy is None else hierarchy)
         if self.hierarchy not in ('host', 'device'):
             raise ValueError("hierarchy: 'host' or 'device'")
+        if self.cluster_model.min_cluster_size > 32 or self.max_points > (1 << 20):
+            self.hierarchy = 'host'
         self._hier = DeviceHierarchy(max_points=self.max_points, device=self.device) if self.hierarchy == 'device' else None
         self.prob_threshold = float(_get(ccfg, 'propability_threshold', 0.3))
         self._filters = self._parse_filters(ccfg)

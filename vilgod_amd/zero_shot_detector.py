@@ -174,7 +174,8 @@ class ZeroShotDetector:
                                            clip_model_path=cfg.paths.clip_model, min_range=ga['min_range'],
                                            z_offset=ga['z_offset'], plane_seed=dev.get('plane_seed', 666), clip=clip_model,
                                            box_mode=dev.get('box_mode', 'reference'), box_workers=dev.get('box_workers', 4),
-                                   angle_mode=dev.get('angle_mode', 'reference'), vit_graph=bool(dev.get('vit_graph', False)))
+                                   angle_mode=dev.get('angle_mode', 'reference'), vit_graph=bool(dev.get('vit_graph', False)),
+                                           hierarchy=dev.get('hierarchy', None))
         self.pipe = pipeline
         self.sequence_data_dir_path = Path(cfg.paths.sequence_data)
         self.my_frames = vdist.shard_frames(self.lenght, self.rank, self.world_size)
