@@ -578,6 +578,7 @@ def main():
             out['config'][f'block{i}_crops'] = bc
         out['config']['us_per_crop'] = round(1e6 * elapsed / max(crops, 1), 2)
         out['config']['gemm_kernel'] = DOMINANT_KERNEL
+        out['config']['hierarchy_stage'] = pipe.hierarchy        # HDBSCAN's hierarchy stage: 'device' (csrc/hdbscan_device.hip) or 'host'
         out['value_block0'] = bvals[0]                 # the clouds rounds 1-4 timed as their single block: comparable across rounds
         if tower2 is not None:
             out['roofline']['tower2_frac'] = tower2['frac']

@@ -157,10 +157,10 @@ def test_detections_from_labels_matches_reference_rule():
 
 
 # ------------------------------------------------------------------------------------------- GPU
-def _gpu_model(cuda, n):
+def _gpu_model(cuda, n, hierarchy='host'):
     from vilgod_amd.hdbscan import HDBSCAN
     return HDBSCAN(cluster_selection_epsilon=0.15, min_cluster_size=15, metric='euclidean', core_dist_n_jobs=-1,
-                   max_points=n + 16, device=cuda)
+                   max_points=n + 16, device=cuda, hierarchy=hierarchy)
 
 
 @pytest.mark.gpu
@@ -198,19 +198,23 @@ def test_hip_core_mst_labels_equal_oracle(cuda, case):
     got_model = model.fit(X)
     assert np.array_equal(got_model.labels_, want_l)
     assert np.array_equal(got_model.probabilities_, want_p)
+    on_device = _gpu_model(cuda, n, hierarchy='device').fit(X)        # the hierarchy stage as kernels (csrc/hdbscan_device.hip) against the oracle
+    assert np.array_equal(on_device.labels_, want_l)
+    assert np.array_equal(on_device.probabilities_, want_p)
     print(f'{case}: n={n} clusters={want_l.max() + 1} rounds={model.n_rounds_}')
 
 
 @pytest.mark.gpu
 def test_hip_cluster_small_and_degenerate(cuda):
     import torch
-    model = _gpu_model(cuda, 1000)
-    for n in [0, 1, 2, 15, 16, 17, 40]:
-        X = np.random.default_rng(n).normal(size=(n, 3)).astype(np.float32)
-        m = model.fit(X)
-        want_l, want_p = ho.fit(X)
-        assert np.array_equal(m.labels_, want_l), n
-        assert np.array_equal(m.probabilities_, want_p), n
+    for hierarchy in ('host', 'device'):
+        model = _gpu_model(cuda, 1000, hierarchy)
+        for n in [0, 1, 2, 15, 16, 17, 40]:
+            X = np.random.default_rng(n).normal(size=(n, 3)).astype(np.float32)
+            m = model.fit(X)
+            want_l, want_p = ho.fit(X)
+            assert np.array_equal(m.labels_, want_l), (hierarchy, n)
+            assert np.array_equal(m.probabilities_, want_p), (hierarchy, n)
 
 
 @pytest.mark.gpu
@@ -292,9 +296,10 @@ def test_hip_cluster_full_size_equals_oracle_fixture(cuda, golden_dir):
     lo, hi, w2, core2 = model.mst(torch.from_numpy(X).to(cuda), want_core=True)
     lo, hi, w2, core2 = lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), core2.cpu().numpy()
     order = np.lexsort((hi, lo, w2))
-    m = model.fit(X)
-    got = mk.digests(X, core2, lo[order], hi[order], w2[order], m.labels_, m.probabilities_)
-    for k in ('n', 'core2_sha256', 'mst_w2_sha256', 'mst_edges_sha256', 'labels_sha256', 'canonical_labels_sha256', 'probs_sha256',
-              'n_clusters', 'n_noise', 'n_detections', 'detection_sizes_sha256'):
-        assert got[k] == g[k], (k, got[k], g[k])
+    for hierarchy in ('host', 'device'):                              # both forms of the hierarchy stage against the frozen oracle result
+        m = _gpu_model(cuda, n, hierarchy).fit(X)
+        got = mk.digests(X, core2, lo[order], hi[order], w2[order], m.labels_, m.probabilities_)
+        for k in ('n', 'core2_sha256', 'mst_w2_sha256', 'mst_edges_sha256', 'labels_sha256', 'canonical_labels_sha256', 'probs_sha256',
+                  'n_clusters', 'n_noise', 'n_detections', 'detection_sizes_sha256'):
+            assert got[k] == g[k], (hierarchy, k, got[k], g[k])
     print(f"full-size fixture: n={n} clusters={got['n_clusters']} noise={got['n_noise']} rounds={model.n_rounds_}: identical")

@@ -19,7 +19,7 @@ from ._lib import lib, ptr, stream_ptr, check
 
 class HDBSCAN:
     def __init__(self, min_cluster_size=5, min_samples=None, cluster_selection_epsilon=0.0, metric='euclidean',
-                 core_dist_n_jobs=None, max_points=400_000, device='cuda', **unused):
+                 core_dist_n_jobs=None, max_points=400_000, device='cuda', hierarchy='host', **unused):
         if metric != 'euclidean':
             raise NotImplementedError('only the euclidean metric of the reference configuration is implemented')
         for k in unused:
@@ -35,6 +35,12 @@ class HDBSCAN:
         self.cluster_selection_epsilon = float(cluster_selection_epsilon)
         self.device = torch.device(device)
         self.max_points = int(max_points)
+        # `fit`'s hierarchy stage: 'host' (csrc/hdbscan_tree.cpp) or 'device' (csrc/hdbscan_device.hip: the tree stays on the GPU);
+        # identical results.  (The fused pipeline chooses for itself: PseudoLabelPipeline(hierarchy=...).)
+        if hierarchy not in ('host', 'device'):
+            raise ValueError("hierarchy: 'host' or 'device'")
+        self.hierarchy = hierarchy
+        self._hier = None
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             check(lib.vg_cluster_create(ctypes.byref(h), self.max_points), 'vg_cluster_create')
@@ -126,7 +132,13 @@ class HDBSCAN:
             self.probabilities_ = np.zeros(n)
             return self
         lo, hi, w2 = self.mst(Xd, dim=dim)
-        labels, probs, _ = self.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), n)
+        if self.hierarchy == 'device':
+            if self._hier is None:
+                self._hier = DeviceHierarchy(max_points=self.max_points, device=self.device)
+            d_labels, d_probs, _ = self._hier.tree_async(lo, hi, w2, n, self.min_cluster_size, self.cluster_selection_epsilon)
+            labels, probs = d_labels.cpu().numpy(), d_probs.cpu().numpy()
+        else:
+            labels, probs, _ = self.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), n)
         self.labels_ = labels.astype(np.int64)
         self.probabilities_ = probs
         return self
