@@ -117,7 +117,9 @@ __device__ __forceinline__ void hd_tree_a_body(const HdView& w, int ns, int* par
     __syncthreads();
     HD_STAMP(1)
     // (ONE lane.  Measured and dropped, round 6: the same steps run wave-uniformly by 64 lanes -- node pairs of 64 splits prefetched into
-    // registers, union by size -- took 312 us instead of 265 for 682 splits: the scalarising readfirstlanes cost more than the loads saved)
+    // registers, union by size -- took 312 us instead of 265 for 682 splits: the scalarising readfirstlanes cost more than the loads saved;
+    // TWO lanes, one per endpoint (finds side by side, roots and sizes crossed by a DPP swap, union by size): 214 against 220 us.  A split
+    // costs ~750 cycles = three dependent LDS round trips of a lone wave, however the work around them is arranged.)
     if (threadIdx.x == 0) hd_kruskal_splits(w, ns, par, top);
     __syncthreads();
     HD_STAMP(2)
