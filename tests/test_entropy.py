@@ -195,6 +195,8 @@ def test_sequence_entropy_and_two_frame_labels_gpu(cuda):
         ent_o.append(no.full_scores(len(X[f]), wv, wi))
         assert np.array_equal(ent_g[f].cpu().numpy(), ent_o[f])      # float32 after the cut: identical here
     two = TwoFrameClusterer(m, n_frames=2, seed=0)
+    # ... and with the hierarchy stage on the device (the tree and the label transfer stay on the GPU: the pipeline's default)
+    two_dev = TwoFrameClusterer(HDBSCAN(min_cluster_size=15, cluster_selection_epsilon=0.15, max_points=50000, hierarchy='device'), n_frames=2, seed=0)
     for fnr in (0, 3, len(X) - 1):
         seq_g = two.cluster_input(fnr, d, ent_g).cpu().numpy()
         seq_o, _, _ = no.two_frame_input(X, ent_o, fnr, 2, seed=0)
@@ -205,3 +207,5 @@ def test_sequence_entropy_and_two_frame_labels_gpu(cuda):
         assert np.array_equal(ho.canonical(lab_g), ho.canonical(lab_o))
         assert np.array_equal(prob_g, prob_o)
         assert (lab_g >= 0).sum() > 100
+        lab_d, prob_d = two_dev.labels(fnr, d, ent_g)
+        assert lab_d.dtype == lab_g.dtype and np.array_equal(lab_d, lab_g) and np.array_equal(prob_d, prob_g)

@@ -179,7 +179,7 @@ def test_device_hierarchy_changes_no_output(cuda):
     frames = [synthetic.make_frame(70 + f, 60_000, n_objects=30) for f in range(4)]
     ref = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=61_000, clip_model_path='/nonexistent', hierarchy='host')
     dev = PseudoLabelPipeline(device=cuda, vit_dtype='f16', max_points=61_000, clip_model_path='/nonexistent', clip=ref.clip, hierarchy='device')
-    assert ref._hier is None and dev._hier is not None
+    assert ref.hierarchy == 'host' and dev.hierarchy == 'device' and dev.cluster_model.hierarchy == 'device'
     ref.new_sequence(); dev.new_sequence()
     a = ref.process_frames([ref.upload(f) for f in frames], poses[1:5], poses[0], n_workers=3)
     b = dev.process_frames([dev.upload(f) for f in frames], poses[1:5], poses[0], n_workers=3)

@@ -212,11 +212,22 @@ class TwoFrameClusterer:
         if m < 2:
             return np.full(n, -1, np.int64), np.zeros(n)
         lo, hi, w2 = self.model.mst(seq, dim=5)
-        lab_seq, prob_seq, _ = self.model.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), m)
+        on_device = getattr(self.model, 'hierarchy', 'host') == 'device'
+        if on_device:        # the hierarchy stage as kernels: the tree stays on the GPU, the label transfer below is a device gather
+            d_lab, d_prob, _ = self.model.tree_device(lo, hi, w2, m)
+        else:
+            lab_seq, prob_seq, _ = self.model.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), m)
         self.model.grid(seq)
         Xf = X_list[fnr]
         o = spatial_order(Xf)
         idx_s, _ = self.model.nearest(Xf.index_select(0, o)[:, :3].contiguous(), self.gate)
+        if on_device:
+            d_idx = torch.empty_like(idx_s).index_copy_(0, o, idx_s).long()
+            ok = d_idx >= 0
+            g = d_idx.clamp_min(0)
+            labels = torch.where(ok, d_lab.index_select(0, g).long(), torch.full_like(g, -1))
+            probs = torch.where(ok, d_prob.index_select(0, g), torch.zeros_like(d_prob[:1]).expand_as(g))
+            return labels.cpu().numpy(), probs.cpu().numpy()
         idx = torch.empty_like(idx_s).index_copy_(0, o, idx_s).cpu().numpy().astype(np.int64)
         ok = idx >= 0
         labels = np.where(ok, lab_seq[np.maximum(idx, 0)], -1).astype(np.int64)

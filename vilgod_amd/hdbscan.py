@@ -39,6 +39,8 @@ class HDBSCAN:
         # identical results.  (The fused pipeline chooses for itself: PseudoLabelPipeline(hierarchy=...).)
         if hierarchy not in ('host', 'device'):
             raise ValueError("hierarchy: 'host' or 'device'")
+        if self.min_cluster_size > 32 or self.max_points > (1 << 20):       # what the device stage holds (include/vilgod_hip.h)
+            hierarchy = 'host'
         self.hierarchy = hierarchy
         self._hier = None
         h = ctypes.c_void_p()
@@ -113,6 +115,13 @@ class HDBSCAN:
                                        p(labels), p(probs), ctypes.byref(nc)), 'vg_hdbscan_tree_host')
         return labels, probs, nc.value
 
+    def tree_device(self, lo, hi, w2, n, stream=None):
+        """CUDA sorted MST (as `mst` returns it) -> (labels int32 [n], probabilities float64 [n], n_clusters int32 [1]) CUDA tensors, queued on
+        the stream, nothing waited for: the hierarchy stage as kernels (csrc/hdbscan_device.hip), the same results as `tree`."""
+        if self._hier is None:
+            self._hier = DeviceHierarchy(max_points=self.max_points, device=self.device)
+        return self._hier.tree_async(lo, hi, w2, n, self.min_cluster_size, self.cluster_selection_epsilon, stream)
+
     def fit(self, X, dim=None):
         """numpy input: every column is a clustering coordinate, like the library (3 = `points_ref_wo_ground[..., :3]`,
         zero_shot_detector.py:246-248; 5 = the two-frame `points_seq`, :239-241).  CUDA tensor input (fused pipeline):
@@ -133,9 +142,7 @@ class HDBSCAN:
             return self
         lo, hi, w2 = self.mst(Xd, dim=dim)
         if self.hierarchy == 'device':
-            if self._hier is None:
-                self._hier = DeviceHierarchy(max_points=self.max_points, device=self.device)
-            d_labels, d_probs, _ = self._hier.tree_async(lo, hi, w2, n, self.min_cluster_size, self.cluster_selection_epsilon)
+            d_labels, d_probs, _ = self.tree_device(lo, hi, w2, n)
             labels, probs = d_labels.cpu().numpy(), d_probs.cpu().numpy()
         else:
             labels, probs, _ = self.tree(lo.cpu().numpy(), hi.cpu().numpy(), w2.cpu().numpy(), n)

@@ -25,7 +25,7 @@ from scipy.spatial.transform import Rotation
 from ._lib import lib, ptr, stream_ptr, check
 from .frame_state import FrameState, pack_clusters, vote, static_from_entropy
 from . import patchworkpp as gpw
-from .hdbscan import HDBSCAN, DeviceHierarchy
+from .hdbscan import HDBSCAN
 from .projection import RealisticProjection, VIEWS_4, VIEWS_6
 from .clip_wrapper import ClipWrapper
 
@@ -79,17 +79,16 @@ class PseudoLabelPipeline:
         ccfg = _get(cfg, 'clustering')
         mcfg = dict(_get(ccfg, 'model'))
         mcfg.pop('_target_', None)
-        self.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **mcfg)
         # hierarchy stage: 'device' (csrc/hdbscan_device.hip: the tree never leaves the GPU; default) or 'host' (csrc/hdbscan_tree.cpp in
         # the frame's thread) -- the same labels and probabilities bit for bit (tests/test_hierarchy.py); the device stage takes 0.9 ms of
         # a 150k-point frame's latency instead of 2.2 and costs the stream of frames nothing (LAB_NOTES.md section 0).  The device stage
-        # holds min_cluster_size <= 32 and <= 2^20 points; beyond that the host stage runs.
-        self.hierarchy = str(os.environ.get('VILGOD_HIERARCHY', 'device') if hierarchy is None else hierarchy)
-        if self.hierarchy not in ('host', 'device'):
+        # holds min_cluster_size <= 32 and <= 2^20 points; beyond that the host stage runs (HDBSCAN decides).
+        hierarchy = str(os.environ.get('VILGOD_HIERARCHY', 'device') if hierarchy is None else hierarchy)
+        if hierarchy not in ('host', 'device'):
             raise ValueError("hierarchy: 'host' or 'device'")
-        if self.cluster_model.min_cluster_size > 32 or self.max_points > (1 << 20):
-            self.hierarchy = 'host'
-        self._hier = DeviceHierarchy(max_points=self.max_points, device=self.device) if self.hierarchy == 'device' else None
+        mcfg['hierarchy'] = hierarchy
+        self.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **mcfg)
+        self.hierarchy = self.cluster_model.hierarchy
         self.prob_threshold = float(_get(ccfg, 'propability_threshold', 0.3))
         self._filters = self._parse_filters(ccfg)
         self.angle_mode = angle_mode             # view direction angle: 'device' | 'reference' (this host's numpy; projection.py)
@@ -145,7 +144,6 @@ class PseudoLabelPipeline:
         import copy
         w = copy.copy(self)
         w.cluster_model = HDBSCAN(max_points=self.max_points, device=self.device, **self._mcfg)
-        w._hier = DeviceHierarchy(max_points=self.max_points, device=self.device) if self.hierarchy == 'device' else None
         w.projection = RealisticProjection(_get(self.cfg, 'lidar_image_projection'), device=self.device,
                                            views=VIEWS_4 if self._n_views == 4 else VIEWS_6, angle_mode=self.angle_mode)
         w.clip = self.clip.view()                # shared read-only weights, own workspace
@@ -405,9 +403,8 @@ class PseudoLabelPipeline:
             return np.full(n, -1, np.int64), np.zeros(n)
         lo, hi, w2 = self.cluster_model.mst(d_X)
         self._mark('mst_kernels')
-        if self._hier is not None:
-            m = self.cluster_model
-            d_labels, d_probs, _ = self._hier.tree_async(lo, hi, w2, n, m.min_cluster_size, m.cluster_selection_epsilon)
+        if self.cluster_model.hierarchy == 'device':
+            d_labels, d_probs, _ = self.cluster_model.tree_device(lo, hi, w2, n)
             self._mark('hierarchy_device')
             labels, probs = d_labels.cpu().numpy(), d_probs.cpu().numpy()
             self._mark('labels_d2h')
