@@ -334,6 +334,7 @@ def test_hip_last_block_on_class_token_rows_only(cuda, n, monkeypatch):
     from vilgod_amd.clip_wrapper import VitEncoder
     wd = cw.synthetic_vit_weights(2, **cw.VIT_B16)
     x = torch.randn(n, 3, 224, 224, generator=torch.Generator().manual_seed(n)).to(cuda)
+    monkeypatch.setenv('VG_VIT_RESID_HL', '0')       # (the fp16-pair residual stream exists with the class-row last block only: fp32 stream on both sides)
     f_cls = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
     monkeypatch.setenv('VG_VIT_CLS_LAST', '0')
     f_all = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
@@ -480,6 +481,29 @@ def test_hip_tower_kernel_families_agree(cuda, monkeypatch):
     rel = ((f_w4 - f_pp).norm() / f_pp.norm()).item()
     print(f'k_gemm_f16_w4 vs k_gemm_f16_pp64 tower: relative L2 {rel:.2e}')
     assert rel < 5e-4           # (measured 1.7e-4: a last-bit difference of a row's rstd moves fp16 roundings downstream; the fp16 tower sits 3.4e-4 from the fp32 tower)
+
+
+@pytest.mark.gpu
+def test_hip_tower_pair_residual_stream_agrees(cuda, monkeypatch):
+    """The residual stream kept as an fp16 pair (the default; VG_VIT_RESID_HL=0: fp32): hi = the copy the next GEMM reads, lo = f16(x - hi):
+    22 bits of x; the residual GEMMs read and write 4 + 4 bytes per element instead of 4 + 6.  The features agree with the fp32-stream tower like the two
+    kernel families agree with each other (a last-bit difference of a row statistic moves fp16 roundings downstream), both sit at the same
+    distance from the fp32 tower, and the pair tower is deterministic."""
+    from vilgod_amd.clip_wrapper import VitEncoder
+    wd = cw.synthetic_vit_weights(2, **cw.VIT_B16)
+    x = torch.randn(40, 3, 224, 224, generator=torch.Generator().manual_seed(40)).to(cuda)
+    f32 = VitEncoder(wd, dtype='f32', device=cuda).encode(x).cpu()
+    monkeypatch.setenv('VG_VIT_RESID_HL', '0')
+    f_x = VitEncoder(wd, dtype='f16', device=cuda).encode(x).cpu()
+    monkeypatch.setenv('VG_VIT_RESID_HL', '1')
+    enc = VitEncoder(wd, dtype='f16', device=cuda)
+    f_hl = enc.encode(x).cpu()
+    assert torch.isfinite(f_hl).all() and torch.equal(f_hl, enc.encode(x).cpu())
+    assert not torch.equal(f_hl, f_x)                     # (the switch reached the handle)
+    rel = ((f_hl - f_x).norm() / f_x.norm()).item()
+    d_x, d_hl = ((f_x - f32).norm() / f32.norm()).item(), ((f_hl - f32).norm() / f32.norm()).item()
+    print(f'pair stream vs fp32 stream: relative L2 {rel:.2e}; to the fp32 tower {d_hl:.2e} (fp32 stream: {d_x:.2e})')
+    assert rel < 5e-4 and d_hl < 1.15 * d_x + 1e-5
 
 
 @pytest.mark.gpu

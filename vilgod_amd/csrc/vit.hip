@@ -43,7 +43,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // QuickGELU x * sigmoid(1.702 x) (model.py:166-168) as x / (1 + 2^(x * QGELU_C)): one multiply in front of v_exp_f32 instead of two
 #define QGELU_C (-1.702f * 1.4426950408889634f)
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_NONE_F32 = 3,
-       EPI_BIAS_RESID_H = 4 };   // 4: fp16 residual stream (k_gemm_f16_pp64 only): resid_h = f16(resid_h + f16(acc + bias))
+       EPI_BIAS_RESID_H = 4,     // 4: fp16 residual stream (k_gemm_f16_pp64 only): resid_h = f16(resid_h + f16(acc + bias))
+       EPI_BIAS_RESID_HL = 5 };  // 5: the residual stream as an fp16 PAIR (k_gemm_f16_w4 only, LN = 2): x = hi + lo, hi = the fp16 copy the next
+                                 //    GEMM reads (ln_x16), lo = f16(x - hi) (`resid`, as f16*): 22 bits of x in 4 bytes, read 4 + written 4 per element
+                                 //    instead of read 4 + written 6
 
 // ---------------------------------------------------------------------------------------------
 // XCD-aware tile order: consecutive hardware block ids are dealt round-robin to the 8 XCDs; give each
@@ -385,13 +388,16 @@ __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ p
                                                      const float* __restrict__ pos, const float* __restrict__ lw,
                                                      const float* __restrict__ lb, TO* __restrict__ x, int n_rows,
                                                      int T, int W, int n_rows_padded, const float* __restrict__ lw1 = nullptr,
-                                                     const float* __restrict__ lb1 = nullptr, f16* __restrict__ h1 = nullptr) {
+                                                     const float* __restrict__ lb1 = nullptr, f16* __restrict__ h1 = nullptr,
+                                                     f16* __restrict__ pair_hi = nullptr, f16* __restrict__ pair_lo = nullptr) {
+    // pair_hi / pair_lo (TO = float, vectorised widths): the stream is written as the fp16 pair of EPI_BIAS_RESID_HL instead of to x
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n_rows_padded) return;
     if (row >= n_rows) {
         // padding rows of the residual stream (GEMM row tile): re-zeroed on every call -- every residual epilogue adds its
         // bias into them, and the workspace carve-up moves when n_crops changes
-        for (int c = lane; c < W; c += 64) x[(size_t)row * W + c] = (TO)0.f;
+        if (pair_hi) for (int c = lane; c < W; c += 64) { pair_hi[(size_t)row * W + c] = (f16)0.f; pair_lo[(size_t)row * W + c] = (f16)0.f; }
+        else for (int c = lane; c < W; c += 64) x[(size_t)row * W + c] = (TO)0.f;
         return;
     }
     const int crop = row / T, t = row - crop * T;
@@ -432,6 +438,13 @@ __global__ __launch_bounds__(256) void k_embed_lnpre(const float* __restrict__ p
                     *(f16x4*)dst = h4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (float)h4[e];           // what a separate LayerNorm kernel would read back
+                } else if (pair_hi) {
+                    const f16x4 h4 = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+                    const f16x4 l4 = {(f16)(o[0] - (float)h4[0]), (f16)(o[1] - (float)h4[1]), (f16)(o[2] - (float)h4[2]), (f16)(o[3] - (float)h4[3])};
+                    *(f16x4*)(pair_hi + (size_t)row * W + c) = h4;
+                    *(f16x4*)(pair_lo + (size_t)row * W + c) = l4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (float)h4[e] + (float)l4[e];          // what the stream holds from here on
                 } else {
                     *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
                 }
@@ -1008,6 +1021,9 @@ struct vg_vit {
     bool f32_mfma = !(getenv("VG_GEMM_F32_MFMA") && atoi(getenv("VG_GEMM_F32_MFMA")) == 0);    // fp32 tower on the matrix cores
     int gemm_w4 = getenv("VG_GEMM_W4") ? atoi(getenv("VG_GEMM_W4")) : 1;                      // projection GEMMs by k_gemm_f16_w4 (round 6: persistent, 4 waves, assembly K loop); 0: k_gemm_f16_pp64 (a tower uses one family: their LayerNorm partials differ in granularity)
     int n_cu = 0;                    // compute units of the device the handle works on (set at the first launch)
+    bool resid_hl = false;           // the residual stream kept as an fp16 PAIR (EPI_BIAS_RESID_HL; round 6, default for the k_gemm_f16_w4 tower with the folded
+                                     // LayerNorm and the last block on the class rows; VG_VIT_RESID_HL=0: the fp32 stream): 22 bits of the stream, a third less
+                                     // written by out_proj / c_proj -- features 1.8e-4 from the fp32-stream tower's, the same distance to the fp32 tower
     bool resid_h = false;            // opt-in (VG_VIT_RESID16=1, dtype 1, width % 256 == 0): fp16 residual stream like upstream's fp16 run.
                                      // +2.7 % frames/s, 3x the feature error (1.1e-3 vs 3.4e-4 rel. L2): default keeps the fp32 stream
     // optional per-launch timing of the projection GEMMs (bench.py roofline): event pairs on the launch stream
@@ -1477,6 +1493,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                                                         f16* __restrict__ ln_x16 = nullptr, long long* __restrict__ trace = nullptr) {
     constexpr int BM = 256, BN = 256;
     constexpr bool F16OUT = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU;
+    constexpr bool HL = EPI == EPI_BIAS_RESID_HL;            // the residual stream as an fp16 pair (hi = ln_x16, lo = (f16*)resid)
+    constexpr bool L16 = F16OUT || HL;                       // the accumulator-to-feature layout of 16-bit outputs (eight consecutive features per lane)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -1523,7 +1541,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     float ln_mean2[2] = {0.f, 0.f}, ln_rstd2[2] = {0.f, 0.f};
     auto issue_raw = [&](int m0_, int n0_, int lane_) {
         const int r15k = lane_ & 15;
-        if constexpr (F16OUT) {
+        if constexpr (L16) {
             const int ncol = n0_ + wn * 128 + r15k * 8;
             raw_b[0] = *(const float4*)(bias + ncol); raw_b[1] = *(const float4*)(bias + ncol + 4);
             if (LN == 1) { raw_c[0] = *(const float4*)(ln_c1 + ncol); raw_c[1] = *(const float4*)(ln_c1 + ncol + 4); }
@@ -1588,10 +1606,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
     const int lane = lane_t;
     const unsigned c0 = (unsigned)((lane & 7) ^ (lane >> 4));
     const unsigned dv0 = (unsigned)(lane >> 3) * rowb + (c0 << 4), dv1 = (unsigned)(lane >> 3) * rowb + ((c0 ^ 4u) << 4);
-    const unsigned wlm = F16OUT ? 8u : 4u;                                   // feature step per (lane >> 3)
+    const unsigned wlm = L16 ? 8u : 4u;                                      // feature step per (lane >> 3)
     const unsigned dw0 = (unsigned)(lane >> 3) * wlm * rowb + (c0 << 4), dw1 = (unsigned)(lane >> 3) * wlm * rowb + ((c0 ^ 4u) << 4);
-    const unsigned wpo = __builtin_amdgcn_readfirstlane((F16OUT ? 64u : 32u) * rowb);     // odd pieces: r += 8
-    const int wrow0 = (wave >> 1) * 128 + (F16OUT ? (wave & 1) * 4 : (wave & 1) * 64);      // feature of (ni = 4 (w & 1), r = 0)
+    const unsigned wpo = __builtin_amdgcn_readfirstlane((L16 ? 64u : 32u) * rowb);        // odd pieces: r += 8
+    const int wrow0 = (wave >> 1) * 128 + (L16 ? (wave & 1) * 4 : (wave & 1) * 64);         // feature of (ni = 4 (w & 1), r = 0)
     const int r15t = lane & 15, q4t = lane >> 4;
     const unsigned swz = (unsigned)((r15t >> 1) & 7);
     const unsigned xo0 = (unsigned)(wm * 128 + r15t) * 128u + (((unsigned)q4t ^ swz) << 4), xo1 = (unsigned)(wm * 128 + r15t) * 128u + (((unsigned)(4 + q4t) ^ swz) << 4);
@@ -1687,6 +1705,57 @@ __global__ __launch_bounds__(256, 1) void k_gemm_f16_w4(const f16* __restrict__ 
                 }
                 *(f16x8*)(const_cast<char*>(cbase) + (size_t)(mi * 16 + e) * ldc * 2 + loff) = h8;
             });
+        });
+    } else if constexpr (HL) {
+        // The residual stream as an fp16 PAIR, in the 16-bit layout (a lane holds eight consecutive features of a token): x = hi + lo read as
+        // two 16-byte rows, v = x + acc + bias, hi' = f16(v), lo' = f16(v - hi') written as two 16-byte rows; hi' IS the next GEMM's operand.
+        // The row statistics are those of hi' + lo' (what every later reader reconstructs).
+        const float bb[8] = {cur_b[0].x, cur_b[0].y, cur_b[0].z, cur_b[0].w, cur_b[1].x, cur_b[1].y, cur_b[1].z, cur_b[1].w};
+        const unsigned loff = ((unsigned)(4 * q4) * (unsigned)ldc + (unsigned)(r15 * 8)) * 2u;
+        char* hbase = (char*)(ln_x16 + (size_t)urow * ldc + n0 + wn * 128);
+        char* lbase = (char*)((f16*)resid + (size_t)urow * ldc + n0 + wn * 128);
+        constexpr int WIN = 3;                               // mi blocks of the stream in flight (a rolling window: 96 registers; four spilled)
+        f16x8 xh[WIN][4], xl[WIN][4];
+        auto load_block = [&](int mb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const size_t ro = (size_t)(mb * 16 + e) * ldc * 2 + loff;
+                xh[mb % WIN][e] = *(const f16x8*)(hbase + ro);
+                xl[mb % WIN][e] = *(const f16x8*)(lbase + ro);
+            }
+        };
+        load_block(0); load_block(1); load_block(2);
+        w4_for<8>([&](auto mic) {
+            constexpr int mi = decltype(mic)::value;
+            float st_mean[4], st_m2[4];
+            float acc[4][8];
+            w4_acc_block<mi>(acc);
+            w4_for<4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                const size_t ro = (size_t)(mi * 16 + e) * ldc * 2 + loff;
+                const f16x8 ph = xh[mi % WIN][e], pl = xl[mi % WIN][e];
+                f16x8 nh, nl;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = (acc[e][j] + bb[j]) + ((float)ph[j] + (float)pl[j]);
+                    nh[j] = (f16)t;
+                    nl[j] = (f16)(t - (float)nh[j]);
+                    v[j] = (float)nh[j] + (float)nl[j];
+                }
+                *(f16x8*)(hbase + ro) = nh;
+                *(f16x8*)(lbase + ro) = nl;
+                const float mean = w4_row16_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * (1.0f / 128.0f);
+                const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+                const float a4 = v[4] - mean, a5 = v[5] - mean, a6 = v[6] - mean, a7 = v[7] - mean;
+                st_mean[e] = mean;
+                st_m2[e] = w4_row16_sum(((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) + ((a4 * a4 + a5 * a5) + (a6 * a6 + a7 * a7)));
+            });
+            if (mi + WIN < 8) load_block(mi + WIN);          // (this block's registers are free: the next one of the window is requested)
+            const float mean = r15 == 0 ? st_mean[0] : r15 == 1 ? st_mean[1] : r15 == 2 ? st_mean[2] : st_mean[3];
+            const float m2 = r15 == 0 ? st_m2[0] : r15 == 1 ? st_m2[1] : r15 == 2 ? st_m2[2] : st_m2[3];
+            if (r15 < 4)
+                *(LnPartial*)((char*)(ln_stats + (size_t)(urow + mi * 16) * (size_t)(N >> 7) + 2 * tn + wn) + (unsigned)((4 * q4 + r15) * (N >> 7)) * 8u) = LnPartial{mean, m2};
         });
     } else {
         // fp32: lane holds features 64 g + 4 r + j (ni = 4 g + j) of the wave's 128: two float4 per (mi, e)
@@ -1955,6 +2024,10 @@ static int launch_gemm(const vg_vit* cv, const void* X, const void* Wt, const fl
             }
         }
     } closer{v, prof, st, 2.0 * (double)M * (double)N * (double)K, use_pp ? 1 : 0};
+    if constexpr (EPI == EPI_BIAS_RESID_HL) {     // the stream as an fp16 pair: k_gemm_f16_w4's producer epilogue only
+        if (!(LN == 2 && v->dtype == 1 && v->gemm_w4 && use_pp && M % 256 == 0 && K % 64 == 0 && K / 64 >= 4 && resid && ln_x16)) return VG_ERR_ARG;
+        return launch_gemm_w4<EPI, LN>(X, Wt, bias, C, resid, M, N, K, ldc, st, ln_c1, ln_stats, ln_x16);
+    } else
     if constexpr (EPI == EPI_BIAS_RESID_H) {      // fp16 residual stream: only the 256 x 256 kernel implements it
         if (!(use_pp && K % 64 == 0 && K / 64 >= 2)) return VG_ERR_ARG;
         return launch_gemm_pp64<EPI>(X, Wt, bias, C, resid, M, N, K, ldc, st);
@@ -2210,6 +2283,7 @@ int vg_vit_create(vg_vit** out, int width, int layers, int heads, int patch, int
     v->resid_h = dtype == 1 && width % 256 == 0 && getenv("VG_VIT_RESID16");
     const char* fold = getenv("VG_VIT_LN_FOLD");
     v->ln_fold = dtype == 1 && width % 256 == 0 && !v->resid_h && !(fold && atoi(fold) == 0);
+    { const char* hl = getenv("VG_VIT_RESID_HL"); v->resid_hl = v->ln_fold && v->gemm_w4 && v->cls_last && width <= 1024 && !(hl && atoi(hl) == 0); }
 #ifdef VG_DEV
     if (getenv("VG_GEMM_V4")) v->resid_h = v->ln_fold = false;      // (k_gemm_f16 has neither epilogue)
 #endif
@@ -2282,11 +2356,14 @@ int vg_vit_set_weight(vg_vit* v, const char* name, const float* h_data, int64_t 
 // The last block's class-token rows, compacted: hc[c] = h[c * T] (attention output, fp16), xc[c] = x[c * T] (residual stream, fp32);
 // rows n_crops .. Mc - 1 (padding of the GEMM row tile) are zeroed.  One workgroup per row.
 __global__ __launch_bounds__(256) void k_gather_cls(const f16* __restrict__ h, const float* __restrict__ x, f16* __restrict__ hc,
-                                                    float* __restrict__ xc, int n_crops, int T, int W) {
+                                                    float* __restrict__ xc, int n_crops, int T, int W,
+                                                    const f16* __restrict__ pair_hi = nullptr, const f16* __restrict__ pair_lo = nullptr) {
+    // pair_hi / pair_lo: the stream kept as an fp16 pair (EPI_BIAS_RESID_HL) -- the compact rows are fp32 either way
     const int c = blockIdx.x;
     for (int i = threadIdx.x; i < W; i += 256) {
         hc[(size_t)c * W + i] = c < n_crops ? h[(size_t)c * T * W + i] : (f16)0.f;
-        xc[(size_t)c * W + i] = c < n_crops ? x[(size_t)c * T * W + i] : 0.f;
+        if (pair_hi) xc[(size_t)c * W + i] = c < n_crops ? (float)pair_hi[(size_t)c * T * W + i] + (float)pair_lo[(size_t)c * T * W + i] : 0.f;
+        else xc[(size_t)c * W + i] = c < n_crops ? x[(size_t)c * T * W + i] : 0.f;
     }
 }
 
@@ -2387,6 +2464,11 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
     const bool rh = v->resid_h;
     bool ln1_done = false;
     f16* xh = (f16*)x;                // the residual stream lives in the same workspace region, as fp16 when `rh`
+    // the stream as an fp16 pair (VG_VIT_RESID_HL): hi = x16 (what in_proj / c_fc read anyway), lo in the fp32 stream's region; every full-row
+    // residual GEMM is then a folded-LayerNorm producer (the last block runs on the compact fp32 class rows: the same condition as `cls_only`)
+    const bool hl = v->resid_hl && fold && !rh && v->dtype == 1 && L > 1 && W % 256 == 0 &&
+                    pad128(n_crops) * W * 16 + pad128(n_crops) * (W / 64) * 8 <= Mp * (3 * W + 256) * es;
+    f16* xlo = (f16*)x;
     if (rh)
         hipLaunchKernelGGL((k_embed_lnpre<f16>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
                            pos_tab, (const float*)need("ln_pre.weight"),
@@ -2399,7 +2481,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         if (ln1_done && (!lw1 || !lb1)) return VG_ERR_ARG;
         hipLaunchKernelGGL((k_embed_lnpre<float>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, pe, (const float*)need("class_embedding"),
                            pos_tab, (const float*)need("ln_pre.weight"),
-                           (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp, lw1, lb1, ln1_done ? (f16*)h : (f16*)nullptr);
+                           (const float*)need("ln_pre.bias"), x, (int)M, T, W, (int)Mp, lw1, lb1, ln1_done ? (f16*)h : (f16*)nullptr,
+                           hl ? (f16*)x16 : (f16*)nullptr, hl ? xlo : (f16*)nullptr);
     }
     VG_LAUNCH_CHECK();
     for (int l = 0; l < L; ++l) {
@@ -2493,7 +2576,8 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             f16* x16c = (f16*)cb;              cb += Mc * W * 2;
             f16* mlpc = (f16*)cb;              cb += Mc * 4 * W * 2;
             LnPartial* lnc = (LnPartial*)cb;
-            hipLaunchKernelGGL(k_gather_cls, dim3((unsigned)Mc), dim3(256), 0, st, (const f16*)h, (const float*)x, hc, xc, n_crops, T, W);
+            hipLaunchKernelGGL(k_gather_cls, dim3((unsigned)Mc), dim3(256), 0, st, (const f16*)h, (const float*)x, hc, xc, n_crops, T, W,
+                               hl ? (const f16*)x16 : (const f16*)nullptr, hl ? (const f16*)xlo : (const f16*)nullptr);
             VG_LAUNCH_CHECK();
             rc = launch_gemm<EPI_BIAS_RESID, 2>(v, hc, wp[4], (const float*)wp[5], nullptr, xc, (int)Mc, W, W, st, 0, nullptr, lnc, x16c);
             if (rc) return rc;
@@ -2507,6 +2591,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
             return VG_OK;
         }
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st)
+           : hl ? launch_gemm<EPI_BIAS_RESID_HL, 2>(v, h, wp[4], (const float*)wp[5], nullptr, (float*)xlo, (int)Mp, W, W, st, 0, nullptr, lnst, x16)
            : fold ? launch_gemm<EPI_BIAS_RESID, 2>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, lnst, x16, pe, pe_bytes)
                   : launch_gemm<EPI_BIAS_RESID>(v, h, wp[4], (const float*)wp[5], nullptr, x, (int)Mp, W, W, st, 0, nullptr, nullptr, nullptr, pe, pe_bytes);
         if (rc) return rc;
@@ -2524,6 +2609,7 @@ int vg_vit_encode(vg_vit* v, const void* d_crops, int input_kind, int n_crops, v
         if (rc) return rc;
         // the last block's c_proj has no LayerNorm consumer in a GEMM (ln_post reads the class token's fp32 row in k_head)
         rc = rh ? launch_gemm<EPI_BIAS_RESID_H>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st)
+           : (hl && l + 1 < L) ? launch_gemm<EPI_BIAS_RESID_HL, 2>(v, mlp, wp[10], (const float*)wp[11], nullptr, (float*)xlo, (int)Mp, W, 4 * W, st, 0, nullptr, lnst, x16)
            : (fold && l + 1 < L) ? launch_gemm<EPI_BIAS_RESID, 2>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st, 0, nullptr, lnst, x16, pe, pe_bytes)
                   : launch_gemm<EPI_BIAS_RESID>(v, mlp, wp[10], (const float*)wp[11], nullptr, x, (int)Mp, W, 4 * W, st, 0, nullptr, nullptr, nullptr, pe, pe_bytes);
         if (rc) return rc;
