@@ -110,11 +110,13 @@ def kinds_of(rows):
             out.update({d: 'in_proj' for d in full})
         elif (epi, ln) == (1, 1):
             out.update({d: 'c_fc' for d in full})
-        elif (epi, ln) == (2, 2):
+        elif (epi, ln) == (5, 2) or ((epi, ln) == (2, 2) and (5, 2) not in by_inst):
+            # the residual GEMMs over all rows: (5, 2) = the stream as an fp16 pair (round 6; then (2, 2) only runs on the last block's class rows).
             # grids differ between frames (crop counts) but a frame's out_proj and c_proj have the same grid and alternate
             for i, d in enumerate(full):
                 out[d] = 'out_proj' if i % 2 == 0 else 'c_proj'
     return out
+PAIR_STREAM = False
 SHAPES = {'in_proj': (2304, 768), 'out_proj': (768, 768), 'c_fc': (3072, 768), 'c_proj': (768, 3072)}
 def algorithmic_bytes(kind, M):
     N, K = SHAPES[kind]
@@ -122,8 +124,11 @@ def algorithmic_bytes(kind, M):
     rd = M * K * 2 + N * K * 2
     if kind in ('in_proj', 'c_fc'):
         return rd + M * 8 * (K // (128 if DOM == 'k_gemm_f16_w4' else 256)), M * N * 2                      # + the row statistics; fp16 output
+    if PAIR_STREAM:
+        return rd + M * N * 4, M * N * 4 + M * 8 * 2                                                          # the stream as an fp16 pair: 2 + 2 bytes read, 2 + 2 written, statistics
     return rd + M * N * 4, M * N * 4 + M * N * 2 + M * 8 * (2 if DOM == 'k_gemm_f16_w4' else 1)                # fp32 residual read; residual + fp16 copy + statistics written
 trace_rows = dispatch_rows(os.path.join(src, 'trace', 'bench_kernel_trace.csv'))
+PAIR_STREAM = any(template_args(r['name']) == (5, 2) for r in trace_rows.values())
 fetch_rows = dispatch_rows(os.path.join(src, 'fetch', 'bench_counter_collection.csv'))
 write_rows = dispatch_rows(os.path.join(src, 'write', 'bench_counter_collection.csv'))
 sq_rows = dispatch_rows(sq_path)
