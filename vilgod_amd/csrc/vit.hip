@@ -1966,8 +1966,12 @@ static int launch_gemm_w4(const void* X, const void* Wt, const float* bias, void
     { static const int cap = getenv("VG_GEMM_W4_GRID") ? atoi(getenv("VG_GEMM_W4_GRID")) : 0; if (cap >= 8 && grid > cap) grid = cap; }   // experiment: two encodes on disjoint CU halves
 #endif
     grid = (grid + 7) / 8 * 8;
+    int cwt = gemm_chunk_tiles_256(ntn);
+#ifdef VG_DEV
+    if (getenv("VG_GEMM_CW")) { const int c = atoi(getenv("VG_GEMM_CW")); if (c >= 1 && ntn % c == 0) cwt = c; }      // tile-order sweep (development build; read per launch)
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const f16*)X, (const f16*)Wt, bias, C, resid, M, N, K,
-                       ldc, gemm_chunk_tiles_256(ntn), ln_c1, ln_stats, ln_x16, trace);
+                       ldc, cwt, ln_c1, ln_stats, ln_x16, trace);
     VG_LAUNCH_CHECK();
     return VG_OK;
 }
